@@ -1,0 +1,53 @@
+"""Deterministic test cases shared by the fixture generator (container) and the tests (anywhere).
+
+Every case is fully described by seeds: weights come from ``oracle.fourm_oracle.seeded_state_dict``,
+batches from ``synthetic_mod_dict``; the fixtures hold only what the upstream model produced.
+"""
+from oracle import fourm_oracle as O
+
+
+def micro_mods():
+    """Seven small modalities covering every embedding kind (grid tokens, learned-position grid
+    tokens, pixels, sequences, dense-embedding sequences)."""
+    return [
+        O.ModSpec("cap", "seq", vocab=100, n_pos=12),
+        O.ModSpec("det", "seq", vocab=100, n_pos=10),
+        O.ModSpec("rgb@32", "patch", n_pos=16, patch=8, in_dec=False),
+        O.ModSpec("t5", "seq_emb", n_pos=6, orig_dim=24, in_dec=False),
+        O.ModSpec("tok_a@32", "tok", vocab=64, n_pos=16, patch=8),
+        O.ModSpec("tok_b@32", "tok", vocab=48, n_pos=16, patch=8),
+        O.ModSpec("tok_g", "tok", vocab=40, n_pos=4, patch=16),
+    ]
+
+
+def _micro(**kw):
+    base = dict(dim=128, enc_depth=2, dec_depth=2, heads=2, mods=micro_mods())
+    base.update(kw)
+    return O.TrunkCfg(**base)
+
+
+CASES = {
+    # name: (cfg factory, options)
+    "micro_swiglu": dict(cfg=lambda: _micro(), B=3, N=20, M=18, bud=(20, 18)),
+    "micro_pad": dict(cfg=lambda: _micro(), B=4, N=24, M=24, bud=(17, 15), loss_type="token",
+                      no_target=("tok_b@32",), seed=3),
+    "micro_gelu": dict(cfg=lambda: _micro(gated=False, act="gelu", qkv_bias=True, proj_bias=True, mlp_bias=True,
+                                          registers=2, causal=True),
+                       B=3, N=20, M=18, bud=(20, 18), norm_bias=True, share_embedding=False, seed=5),
+    "micro_qknorm": dict(cfg=lambda: _micro(qk_norm=True, sep=False), B=2, N=16, M=16, bud=(16, 16), seed=7),
+    # BASELINE.json configs[0]: 4M-Ti mod7, one masked-modeling step, seq_len 128+128, batch 2
+    "ti_mod7": dict(cfg=lambda: O.named_cfg("tiny", O.mod7_specs()), B=2, N=128, M=128, bud=(128, 128), seed=0),
+}
+
+
+def build_case(name: str):
+    c = CASES[name]
+    cfg = c["cfg"]()
+    seed = c.get("seed", 1)
+    learned = ("tok_g",) if any(m.name == "tok_g" for m in cfg.mods) else ()
+    share = c.get("share_embedding", True)
+    nb = c.get("norm_bias", False)
+    sd = O.seeded_state_dict(cfg, seed=seed, share_embedding=share, learned_pos=learned, norm_bias=nb)
+    md = O.synthetic_mod_dict(cfg, c["B"], c["bud"][0], c["bud"][1], seed=seed, no_target=c.get("no_target", ()))
+    return dict(cfg=cfg, sd=sd, mod_dict=md, N=c["N"], M=c["M"], loss_type=c.get("loss_type", "mod"),
+                order_seed=seed, share_embedding=share, norm_bias=nb, learned_pos=learned)
