@@ -1,0 +1,233 @@
+/* C ABI of libfourm_hip.so — the MI355X (gfx950) kernels behind the 4M training hot path.
+ *
+ * The upstream project (apple/ml-4m) is pure PyTorch and has no FFI of its own; every entry point
+ * below therefore names the chain of upstream torch ops it replaces (file:line under
+ * /root/reference).  INTEGRATION.md shows the ctypes binding a maintainer would add upstream.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless stated otherwise; the caller owns all memory,
+ *     including workspaces; no function allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream), 0 = null stream;
+ *   - bf16 buffers are raw uint16 bit patterns; leading dimensions (ld*) are in ELEMENTS;
+ *   - return value: 0 = launched, <0 = rejected (-1 bad argument, -2 launch failure); the reason is
+ *     available from fm_last_error() (thread-local, valid until the next call on that thread);
+ *   - functions are re-entrant; one host thread per device is the intended use.
+ */
+#ifndef FOURM_HIP_H
+#define FOURM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FM_ABI_VERSION 1
+int fm_abi_version(void);
+const char* fm_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM (bf16 operands, fp32 accumulate on the MFMA matrix cores)
+ * ---------------------------------------------------------------------------------------------- */
+enum fm_epilogue {
+    FM_EPI_BF16 = 0,     /* out(bf16)  = bf16(acc + bias)                                            */
+    FM_EPI_GELU = 1,     /* out(bf16)  = gelu(bf16(acc + bias)); out2(bf16, optional) = pre-activation */
+    FM_EPI_RESIDUAL = 2, /* out(f32)   = res(f32) + bf16(acc + bias)      (out may alias res)         */
+    FM_EPI_SWIGLU = 3,   /* W -> g, W2 -> u: out(bf16)[m][h] = silu(g)*u; out2(bf16)[m][h] = g, [m][Hp+h] = u */
+    FM_EPI_F32 = 4       /* out(f32)   = acc + bias                                                   */
+};
+
+typedef struct fm_gemm_group {  /* one entry per row segment (modality) in grouped mode */
+    const void* W;              /* NT: weight-like operand of this group; TN: unused               */
+    void* out;                  /* TN: fp32 accumulator of this group;    NT: unused               */
+    int32_t N, K, ldw, pad_;
+} fm_gemm_group;
+
+/* out[m][n] = sum_k X[m][k] * W[n][k]  (+ epilogue).
+ * Replaces nn.Linear forward under bf16 autocast — fourm/models/fm_utils.py:116-126,137-144,155-157,
+ * 190-194 — and, with a transposed weight shadow, its input gradient.
+ * K % 64 == 0 (zero padded), ldw/ldx % 8 == 0, N % 4 == 0 (any N for FM_EPI_SWIGLU), ldo % 4 == 0.
+ * Grouped mode (groups != NULL): rows of X are segmented in 128-row tiles, tile_group[tile] selects
+ * the group (or -1 = skip); W/N/K/ldw come from the group record, max_N bounds the launch. */
+typedef struct fm_gemm_nt_args {
+    const void* W; const void* W2; const void* X;
+    void* out; void* out2; const void* res; const void* bias; const void* bias2;
+    int32_t M, N, K, ldw, ldx, ldo, ldo2, ldr, Hp, epilogue;
+    const fm_gemm_group* groups; const int32_t* tile_group; int32_t max_N, pad_;
+} fm_gemm_nt_args;
+int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
+
+/* out[n][k] += sum_r A[r][n] * B[r][k]   (fp32 atomic accumulation, reduction split over blocks).
+ * Replaces the weight-gradient matmul autograd runs for nn.Linear (dW = dY^T X).
+ * R % 64 == 0 with zero rows beyond the live ones; lda/ldb % 8 == 0; a_cols/b_cols = number of
+ * readable columns of A/B (0 = lda/ldb).  splits <= 0 picks a split count; force_tr: -1 = library
+ * default, 0 = 2-byte LDS gathers, 1 = ds_read_b64_tr_b16 transpose reads.
+ * Grouped mode: group g reduces rows [seg_start[g], seg_start[g] + roundup64(seg_count[g])) into
+ * groups[g].out with N = groups[g].N. */
+typedef struct fm_gemm_tn_args {
+    const void* A; const void* B; void* out;
+    int32_t R, N, K, lda, ldb, ldo, a_cols, b_cols, splits, force_tr;
+    const fm_gemm_group* groups; const int32_t* seg_start; const int32_t* seg_count;
+    int32_t n_groups, max_N, max_R, pad_;
+} fm_gemm_tn_args;
+int fm_gemm_tn(const fm_gemm_tn_args* args, void* stream);
+void fm_set_tn_transpose_read(int on);
+int fm_get_tn_transpose_read(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (eps inside the sqrt, fp32 statistics) — F.layer_norm as used by
+ * fourm/models/fm_utils.py:93-108 (and nn.LayerNorm in the *_gelu factories, fm.py:853).
+ * x: f32 (R, D); y: bf16 (default) or f32; b may be NULL; mean/rstd (R) f32 optional outputs.
+ * row_map (optional): y row r is written to row row_map[r] (skipped when negative).
+ * D % 4 == 0, D <= 2048. */
+int fm_layernorm_fwd(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int y_is_f32,
+                     void* mean, void* rstd, const int32_t* row_map, int R, int D, float eps, void* stream);
+/* dx(f32) = dres + LN'(dy);  dw += sum_r dy*xhat;  db += sum_r dy  (fp32 atomics; dw/db may be NULL).
+ * dy: bf16, read at row dy_row_map[r] when a map is given (negative = zero gradient).
+ * dres (optional, may alias dx) is the residual-stream gradient flowing around the norm.
+ * dx_bf16 (optional) receives a bf16 copy of dx (operand of the next GEMM). */
+int fm_layernorm_bwd(const void* dy, int lddy, const int32_t* dy_row_map, const void* x, int ldx, const void* w,
+                     const void* mean, const void* rstd, const void* dres, void* dx, int lddx, void* dx_bf16,
+                     int lddxbf, void* dw, void* db, int R, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Masked multi-head attention, head_dim 64 — fourm/models/fm_utils.py:160-180 (Attention) and
+ * :197-219 (CrossAttention).  Element (b, t, h, d) of Q lives at Q[(b*Nq + t)*ldq + h*64 + d]
+ * (K, V with Nk; O, dO, dQ like Q; dK, dV like K), so q/k/v can alias one fused qkv buffer.
+ * A blocked score is replaced by -finfo(bf16).max (upstream semantics: fully blocked rows attend
+ * uniformly).  stat_m / stat_l: (B, H, Nq) f32 row max and row sum, written by fwd, read by bwd. */
+enum fm_mask_kind {
+    FM_MASK_NONE = 0,
+    FM_MASK_KEYPAD = 1,   /* kpad (B, Nk) uint8, 1 = blocked                  — fm.py:388                   */
+    FM_MASK_DECODER = 2,  /* k >= cs[b][q] (or k > q if causal)  ||  modq[b][q] != modk[b][k] — fm.py:440-475 */
+    FM_MASK_DENSE = 3     /* dense (B, Nq, Nk) uint8, 1 = blocked                                            */
+};
+typedef struct fm_attn_args {
+    const void* Q; const void* K; const void* V; void* O;
+    void* stat_m; void* stat_l;
+    int32_t ldq, ldk, ldv, ldo;
+    int32_t B, H, Nq, Nk, head_dim, mask_kind;
+    float scale; int32_t causal;
+    const void* kpad; const int32_t* cs; const int16_t* modq; const int16_t* modk; const void* dense;
+    /* backward only */
+    const void* dO; void* dQ; void* dK; void* dV;
+    int32_t lddo, lddq, lddk, lddv;
+    int32_t force_tr, pad_;   /* -1 = library default, 0 = 2-byte LDS gathers, 1 = transpose reads */
+} fm_attn_args;
+int fm_attn_fwd(const fm_attn_args* args, void* stream);
+int fm_attn_bwd(const fm_attn_args* args, void* stream);   /* Nq, Nk <= 256 */
+void fm_set_attn_transpose_read(int on);
+int fm_get_attn_transpose_read(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token selection + embedding  (encoder: fm.py:245-277,338-390 + encoder_embeddings.py forward()s;
+ * decoder: fm.py:279-336,392-438 + decoder_embeddings.py forward_embed()s)
+ * ---------------------------------------------------------------------------------------------- */
+#define FM_MAX_MODS 24
+enum fm_mod_kind {
+    FM_KIND_TOK = 0,      /* grid of discrete tokens      (ImageToken{En,De}coderEmbedding)   */
+    FM_KIND_PATCH = 1,    /* raw pixels, patch projection (ImageEncoderEmbedding)             */
+    FM_KIND_SEQ = 2,      /* token sequence               (Sequence{En,De}coderEmbedding)     */
+    FM_KIND_SEQ_EMB = 3   /* dense-embedding sequence     (SequenceEmbEncoderEmbedding)       */
+};
+typedef struct fm_mod_desc {
+    const void* ids;       /* TOK/SEQ: int64 or int32 ids; PATCH: f32 pixels (C,H,W); SEQ_EMB: f32 (n_pos, orig_dim) */
+    const void* mask;      /* uint8 (B, mask_stride): input_mask (encoder) / target_mask (decoder), 1 = masked        */
+    const void* dam;       /* int32 (B, mask_stride): decoder_attention_mask (decoder only)                           */
+    const void* table;     /* f32 (vocab, D) token_emb.weight                                                         */
+    const void* pos;       /* f32 (pos_rows, D) pos_emb                                                               */
+    const void* mod_emb;   /* f32 (D)                                                                                 */
+    const void* proj_bias; /* SEQ_EMB: f32 (D) emb_proj.bias                                                          */
+    int32_t L;             /* positions contributed to the concatenation (decoder sequences: tensor_len - 1)         */
+    int32_t kind, ids_are_i64, mod_id;
+    int32_t max_len;       /* decoder sequences: position ids >= max_len collapse to 0 (decoder_embeddings.py:128)   */
+    int32_t shifted;       /* decoder sequences: input j, target j+1, mask[j] | mask[j+1]   (fm.py:309-319)           */
+    int32_t mask_stride, id_stride;   /* elements per sample in mask/dam resp. ids                                    */
+    int32_t patch, channels, grid_w, orig_dim;
+    int32_t head_index;    /* decoder: index of this modality's head (stable, independent of the shuffled order)    */
+    int32_t pad_;
+} fm_mod_desc;
+
+typedef struct fm_select_desc {
+    fm_mod_desc mods[FM_MAX_MODS];   /* in concatenation order */
+    int32_t n_mods, batch, dim, n_keep, n_reg, total_len, is_decoder, pad_;
+    const void* reg_tokens;  /* f32 (n_reg, D)                      */
+    const void* mask_token;  /* f32 (D), decoder                    */
+    /* outputs, Nt = n_reg + n_keep rows per sample */
+    void* tokens;       /* f32 (B, Nt, D)  gathered token rows (zero where masked)                 */
+    void* emb;          /* f32 (B, Nt, D)  pos_emb + mod_emb (zero where masked)                   */
+    void* x0;           /* f32 (B, Nt, D)  optional: tokens + emb                                  */
+    void* out_mask;     /* uint8 (B, Nt)   1 = masked slot                                         */
+    void* out_mod;      /* int16 (B, Nt)   modality id, -1 where masked / register                 */
+    void* slot_mod;     /* int32 (B, Nt)   index into mods[] (-1 masked, -2 register)              */
+    void* slot_src;     /* int32 (B, Nt)   token id (TOK/SEQ) or position inside the modality      */
+    void* slot_pos;     /* int32 (B, Nt)   pos_emb row used                                        */
+    void* target_ids;   /* int64 (B, Nt)   decoder                                                 */
+    void* out_cs;       /* int32 (B, Nt)   decoder: cumsum of the kept decoder_attention_mask      */
+    void* out_mod_pre;  /* int16 (B, Nt)   decoder: modality id *before* pads are set to -1        */
+    void* out_mod_index;/* int32 (B, Nt)   decoder: head index, -1 where masked                    */
+    void* patch_rows;   /* bf16 (B*Nt, patch_ld)  optional: pixels of the kept PATCH slots, zero elsewhere  */
+    void* seqemb_rows;  /* bf16 (B*Nt, seqemb_ld) optional: embeddings of the kept SEQ_EMB slots            */
+    int32_t patch_ld, seqemb_ld;
+} fm_select_desc;
+int fm_select_embed(const fm_select_desc* desc, void* stream);
+
+typedef struct fm_embed_bwd_mod {
+    void* d_table;      /* f32 (vocab, D) or NULL */
+    void* d_pos;        /* f32 (pos_rows, D) for learned position embeddings, NULL for fixed sin-cos */
+    void* d_mod_emb;    /* f32 (D) */
+    void* d_proj_bias;  /* SEQ_EMB: f32 (D) */
+    int32_t kind, has_padding_idx, padding_idx, pad_;
+} fm_embed_bwd_mod;
+typedef struct fm_embed_bwd_desc {
+    fm_embed_bwd_mod mods[FM_MAX_MODS];
+    const void* dx;          /* f32 (B, Nt, lddx): gradient w.r.t. tokens + emb */
+    const void* slot_mod; const void* slot_src; const void* slot_pos;
+    void* d_mask_token;      /* decoder */
+    void* d_reg_tokens;      /* encoder, (n_reg, D) */
+    int32_t n_mods, batch, dim, Nt, lddx, is_decoder;
+} fm_embed_bwd_desc;
+int fm_embed_bwd(const fm_embed_bwd_desc* desc, void* stream);
+
+/* dense (B, M, M) uint8 mask from the compressed form (FourM.adapt_decoder_attention_mask, fm.py:440-475) */
+int fm_dense_decoder_mask(const int32_t* cs, const int16_t* mod, void* out, int B, int M, int causal, int use_cs,
+                          int use_sep, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Heads: segment rows by modality, cross-entropy  (fm.py:573-637)
+ * ---------------------------------------------------------------------------------------------- */
+enum fm_loss_type { FM_LOSS_MOD = 0, FM_LOSS_TOKEN = 1 };
+/* Buckets rows 0..R-1 by head_of_row (-1 = no head) into 128-row-aligned segments of a padded row
+ * space of Rp rows (Rp % 128 == 0, Rp >= roundup128(R) + 128*(n_heads-1)).  perm[pr] = source row or
+ * -1; row_to_padded[r] = padded row or -1; tile_group[pr/128] = head or -1. */
+int fm_segment_rows(const int32_t* head_of_row, int R, int n_heads, int32_t* seg_start, int32_t* seg_count,
+                    int32_t* perm, int32_t* row_to_padded, int32_t* tile_group, int Rp, void* stream);
+int fm_gather_rows(const void* src, int ld_src, const int32_t* perm, void* dst, int ld_dst, int Rp, int D, void* stream);
+/* logits: bf16 (Rp, ldl) produced by the grouped fm_gemm_nt.  Writes row_loss (Rp) f32, head_loss
+ * (n_heads) f32 and total_loss (1) f32.  With write_grad the logits are replaced in place by
+ * d(total)/d(logits) * grad_scale[0] (bf16; pad rows and columns up to roundup64(vocab) zeroed). */
+int fm_cross_entropy(void* logits, int ldl, const int32_t* perm, const int32_t* tile_group, const int64_t* target_ids,
+                     const int32_t* vocab, const int32_t* seg_start, const int32_t* seg_count, const void* grad_scale,
+                     int loss_type, int n_heads, int Rp, int max_vocab, void* row_loss, void* head_loss, void* total_loss,
+                     int write_grad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise / reductions
+ * ---------------------------------------------------------------------------------------------- */
+int fm_swiglu_bwd(const void* da, int ldda, const void* gu, int ldgu, void* dgu, int lddgu, int R, int H, int Hp, void* stream);
+int fm_gelu_bwd(const void* dh, int lddh, const void* pre, int ldp, void* dpre, int lddp, int R, int H, int Hp, void* stream);
+/* bf16 weight shadows: dst[r][c] = src[r][c] (pad columns zero) / dst[c][r] = src[r][c] (pad columns zero) */
+int fm_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, void* stream);
+int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, void* stream);
+int fm_colsum(const void* dy, int ldy, void* db, int R, int N, void* stream);            /* db[n] += sum_r dy[r][n] */
+int fm_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream);
+/* torch.optim.AdamW update on a contiguous fp32 range (fourm/utils/optim_factory.py:239-240);
+ * grad_mult: optional device scalar multiplied into the gradient (clipping). */
+int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
+             float weight_decay, int64_t step, const void* grad_mult, void* stream);
+int fm_sumsq(const void* x, int64_t n, void* out, void* stream);                         /* out[0] += sum x^2 */
+int fm_clip_coef(const void* sumsq, float max_norm, void* norm_out, void* coef_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOURM_HIP_H */

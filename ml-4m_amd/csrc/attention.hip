@@ -1,0 +1,470 @@
+// Masked multi-head attention, forward and backward, head_dim = 64 (every named 4M config), gfx950.
+//
+// Replaces  q@k^T * scale -> masked_fill(-finfo.max) -> softmax -> @v  of
+// fourm/models/fm_utils.py:160-180 (self) and :197-219 (cross) and the autograd graph behind them.
+//
+// Mask semantics are upstream's: a blocked score is *replaced by* -finfo(bf16).max (not -inf), so a
+// fully blocked query row attends uniformly to all keys.  Mask kinds:
+//   FM_MASK_NONE     nothing blocked
+//   FM_MASK_KEYPAD   blocked[b][q][k] = kpad[b][k]                              (fm.py:388, (B,1,N) mask)
+//   FM_MASK_DECODER  blocked[b][q][k] = k >= cs[b][q]  ||  mod[b][q] != mod[b][k]   (fm.py:440-475,
+//                    cs = cumsum of the compressed decoder_attention_mask; either term can be disabled)
+//   FM_MASK_DENSE    blocked[b][q][k] = dense[b][q][k]                           (arbitrary (B,n1,n2) bool)
+//
+// Scores are computed transposed (S^T = K Q^T) so that a lane owns one query: the online-softmax
+// statistics are lane-local and P^T feeds the PV MFMA straight from registers.  V (and, in the
+// backward, K / Q / dO) are consumed "column-wise" from row-major LDS tiles through lds_col_frag.
+#include "common.h"
+#include "fourm_hip.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int ROWB = 128;                       // bytes per LDS row (64 bf16)
+constexpr float NEG_FILL = -3.3895313892515355e38f;   // -finfo(bfloat16).max
+
+struct AttnArgs {
+    const bf16_t* Q; const bf16_t* K; const bf16_t* V; bf16_t* O;
+    float* stat_m; float* stat_l;
+    int ldq, ldk, ldv, ldo;
+    int B, H, Nq, Nk;
+    float scale;
+    int mask_kind;
+    const uint8_t* kpad;          // (B, Nk)
+    const int32_t* cs;            // (B, Nq)   or null (no cumsum term)
+    const int16_t* modq;          // (B, Nq)   or null (no modality term)
+    const int16_t* modk;          // (B, Nk)
+    const uint8_t* dense;         // (B, Nq, Nk)
+    int causal;                   // FM_MASK_DECODER: use k > q instead of the cumsum rule
+    // backward only
+    const bf16_t* dO; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
+    int lddo, lddq, lddk, lddv;
+};
+
+__device__ __forceinline__ const char* tile_addr(const char* tile, int row, int col) {
+    return tile + row * ROWB + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2;
+}
+
+// copy `rows` x 64 bf16 (row stride ld elements) into a swizzled LDS tile; rows >= limit are clamped
+template <int NWAVES>
+__device__ __forceinline__ void stage_rows(const bf16_t* src, int ld, int row0, int limit, int rows, char* tile, int wave, int lane) {
+    for (int p = wave; p < rows / 8; p += NWAVES) {
+        const int t = p * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((t >> 1) & 7);
+        int r = row0 + t;
+        r = r < limit ? r : limit - 1;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src + (size_t)r * ld + lc * 8), LDS_PTR(tile + p * 8 * ROWB), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int kk, int fhi) {
+    return *(const bf16x8_t*)(tile + row * ROWB + ((((kk * 2 + fhi) ^ ((row >> 1) & 7))) << 4));
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const float* p) {
+    union { bf16x8_t v; uint32_t u[4]; } x;
+    x.u[0] = pack2bf(p[0], p[1]); x.u[1] = pack2bf(p[2], p[3]); x.u[2] = pack2bf(p[4], p[5]); x.u[3] = pack2bf(p[6], p[7]);
+    return x.v;
+}
+
+__device__ __forceinline__ bool blocked_qk(const AttnArgs& a, int b, int q, int k, int csq, int mq, int mk, bool kp) {
+    switch (a.mask_kind) {
+        case FM_MASK_KEYPAD: return kp;
+        case FM_MASK_DECODER: {
+            bool blk = false;
+            if (a.causal) blk = k > q;
+            else if (a.cs) blk = k >= csq;
+            if (a.modq) blk = blk || (mq != mk);
+            return blk;
+        }
+        case FM_MASK_DENSE: return a.dense[((size_t)b * a.Nq + q) * a.Nk + k] != 0;
+        default: return false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid (ceil(Nq/128), H, B), 4 waves x 32 queries, keys in tiles of 64 with online softmax
+// ------------------------------------------------------------------------------------------------
+template <bool TR>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    constexpr int KT = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [2 buffers][K tile 8 KB | V tile 8 KB] then per-buffer key metadata
+    char* tiles = smem;
+    int16_t* kmod_l = (int16_t*)(smem + 2 * 2 * KT * ROWB);      // [2][64]
+    uint8_t* kpad_l = (uint8_t*)(kmod_l + 2 * KT);               // [2][64]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fhi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q = q0 + (lane & 31);
+    const int qc = q < a.Nq ? q : a.Nq - 1;
+
+    const bf16_t* Qb = a.Q + (size_t)b * a.Nq * a.ldq + h * HD;
+    const bf16_t* Kb = a.K + (size_t)b * a.Nk * a.ldk + h * HD;
+    const bf16_t* Vb = a.V + (size_t)b * a.Nk * a.ldv + h * HD;
+
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(Qb + (size_t)qc * a.ldq + (kk * 2 + fhi) * 8);
+    int csq = 0, mq = 0;
+    if (a.mask_kind == FM_MASK_DECODER) {
+        if (a.cs) csq = a.cs[(size_t)b * a.Nq + qc];
+        if (a.modq) mq = a.modq[(size_t)b * a.Nq + qc];
+    }
+
+    auto stage = [&](int t, int buf) {
+        char* kt = tiles + buf * 2 * KT * ROWB;
+        stage_rows<4>(Kb, a.ldk, t * KT, a.Nk, KT, kt, wave, lane);
+        stage_rows<4>(Vb, a.ldv, t * KT, a.Nk, KT, kt + KT * ROWB, wave, lane);
+        if (threadIdx.x < KT) {
+            const int k = t * KT + threadIdx.x;
+            const int kc = k < a.Nk ? k : a.Nk - 1;
+            kmod_l[buf * KT + threadIdx.x] = (a.mask_kind == FM_MASK_DECODER && a.modk) ? a.modk[(size_t)b * a.Nk + kc] : (int16_t)0;
+            kpad_l[buf * KT + threadIdx.x] = (a.mask_kind == FM_MASK_KEYPAD) ? a.kpad[(size_t)b * a.Nk + kc] : (uint8_t)0;
+        }
+    };
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int NT = (a.Nk + KT - 1) / KT;
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < NT; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < NT) stage(t + 1, buf ^ 1);
+        const char* kt = tiles + buf * 2 * KT * ROWB;
+        const char* vt = kt + KT * ROWB;
+
+        // ---- S^T = K Q^T for the 64 keys of this tile ----------------------------------------
+        f32x16_t st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, kb * 32 + (lane & 31), kk, fhi), qf[kk], st[kb], 0, 0, 0);
+        }
+        // ---- mask + running max ---------------------------------------------------------------
+        float p[2][16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                const int k = t * KT + kl;
+                float s = bfround(bfround(st[kb][r]) * a.scale);
+                if (a.mask_kind != FM_MASK_NONE) {
+                    const bool blk = blocked_qk(a, b, qc, k < a.Nk ? k : a.Nk - 1, csq, mq, kmod_l[buf * KT + kl], kpad_l[buf * KT + kl] != 0);
+                    s = blk ? NEG_FILL : s;
+                }
+                s = k < a.Nk ? s : -INFINITY;
+                p[kb][r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);     // first tile: exp(-inf) = 0
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[kb][r] = __expf(p[kb][r] - m_new);
+                psum += p[kb][r];
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        // ---- O^T += V^T P^T ---------------------------------------------------------------------
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t pb = pack8(&p[kb][8 * s]);
+                const int rA = kb * 32 + s * 16 + 4 * fhi;
+#pragma unroll
+                for (int df = 0; df < 2; ++df) {
+                    const bf16x8_t vf = lds_col_frag<TR>([&](int r, int c) { return tile_addr(vt, r, c); }, rA, rA + 8, df * 32);
+                    o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o[df], 0, 0, 0);
+                }
+            }
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q < a.Nq) {
+        bf16_t* orow = a.O + ((size_t)b * a.Nq + q) * a.ldo + h * HD;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = df * 32 + 8 * g + 4 * fhi;
+                *(uint2*)(orow + d) = make_uint2(pack2bf(o[df][4 * g] * inv, o[df][4 * g + 1] * inv),
+                                                 pack2bf(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv));
+            }
+        if (fhi == 0 && a.stat_m) {
+            const size_t si = ((size_t)b * a.H + h) * a.Nq + q;
+            a.stat_m[si] = m_run;
+            a.stat_l[si] = l_tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: one workgroup per (b, h); Q, K, V, dO of that head live in LDS (Nq, Nk <= 256).
+//   pass A  (a wave owns 32 keys, loops over queries)   -> dK, dV
+//   pass B  (a wave owns 32 queries, loops over keys)   -> dQ
+// S and dP are recomputed in both passes, so no atomics and no register-tile transposes.
+// ------------------------------------------------------------------------------------------------
+template <bool TR>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
+    char* Ql = smem;
+    char* dOl = Ql + NqP * ROWB;
+    char* Kl = dOl + NqP * ROWB;
+    char* Vl = Kl + NkP * ROWB;
+    float* m_l = (float*)(Vl + NkP * ROWB);
+    float* linv_l = m_l + NqP;
+    float* delta_l = linv_l + NqP;
+    int32_t* cs_l = (int32_t*)(delta_l + NqP);
+    int16_t* modq_l = (int16_t*)(cs_l + NqP);
+    int16_t* modk_l = modq_l + NqP;
+    uint8_t* kpad_l = (uint8_t*)(modk_l + NkP);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fhi = lane >> 5;
+    const int b = blockIdx.y, h = blockIdx.x;
+
+    const bf16_t* Qb = a.Q + (size_t)b * a.Nq * a.ldq + h * HD;
+    const bf16_t* Kb = a.K + (size_t)b * a.Nk * a.ldk + h * HD;
+    const bf16_t* Vb = a.V + (size_t)b * a.Nk * a.ldv + h * HD;
+    const bf16_t* Ob = a.O + (size_t)b * a.Nq * a.ldo + h * HD;
+    const bf16_t* dOb = a.dO + (size_t)b * a.Nq * a.lddo + h * HD;
+
+    stage_rows<4>(Qb, a.ldq, 0, a.Nq, NqP, Ql, wave, lane);
+    stage_rows<4>(dOb, a.lddo, 0, a.Nq, NqP, dOl, wave, lane);
+    stage_rows<4>(Kb, a.ldk, 0, a.Nk, NkP, Kl, wave, lane);
+    stage_rows<4>(Vb, a.ldv, 0, a.Nk, NkP, Vl, wave, lane);
+    for (int q = wave; q < NqP; q += 4) {
+        float dl = 0.f;
+        if (q < a.Nq) dl = bf2f(Ob[(size_t)q * a.ldo + lane]) * bf2f(dOb[(size_t)q * a.lddo + lane]);
+        dl = wave_sum(dl);
+        if (lane == 0) {
+            const size_t si = ((size_t)b * a.H + h) * a.Nq + (q < a.Nq ? q : 0);
+            delta_l[q] = dl;
+            m_l[q] = q < a.Nq ? a.stat_m[si] : 0.f;
+            linv_l[q] = q < a.Nq ? 1.0f / a.stat_l[si] : 0.f;
+            cs_l[q] = (a.mask_kind == FM_MASK_DECODER && a.cs && q < a.Nq) ? a.cs[(size_t)b * a.Nq + q] : 0;
+            modq_l[q] = (a.mask_kind == FM_MASK_DECODER && a.modq && q < a.Nq) ? a.modq[(size_t)b * a.Nq + q] : (int16_t)0;
+        }
+    }
+    for (int k = threadIdx.x; k < NkP; k += 256) {
+        const int kc = k < a.Nk ? k : a.Nk - 1;
+        modk_l[k] = (a.mask_kind == FM_MASK_DECODER && a.modk) ? a.modk[(size_t)b * a.Nk + kc] : (int16_t)0;
+        kpad_l[k] = (a.mask_kind == FM_MASK_KEYPAD) ? a.kpad[(size_t)b * a.Nk + kc] : (uint8_t)0;
+    }
+    __syncthreads();
+
+    const int nQB = NqP / 32, nKB = NkP / 32;
+
+    // ---- pass A: dK, dV -------------------------------------------------------------------------
+    for (int kb = wave; kb < nKB; kb += 4) {
+        const int k = kb * 32 + (lane & 31);            // this lane's key
+        const int kc = k < a.Nk ? k : a.Nk - 1;
+        const int mk = modk_l[kc];
+        const bool kp = kpad_l[kc] != 0;
+        bf16x8_t kf[4], vf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            kf[kk] = row_frag(Kl, kb * 32 + (lane & 31), kk, fhi);
+            vf[kk] = row_frag(Vl, kb * 32 + (lane & 31), kk, fhi);
+        }
+        f32x16_t dKt[2], dVt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dKt[i][r] = dVt[i][r] = 0.f;
+        for (int qb = 0; qb < nQB; ++qb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ql, qb * 32 + (lane & 31), kk, fhi), kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOl, qb * 32 + (lane & 31), kk, fhi), vf[kk], dp, 0, 0, 0);
+            }
+            float pv[16], dsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                const int qc = q < a.Nq ? q : a.Nq - 1;
+                float sc = bfround(bfround(s[r]) * a.scale);
+                const bool blk = a.mask_kind != FM_MASK_NONE && blocked_qk(a, b, qc, kc, cs_l[qc], modq_l[qc], mk, kp);
+                sc = blk ? NEG_FILL : sc;
+                float pr = __expf(sc - m_l[q]) * linv_l[q];
+                pr = (q < a.Nq && k < a.Nk) ? pr : 0.f;
+                pv[r] = pr;
+                // masked_fill stops the gradient at blocked scores (they matter only in fully blocked rows)
+                dsv[r] = blk ? 0.f : pr * (dp[r] - delta_l[q]) * a.scale;
+            }
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const bf16x8_t pb = pack8(&pv[8 * sblk]), db = pack8(&dsv[8 * sblk]);
+                const int rA = qb * 32 + sblk * 16 + 4 * fhi;
+#pragma unroll
+                for (int df = 0; df < 2; ++df) {
+                    const bf16x8_t dof = lds_col_frag<TR>([&](int r, int c) { return tile_addr(dOl, r, c); }, rA, rA + 8, df * 32);
+                    dVt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, pb, dVt[df], 0, 0, 0);
+                    const bf16x8_t qcf = lds_col_frag<TR>([&](int r, int c) { return tile_addr(Ql, r, c); }, rA, rA + 8, df * 32);
+                    dKt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qcf, db, dKt[df], 0, 0, 0);
+                }
+            }
+        }
+        if (k < a.Nk) {
+            bf16_t* dkrow = a.dK + ((size_t)b * a.Nk + k) * a.lddk + h * HD;
+            bf16_t* dvrow = a.dV + ((size_t)b * a.Nk + k) * a.lddv + h * HD;
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = df * 32 + 8 * g + 4 * fhi;
+                    *(uint2*)(dkrow + d) = make_uint2(pack2bf(dKt[df][4 * g], dKt[df][4 * g + 1]), pack2bf(dKt[df][4 * g + 2], dKt[df][4 * g + 3]));
+                    *(uint2*)(dvrow + d) = make_uint2(pack2bf(dVt[df][4 * g], dVt[df][4 * g + 1]), pack2bf(dVt[df][4 * g + 2], dVt[df][4 * g + 3]));
+                }
+        }
+    }
+
+    // ---- pass B: dQ -----------------------------------------------------------------------------
+    for (int qb = wave; qb < nQB; qb += 4) {
+        const int q = qb * 32 + (lane & 31);
+        const int qc = q < a.Nq ? q : a.Nq - 1;
+        const float mq_ = m_l[q], li = linv_l[q], dl = delta_l[q];
+        const int csq = cs_l[qc], mq = modq_l[qc];
+        bf16x8_t qf[4], dof[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf[kk] = row_frag(Ql, qb * 32 + (lane & 31), kk, fhi);
+            dof[kk] = row_frag(dOl, qb * 32 + (lane & 31), kk, fhi);
+        }
+        f32x16_t dQt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
+        for (int kb = 0; kb < nKB; ++kb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + (lane & 31), kk, fhi), qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vl, kb * 32 + (lane & 31), kk, fhi), dof[kk], dp, 0, 0, 0);
+            }
+            float dsv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                const int kc = k < a.Nk ? k : a.Nk - 1;
+                float sc = bfround(bfround(s[r]) * a.scale);
+                const bool blk = a.mask_kind != FM_MASK_NONE && blocked_qk(a, b, qc, kc, csq, mq, modk_l[kc], kpad_l[kc] != 0);
+                sc = blk ? NEG_FILL : sc;
+                float pr = __expf(sc - mq_) * li;
+                pr = (q < a.Nq && k < a.Nk) ? pr : 0.f;
+                dsv[r] = blk ? 0.f : pr * (dp[r] - dl) * a.scale;
+            }
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const bf16x8_t db = pack8(&dsv[8 * sblk]);
+                const int rA = kb * 32 + sblk * 16 + 4 * fhi;
+#pragma unroll
+                for (int df = 0; df < 2; ++df) {
+                    const bf16x8_t kcf = lds_col_frag<TR>([&](int r, int c) { return tile_addr(Kl, r, c); }, rA, rA + 8, df * 32);
+                    dQt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcf, db, dQt[df], 0, 0, 0);
+                }
+            }
+        }
+        if (q < a.Nq) {
+            bf16_t* dqrow = a.dQ + ((size_t)b * a.Nq + q) * a.lddq + h * HD;
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = df * 32 + 8 * g + 4 * fhi;
+                    *(uint2*)(dqrow + d) = make_uint2(pack2bf(dQt[df][4 * g], dQt[df][4 * g + 1]), pack2bf(dQt[df][4 * g + 2], dQt[df][4 * g + 3]));
+                }
+        }
+    }
+}
+
+int fill(AttnArgs& a, const fm_attn_args* p, const char* who) {
+    FM_CHECK_ARG(p && p->Q && p->K && p->V && p->O, "%s: null pointer", who);
+    FM_CHECK_ARG(p->head_dim == HD, "%s: head_dim=%d unsupported (this build handles 64)", who, p->head_dim);
+    FM_CHECK_ARG(p->B > 0 && p->H > 0 && p->Nq > 0 && p->Nk > 0, "%s: bad shape", who);
+    FM_CHECK_ARG(p->ldq % 8 == 0 && p->ldk % 8 == 0 && p->ldv % 8 == 0 && p->ldo % 4 == 0, "%s: leading dims must be multiples of 8", who);
+    FM_CHECK_ARG(p->mask_kind != FM_MASK_KEYPAD || p->kpad, "%s: FM_MASK_KEYPAD needs kpad", who);
+    FM_CHECK_ARG(p->mask_kind != FM_MASK_DENSE || p->dense, "%s: FM_MASK_DENSE needs dense", who);
+    FM_CHECK_ARG(p->mask_kind != FM_MASK_DECODER || ((p->modq == nullptr) == (p->modk == nullptr)), "%s: modq and modk go together", who);
+    a.Q = (const bf16_t*)p->Q; a.K = (const bf16_t*)p->K; a.V = (const bf16_t*)p->V; a.O = (bf16_t*)p->O;
+    a.stat_m = (float*)p->stat_m; a.stat_l = (float*)p->stat_l;
+    a.ldq = p->ldq; a.ldk = p->ldk; a.ldv = p->ldv; a.ldo = p->ldo;
+    a.B = p->B; a.H = p->H; a.Nq = p->Nq; a.Nk = p->Nk; a.scale = p->scale; a.mask_kind = p->mask_kind;
+    a.kpad = (const uint8_t*)p->kpad; a.cs = p->cs; a.modq = p->modq; a.modk = p->modk; a.dense = (const uint8_t*)p->dense;
+    a.causal = p->causal;
+    a.dO = (const bf16_t*)p->dO; a.dQ = (bf16_t*)p->dQ; a.dK = (bf16_t*)p->dK; a.dV = (bf16_t*)p->dV;
+    a.lddo = p->lddo; a.lddq = p->lddq; a.lddk = p->lddk; a.lddv = p->lddv;
+    return 0;
+}
+
+int g_attn_tr = 0;
+
+}  // namespace
+
+extern "C" void fm_set_attn_transpose_read(int on) { g_attn_tr = on; }
+extern "C" int fm_get_attn_transpose_read(void) { return g_attn_tr; }
+
+extern "C" int fm_attn_fwd(const fm_attn_args* p, void* stream) {
+    AttnArgs a{};
+    if (int rc = fill(a, p, "fm_attn_fwd")) return rc;
+    FM_CHECK_ARG((a.stat_m == nullptr) == (a.stat_l == nullptr), "fm_attn_fwd: stat_m and stat_l go together");
+    const size_t lds = 2 * 2 * 64 * ROWB + 2 * 64 * 2 + 2 * 64;
+    dim3 grid((a.Nq + 127) / 128, a.H, a.B);
+    const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
+    if (tr) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    FM_CHECK_LAUNCH("fm_attn_fwd");
+    return 0;
+}
+
+extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
+    AttnArgs a{};
+    if (int rc = fill(a, p, "fm_attn_bwd")) return rc;
+    FM_CHECK_ARG(a.dO && a.dQ && a.dK && a.dV && a.stat_m && a.stat_l, "fm_attn_bwd: null pointer");
+    FM_CHECK_ARG(a.Nq <= 256 && a.Nk <= 256, "fm_attn_bwd: Nq=%d Nk=%d exceed the 256-token training budget of this kernel", a.Nq, a.Nk);
+    FM_CHECK_ARG(p->lddo % 8 == 0 && p->lddq % 4 == 0 && p->lddk % 4 == 0 && p->lddv % 4 == 0, "fm_attn_bwd: leading dims");
+    const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
+    const size_t lds = (size_t)(2 * NqP + 2 * NkP) * ROWB + NqP * (3 * 4 + 4 + 2) + NkP * (2 + 1) + 64;
+    static bool once = (hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) &&
+                       (hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
+    (void)once;
+    dim3 grid(a.H, a.B);
+    const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
+    if (tr) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    FM_CHECK_LAUNCH("fm_attn_bwd");
+    return 0;
+}

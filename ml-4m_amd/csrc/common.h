@@ -1,0 +1,114 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the 4M hot path.
+// Wavefront = 64 lanes everywhere; no other architecture is targeted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ---- error reporting (host side) -----------------------------------------------------------
+extern "C" const char* fm_last_error(void);
+void fm_set_error(const char* fmt, ...);
+#define FM_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            fm_set_error(__VA_ARGS__);          \
+            return -1;                          \
+        }                                       \
+    } while (0)
+#define FM_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            fm_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+            return -2;                                                               \
+        }                                                                            \
+    } while (0)
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    // round-to-nearest-even (matches torch .to(bfloat16)); NaN stays NaN
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- wave / block reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ int wave_scan_incl(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// XCD-aware remap of a linear workgroup id: consecutive remapped ids run on the same XCD (and
+// therefore share one L2).  Bijective for every grid size (guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    int xcd = bid % NX, q = nwg / NX, r = nwg % NX;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + bid / NX;
+}
+
+// Read a "column fragment" from a row-major bf16 LDS tile: 8 values T[rA+0..3][c], T[rB+0..3][c]
+// for this lane's column.  Two implementations, selected at compile time:
+//   TR = true : two ds_read_b64_tr_b16 (hardware 4x16 transpose read); the 16 lanes of a group
+//               address one 4-row x 16-column block each (lane i -> row i>>2, columns (i&3)*4..+3)
+//   TR = false: eight 2-byte LDS reads (slow reference path, layout-agnostic)
+// `addr_of(row, col)` returns a (generic) pointer to element (row, col) inside the (swizzled) LDS
+// tile; 4 consecutive columns starting at a multiple of 4 must be contiguous.
+template <bool TR, typename AddrFn>
+__device__ __forceinline__ bf16x8_t lds_col_frag(AddrFn addr_of, int rA, int rB, int col_base32) {
+    const int lane = threadIdx.x & 63;
+    union { bf16x8_t v; s16x4_t h[2]; uint16_t e[8]; } u;
+    if constexpr (TR) {
+        const int i = lane & 15;
+        const int c = col_base32 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(addr_of(rA + (i >> 2), c)));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(addr_of(rB + (i >> 2), c)));
+    } else {
+        const int c = col_base32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u.e[j] = *(const uint16_t*)addr_of(rA + j, c);
+            u.e[4 + j] = *(const uint16_t*)addr_of(rB + j, c);
+        }
+    }
+    return u.v;
+}

@@ -1,0 +1,258 @@
+// HBM-bound element-wise / reduction kernels around the GEMMs: activation backward, bf16 weight
+// shadows (plain and transposed, zero padded to the GEMM contracts), bias gradients, AdamW and the
+// gradient norm.  All 16-byte vectorised, grid-stride, one pass over memory.
+#include "common.h"
+#include "fourm_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld_bf4(const bf16_t* p) {
+    const uint2 v = *(const uint2*)p;
+    return make_float4(bf2f((bf16_t)(v.x & 0xffff)), bf2f((bf16_t)(v.x >> 16)), bf2f((bf16_t)(v.y & 0xffff)), bf2f((bf16_t)(v.y >> 16)));
+}
+__device__ __forceinline__ void st_bf4(bf16_t* p, float a, float b, float c, float d) {
+    *(uint2*)p = make_uint2(pack2bf(a, b), pack2bf(c, d));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// a = silu(g) * u  ->  dg = da * u * silu'(g),  du = da * silu(g)        (GatedMlp, fm_utils.py:142-144)
+// gu / dgu: (R, 2*Hp) with g | u halves;  da: (R, Hp).  Pad columns (>= H) are written as zero.
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ da, int ldda, const bf16_t* __restrict__ gu, int ldgu,
+                                                         bf16_t* __restrict__ dgu, int lddgu, int R, int H, int Hp) {
+    const int cpr = Hp / 4;
+    const size_t total = (size_t)R * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = i / cpr, c = (i % cpr) * 4;
+        const float4 d = ld_bf4(da + (size_t)r * ldda + c);
+        const float4 g = ld_bf4(gu + (size_t)r * ldgu + c), u = ld_bf4(gu + (size_t)r * ldgu + Hp + c);
+        float dg[4], du[4];
+        const float dv[4] = {d.x, d.y, d.z, d.w}, gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = sigmoid_f(gv[e]);
+            const float s = bfround(gv[e] * sg);
+            const float ds = bfround(dv[e] * uv[e]);
+            du[e] = (c + e < H) ? dv[e] * s : 0.f;
+            dg[e] = (c + e < H) ? ds * (sg * (1.0f + gv[e] * (1.0f - sg))) : 0.f;
+        }
+        st_bf4(dgu + (size_t)r * lddgu + c, dg[0], dg[1], dg[2], dg[3]);
+        st_bf4(dgu + (size_t)r * lddgu + Hp + c, du[0], du[1], du[2], du[3]);
+    }
+}
+
+// h = gelu(pre)  ->  dpre = dh * gelu'(pre)        (Mlp, fm_utils.py:121-126; exact erf GELU)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ dh, int lddh, const bf16_t* __restrict__ pre, int ldp,
+                                                       bf16_t* __restrict__ dpre, int lddp, int R, int H, int Hp) {
+    const int cpr = Hp / 4;
+    const size_t total = (size_t)R * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = i / cpr, c = (i % cpr) * 4;
+        const float4 d = ld_bf4(dh + (size_t)r * lddh + c), x = ld_bf4(pre + (size_t)r * ldp + c);
+        const float dv[4] = {d.x, d.y, d.z, d.w}, xv[4] = {x.x, x.y, x.z, x.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float cdf = 0.5f * (1.0f + erff(xv[e] * 0.70710678118654752f));
+            const float pdf = 0.3989422804014327f * __expf(-0.5f * xv[e] * xv[e]);
+            o[e] = (c + e < H) ? dv[e] * (cdf + xv[e] * pdf) : 0.f;
+        }
+        st_bf4(dpre + (size_t)r * lddp + c, o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dst (rows, ldd) bf16 <- src (rows, cols) f32, columns [cols, ldd) zero
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd, int rows, int cols) {
+    const int cpr = ldd / 4;
+    const size_t total = (size_t)rows * cpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = i / cpr, c = (i % cpr) * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (c + e < cols) ? src[(size_t)r * lds_ + c + e] : 0.f;
+        st_bf4(dst + (size_t)r * ldd + c, v[0], v[1], v[2], v[3]);
+    }
+}
+
+// dst (cols_pad_rows = cols, ldd >= rows) bf16 <- transpose of src (rows, cols) f32; dst columns [rows, ldd) zero.
+// 64x64 tiles through LDS: coalesced on both sides.
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd, int rows, int cols) {
+    __shared__ float tile[64][65];
+    const int tr0 = blockIdx.y * 64, tc0 = blockIdx.x * 64;     // tile origin in src (row, col)
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i / 64, c = i % 64;
+        const int gr = tr0 + r, gc = tc0 + c;
+        tile[r][c] = (gr < rows && gc < cols) ? src[(size_t)gr * lds_ + gc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i / 64, r = i % 64;                     // dst row = src col
+        const int gc = tc0 + c, gr = tr0 + r;
+        if (gc < cols && gr < ldd) dst[(size_t)gc * ldd + gr] = f2bf(tile[r][c]);
+    }
+}
+
+// db[n] += sum_r dY[r][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dy, int ldy, float* __restrict__ db, int R, int N, int rows_per_block) {
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s += bf2f(dy[(size_t)r * ldy + n]);
+        unsafeAtomicAdd(db + n, s);
+    }
+}
+
+// torch.optim.AdamW (decoupled weight decay), one launch per contiguous run of one parameter group.
+// grad_mult (device scalar, optional) = gradient clipping coefficient.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    size_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    const float* __restrict__ grad_mult) {
+    const float gm = grad_mult ? grad_mult[0] : 1.0f;
+    const float step = lr / bc1;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+        if (i + 4 <= n) {
+            float4 pp = *(float4*)(p + i), mm = *(float4*)(m + i), vv = *(float4*)(v + i);
+            const float4 gg = *(const float4*)(g + i);
+            float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+            const float ga[4] = {gg.x * gm, gg.y * gm, gg.z * gm, gg.w * gm};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pa[e] *= 1.0f - lr * wd;
+                ma[e] = beta1 * ma[e] + (1.0f - beta1) * ga[e];
+                va[e] = beta2 * va[e] + (1.0f - beta2) * ga[e] * ga[e];
+                pa[e] -= step * ma[e] / (sqrtf(va[e]) / bc2_sqrt + eps);
+            }
+            *(float4*)(p + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+            *(float4*)(m + i) = make_float4(ma[0], ma[1], ma[2], ma[3]);
+            *(float4*)(v + i) = make_float4(va[0], va[1], va[2], va[3]);
+        } else {
+            for (size_t j = i; j < n; ++j) {
+                const float gj = g[j] * gm;
+                float pj = p[j] * (1.0f - lr * wd);
+                const float mj = beta1 * m[j] + (1.0f - beta1) * gj;
+                const float vj = beta2 * v[j] + (1.0f - beta2) * gj * gj;
+                pj -= step * mj / (sqrtf(vj) / bc2_sqrt + eps);
+                p[j] = pj; m[j] = mj; v[j] = vj;
+            }
+        }
+    }
+}
+
+// out[0] += sum x^2   (fp32 partials per workgroup, one atomic each)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+        if (i + 4 <= n) {
+            const float4 v = *(const float4*)(x + i);
+            s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        } else {
+            for (size_t j = i; j < n; ++j) s += x[j] * x[j];
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// norm = sqrt(sumsq); coef = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* norm_out, float* coef_out) {
+    const float nrm = sqrtf(sumsq[0]);
+    norm_out[0] = nrm;
+    if (coef_out) coef_out[0] = max_norm > 0.f ? fminf(1.0f, max_norm / (nrm + 1e-6f)) : 1.0f;
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+        if (i + 4 <= n) {
+            const float4 v = *(const float4*)(src + i);
+            st_bf4(dst + i, v.x, v.y, v.z, v.w);
+        } else {
+            for (size_t j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+        }
+    }
+}
+
+inline int grid_for(size_t work_items) {
+    size_t g = (work_items + 255) / 256;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" int fm_swiglu_bwd(const void* da, int ldda, const void* gu, int ldgu, void* dgu, int lddgu, int R, int H, int Hp, void* stream) {
+    FM_CHECK_ARG(da && gu && dgu && R > 0 && H > 0 && Hp >= H && Hp % 4 == 0, "fm_swiglu_bwd: bad argument");
+    FM_CHECK_ARG(ldda % 4 == 0 && ldgu % 4 == 0 && lddgu % 4 == 0, "fm_swiglu_bwd: leading dims must be multiples of 4");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((size_t)R * Hp / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)da, ldda,
+                       (const bf16_t*)gu, ldgu, (bf16_t*)dgu, lddgu, R, H, Hp);
+    FM_CHECK_LAUNCH("fm_swiglu_bwd");
+    return 0;
+}
+
+extern "C" int fm_gelu_bwd(const void* dh, int lddh, const void* pre, int ldp, void* dpre, int lddp, int R, int H, int Hp, void* stream) {
+    FM_CHECK_ARG(dh && pre && dpre && R > 0 && H > 0 && Hp >= H && Hp % 4 == 0, "fm_gelu_bwd: bad argument");
+    FM_CHECK_ARG(lddh % 4 == 0 && ldp % 4 == 0 && lddp % 4 == 0, "fm_gelu_bwd: leading dims must be multiples of 4");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for((size_t)R * Hp / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, lddh,
+                       (const bf16_t*)pre, ldp, (bf16_t*)dpre, lddp, R, H, Hp);
+    FM_CHECK_LAUNCH("fm_gelu_bwd");
+    return 0;
+}
+
+extern "C" int fm_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, void* stream) {
+    FM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_dst >= cols && ld_dst % 4 == 0, "fm_cast_pad: bad argument");
+    hipLaunchKernelGGL(cast_pad_kernel, dim3(grid_for((size_t)rows * ld_dst / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src,
+                       (bf16_t*)dst, ld_dst, rows, cols);
+    FM_CHECK_LAUNCH("fm_cast_pad");
+    return 0;
+}
+
+extern "C" int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, void* stream) {
+    FM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_dst >= rows, "fm_transpose_cast_pad: bad argument");
+    dim3 grid((cols + 63) / 64, (ld_dst + 63) / 64);
+    hipLaunchKernelGGL(transpose_cast_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols);
+    FM_CHECK_LAUNCH("fm_transpose_cast_pad");
+    return 0;
+}
+
+extern "C" int fm_colsum(const void* dy, int ldy, void* db, int R, int N, void* stream) {
+    FM_CHECK_ARG(dy && db && R > 0 && N > 0, "fm_colsum: bad argument");
+    const int rpb = 256;
+    dim3 grid((N + 255) / 256, (R + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, ldy, (float*)db, R, N, rpb);
+    FM_CHECK_LAUNCH("fm_colsum");
+    return 0;
+}
+
+extern "C" int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int64_t step, const void* grad_mult, void* stream) {
+    FM_CHECK_ARG(p && g && m && v && n > 0 && step > 0, "fm_adamw: bad argument");
+    FM_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "fm_adamw: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (float*)p, (const float*)g, (float*)m,
+                       (float*)v, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult);
+    FM_CHECK_LAUNCH("fm_adamw");
+    return 0;
+}
+
+extern "C" int fm_sumsq(const void* x, int64_t n, void* out, void* stream) {
+    FM_CHECK_ARG(x && out && n > 0 && (((uintptr_t)x) & 15) == 0, "fm_sumsq: bad argument");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (size_t)n, (float*)out);
+    FM_CHECK_LAUNCH("fm_sumsq");
+    return 0;
+}
+
+extern "C" int fm_clip_coef(const void* sumsq, float max_norm, void* norm_out, void* coef_out, void* stream) {
+    FM_CHECK_ARG(sumsq && norm_out, "fm_clip_coef: null pointer");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const float*)sumsq, max_norm, (float*)norm_out, (float*)coef_out);
+    FM_CHECK_LAUNCH("fm_clip_coef");
+    return 0;
+}
+
+extern "C" int fm_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream) {
+    FM_CHECK_ARG(src && dst && n > 0 && (((uintptr_t)src) & 15) == 0 && (((uintptr_t)dst) & 7) == 0, "fm_f32_to_bf16: bad argument");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src, (bf16_t*)dst, (size_t)n);
+    FM_CHECK_LAUNCH("fm_f32_to_bf16");
+    return 0;
+}

@@ -1,0 +1,413 @@
+// bf16 MFMA GEMMs for the 4M trunk (gfx950).
+//
+//   NT  out[m][n] = sum_k X[m][k] * W[n][k]          forward Linear and dX (with a W^T shadow)
+//   TN  out[n][k] += sum_r A[r][n] * B[r][k]         dW = dY^T X   (fp32 accumulate into the grad)
+//
+// Both use v_mfma_f32_32x32x16_bf16 with the *weight-like* operand on the MFMA row side, so that in
+// the accumulator a lane holds 4 consecutive output features of one token row: epilogues (bias, GELU,
+// SwiGLU, residual add) run on registers and stores are 8/16-byte row-contiguous chunks.
+//
+// LDS tiles are filled with global_load_lds (16 B per lane, LDS image is lane-linear) and read with
+// ds_read_b128; bank conflicts are removed by XOR-swizzling the 16-B chunk index on the *source*
+// address and again on the read (guide rule 21).
+//
+// Contracts (the Python layer allocates every bf16 buffer and guarantees them):
+//   * the reduction dimension is a multiple of 64 and zero padded;
+//   * leading dimensions are multiples of 8 elements (16-byte aligned rows).
+#include "common.h"
+#include "fourm_hip.h"
+
+namespace {
+
+constexpr int BK = 64;           // reduction elements per LDS stage
+constexpr int ROWB = BK * 2;     // bytes per LDS tile row (NT tiles)
+
+enum { EPI_BF16 = FM_EPI_BF16, EPI_GELU = FM_EPI_GELU, EPI_RES = FM_EPI_RESIDUAL, EPI_SWIGLU = FM_EPI_SWIGLU,
+       EPI_F32 = FM_EPI_F32 };
+
+struct NTArgs {
+    const bf16_t* W; const bf16_t* W2; const bf16_t* X;
+    void* out; void* out2; const float* res; const float* bias; const float* bias2;
+    int M, N, K, ldw, ldx, ldo, ldo2, ldr, Hp;
+    const fm_gemm_group* groups; const int* tile_group;   // grouped mode (may be null)
+    int n_tiles_w, n_tiles_x;
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// NT kernel
+// ------------------------------------------------------------------------------------------------
+template <int TW, int TX, int WW, int WX, int EPI, bool GROUPED>
+__global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
+    constexpr int NWAVES = WW * WX;
+    constexpr int FW = TW / WW / 32, FX = TX / WX / 32;      // 32x32 fragments per wave
+    constexpr int STAGE = (TW + TX) * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ww = wave / WX, wx = wave % WX;
+
+    // ---- which tile ------------------------------------------------------------------------
+    const int nwg = a.n_tiles_w * a.n_tiles_x;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int tx = tile / a.n_tiles_w, tw = tile % a.n_tiles_w;   // W tiles fastest: X tile shared in L2
+    const bf16_t* Wp = a.W;
+    int N = a.N, K = a.K, ldw = a.ldw;
+    if constexpr (GROUPED) {
+        const int g = a.tile_group[tx];
+        if (g < 0) return;
+        Wp = (const bf16_t*)a.groups[g].W; N = a.groups[g].N; K = a.groups[g].K; ldw = a.groups[g].ldw;
+    }
+    constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;        // output features per W tile
+    const int n0 = tw * NPT, m0 = tx * TX;
+    if (n0 >= N) return;
+
+    // ---- staging: each wave-instruction moves 8 rows x 128 B ---------------------------------
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * STAGE;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int p = 0; p < TW / (8 * NWAVES); ++p) {
+            const int t = p * 8 * NWAVES + wave * 8 + (lane >> 3);
+            const int lc = (lane & 7) ^ ((t >> 1) & 7);
+            const bf16_t* src;
+            if constexpr (EPI == EPI_SWIGLU) {
+                int n = n0 + (t >> 6) * 32 + (t & 31);
+                n = n < N ? n : N - 1;
+                src = (((t >> 5) & 1) ? a.W2 : Wp) + (size_t)n * ldw + k0 + lc * 8;
+            } else {
+                int n = n0 + t;
+                n = n < N ? n : N - 1;
+                src = Wp + (size_t)n * ldw + k0 + lc * 8;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + (p * 8 * NWAVES + wave * 8) * ROWB), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < TX / (8 * NWAVES); ++p) {
+            const int t = p * 8 * NWAVES + wave * 8 + (lane >> 3);
+            const int lc = (lane & 7) ^ ((t >> 1) & 7);
+            int m = m0 + t;
+            m = m < a.M ? m : a.M - 1;
+            const bf16_t* src = a.X + (size_t)m * a.ldx + k0 + lc * 8;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + TW * ROWB + (p * 8 * NWAVES + wave * 8) * ROWB), 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[FW][FX];
+#pragma unroll
+    for (int i = 0; i < FW; ++i)
+#pragma unroll
+        for (int j = 0; j < FX; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int KT = K / BK;
+    stage(0, 0);
+    __syncthreads();   // (drains the LDS-DMA: vmcnt(0) + barrier)
+
+    // per-lane constants of the fragment reads
+    const int frow = lane & 31;                 // row inside a 32-row fragment
+    const int fswz = (frow >> 1) & 7;           // swizzle key (fragment bases are multiples of 32)
+    const int fhi = lane >> 5;
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+        const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * ROWB;
+        const char* xt = smem + buf * STAGE + TW * ROWB + (wx * (TX / WX) + frow) * ROWB;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int off = ((kk * 2 + fhi) ^ fswz) * 16;
+            bf16x8_t wf[FW], xf[FX];
+#pragma unroll
+            for (int i = 0; i < FW; ++i) wf[i] = *(const bf16x8_t*)(wt + i * 32 * ROWB + off);
+#pragma unroll
+            for (int j = 0; j < FX; ++j) xf[j] = *(const bf16x8_t*)(xt + j * 32 * ROWB + off);
+#pragma unroll
+            for (int i = 0; i < FW; ++i)
+#pragma unroll
+                for (int j = 0; j < FX; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds, per fragment, 4 groups of 4 consecutive features of one row ---
+#pragma unroll
+    for (int j = 0; j < FX; ++j) {
+        const int m = m0 + wx * (TX / WX) + j * 32 + frow;
+        if (m >= a.M) continue;
+        if constexpr (EPI == EPI_SWIGLU) {
+            static_assert(EPI != EPI_SWIGLU || FW == 2, "SwiGLU tile needs a (g,u) fragment pair per wave");
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int h = n0 + ww * 32 + 8 * g + 4 * fhi;      // hidden index of the 4-group
+                if (h >= N) continue;
+                float gv[4], uv[4], av[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b1[e] = bfround(a.bias[min(h + e, N - 1)]);
+                }
+                if (a.bias2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b2[e] = bfround(a.bias2[min(h + e, N - 1)]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool live = h + e < N;          // hidden sizes need not be multiples of 4 (2730)
+                    gv[e] = live ? bfround(acc[0][j][4 * g + e] + b1[e]) : 0.f;
+                    uv[e] = live ? bfround(acc[1][j][4 * g + e] + b2[e]) : 0.f;
+                    av[e] = bfround(silu_f(gv[e])) * uv[e];
+                }
+                bf16_t* gu = (bf16_t*)a.out2 + (size_t)m * a.ldo2;
+                *(uint2*)(gu + h) = make_uint2(pack2bf(gv[0], gv[1]), pack2bf(gv[2], gv[3]));
+                *(uint2*)(gu + a.Hp + h) = make_uint2(pack2bf(uv[0], uv[1]), pack2bf(uv[2], uv[3]));
+                *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + h) = make_uint2(pack2bf(av[0], av[1]), pack2bf(av[2], av[3]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < FW; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + ww * (TW / WW) + i * 32 + 8 * g + 4 * fhi;
+                    if (n >= N) continue;
+                    float v[4], b[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) {
+                        const float4 t = *(const float4*)(a.bias + n);     // n % 4 == 0, bias 16-B aligned
+                        b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + ((EPI == EPI_F32) ? b[e] : bfround(b[e]));
+                    if constexpr (EPI == EPI_BF16) {
+                        *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    } else if constexpr (EPI == EPI_GELU) {
+                        if (a.out2)
+                            *(uint2*)((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_f(bfround(v[e]));
+                        *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    } else if constexpr (EPI == EPI_RES) {
+                        const float4 r = *(const float4*)(a.res + (size_t)m * a.ldr + n);
+                        float4 o = make_float4(r.x + bfround(v[0]), r.y + bfround(v[1]), r.z + bfround(v[2]), r.w + bfround(v[3]));
+                        *(float4*)((float*)a.out + (size_t)m * a.ldo + n) = o;
+                    } else {  // EPI_F32
+                        *(float4*)((float*)a.out + (size_t)m * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN kernel:  out[n][k] += sum_r A[r][n] * B[r][k]      (fp32 atomic accumulate, split over r)
+// ------------------------------------------------------------------------------------------------
+struct TNArgs {
+    const bf16_t* A; const bf16_t* B; float* out;
+    int R, N, K, lda, ldb, ldo, splits;
+    int a_cols, b_cols;                       // readable columns of A / B (clamp for the tile loads)
+    const fm_gemm_group* groups; const int* seg_start; const int* seg_count;   // grouped (per-modality rows)
+    int n_tiles_a, n_tiles_b;
+};
+
+constexpr int TROWB = 256;   // TN LDS tile row: 128 bf16 columns
+
+__device__ __forceinline__ const char* tn_addr(const char* tile, int row, int col) {
+    return tile + row * TROWB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
+}
+
+template <bool TR, bool GROUPED>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
+    constexpr int TA = 128, TB = 128, NWAVES = 4;
+    constexpr int STAGE = 2 * BK * TROWB;      // A tile + B tile, 64 reduction rows each
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wa = wave >> 1, wb = wave & 1;
+
+    const int nwg = a.n_tiles_a * a.n_tiles_b;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int ta = tile / a.n_tiles_b, tb = tile % a.n_tiles_b;
+    const int split = blockIdx.y;
+    int N = a.N, r_begin = 0, r_end = a.R;
+    float* out = a.out;
+    if constexpr (GROUPED) {
+        const int g = blockIdx.z;
+        N = a.groups[g].N; out = (float*)a.groups[g].out;
+        r_begin = a.seg_start[g];
+        r_end = r_begin + ((a.seg_count[g] + BK - 1) / BK) * BK;
+    }
+    const int n0 = ta * TA, k0 = tb * TB;
+    if (n0 >= N || k0 >= a.K) return;
+    const int nt = (r_end - r_begin) / BK;                      // reduction tiles in total
+    const int per = (nt + a.splits - 1) / a.splits;
+    const int t_begin = split * per, t_end = min(nt, t_begin + per);
+    if (t_begin >= t_end) return;
+
+    auto stage = [&](int t, int buf) {
+        char* base = smem + buf * STAGE;
+        const int r0 = r_begin + t * BK;
+#pragma unroll
+        for (int p = 0; p < BK / (4 * NWAVES); ++p) {
+            const int row = p * 4 * NWAVES + wave * 4 + (lane >> 4);
+            const int lc = (lane & 15) ^ ((row & 3) << 2);
+            int ca = n0 + lc * 8; ca = ca <= a.a_cols - 8 ? ca : a.a_cols - 8;
+            int cb = k0 + lc * 8; cb = cb <= a.b_cols - 8 ? cb : a.b_cols - 8;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a.A + (size_t)(r0 + row) * a.lda + ca),
+                                             LDS_PTR(base + (p * 4 * NWAVES + wave * 4) * TROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb),
+                                             LDS_PTR(base + BK * TROWB + (p * 4 * NWAVES + wave * 4) * TROWB), 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    stage(t_begin, 0);
+    __syncthreads();
+    const int fhi = lane >> 5;
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) stage(t + 1, buf ^ 1);
+        const char* at = smem + buf * STAGE;
+        const char* bt = at + BK * TROWB;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int rA = kk * 16 + fhi * 8, rB = rA + 4;
+            bf16x8_t af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = lds_col_frag<TR>([&](int r, int c) { return tn_addr(at, r, c); }, rA, rB, wa * 64 + i * 32);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[j] = lds_col_frag<TR>([&](int r, int c) { return tn_addr(bt, r, c); }, rA, rB, wb * 64 + j * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // accumulator: rows <-> n (A columns), cols <-> k (B columns); lane = k, regs = n
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = k0 + wb * 64 + j * 32 + (lane & 31);
+        if (k >= a.K) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wa * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                if (n < N) unsafeAtomicAdd(out + (size_t)n * a.ldo + k, acc[i][j][r]);
+            }
+    }
+}
+
+template <int EPI, bool GROUPED>
+int launch_nt(const NTArgs& a0, int max_n, hipStream_t s) {
+    NTArgs a = a0;
+    constexpr int TW = 128, TX = 128;
+    constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
+    a.n_tiles_w = (max_n + NPT - 1) / NPT;
+    a.n_tiles_x = (a.M + TX - 1) / TX;
+    const int grid = a.n_tiles_w * a.n_tiles_x;
+    const size_t lds = 2 * (TW + TX) * ROWB;
+    auto k = gemm_nt_kernel<TW, TX, 2, 2, EPI, GROUPED>;
+    static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    FM_CHECK_LAUNCH("fm_gemm_nt");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
+    FM_CHECK_ARG(p && p->X && p->out, "fm_gemm_nt: null pointer");
+    const bool grouped = p->groups != nullptr;
+    FM_CHECK_ARG(grouped || p->W, "fm_gemm_nt: W is null");
+    FM_CHECK_ARG(p->M > 0 && (grouped || (p->N > 0 && p->K > 0)), "fm_gemm_nt: bad shape M=%d N=%d K=%d", p->M, p->N, p->K);
+    FM_CHECK_ARG(grouped || p->K % BK == 0, "fm_gemm_nt: K=%d must be a multiple of %d (zero padded)", p->K, BK);
+    FM_CHECK_ARG(p->ldx % 8 == 0 && (grouped || p->ldw % 8 == 0), "fm_gemm_nt: leading dims must be multiples of 8");
+    FM_CHECK_ARG(grouped || p->N % 4 == 0, "fm_gemm_nt: N=%d must be a multiple of 4", p->N);
+    FM_CHECK_ARG(p->ldo % 4 == 0, "fm_gemm_nt: ldo must be a multiple of 4");
+    NTArgs a{};
+    a.W = (const bf16_t*)p->W; a.W2 = (const bf16_t*)p->W2; a.X = (const bf16_t*)p->X;
+    a.out = p->out; a.out2 = p->out2; a.res = (const float*)p->res; a.bias = (const float*)p->bias; a.bias2 = (const float*)p->bias2;
+    a.M = p->M; a.N = p->N; a.K = p->K; a.ldw = p->ldw; a.ldx = p->ldx; a.ldo = p->ldo; a.ldo2 = p->ldo2; a.ldr = p->ldr; a.Hp = p->Hp;
+    a.groups = p->groups; a.tile_group = p->tile_group;
+    hipStream_t s = (hipStream_t)stream;
+    const int max_n = grouped ? p->max_N : p->N;
+    if (grouped) {
+        FM_CHECK_ARG(p->tile_group && p->max_N > 0, "fm_gemm_nt: grouped mode needs tile_group and max_N");
+        FM_CHECK_ARG(p->epilogue == FM_EPI_BF16, "fm_gemm_nt: grouped mode supports FM_EPI_BF16 only");
+        return launch_nt<EPI_BF16, true>(a, max_n, s);
+    }
+    switch (p->epilogue) {
+        case FM_EPI_BF16: return launch_nt<EPI_BF16, false>(a, max_n, s);
+        case FM_EPI_GELU: return launch_nt<EPI_GELU, false>(a, max_n, s);
+        case FM_EPI_RESIDUAL:
+            FM_CHECK_ARG(p->res && p->ldr % 4 == 0, "fm_gemm_nt: residual epilogue needs res / ldr%%4==0");
+            return launch_nt<EPI_RES, false>(a, max_n, s);
+        case FM_EPI_SWIGLU:
+            FM_CHECK_ARG(p->W2 && p->out2 && p->Hp % 4 == 0 && p->ldo2 % 4 == 0, "fm_gemm_nt: SwiGLU epilogue needs W2, out2, Hp%%4==0");
+            return launch_nt<EPI_SWIGLU, false>(a, max_n, s);
+        case FM_EPI_F32: return launch_nt<EPI_F32, false>(a, max_n, s);
+    }
+    fm_set_error("fm_gemm_nt: unknown epilogue %d", p->epilogue);
+    return -1;
+}
+
+static int g_tn_use_tr = 0;
+extern "C" void fm_set_tn_transpose_read(int on) { g_tn_use_tr = on; }
+extern "C" int fm_get_tn_transpose_read(void) { return g_tn_use_tr; }
+
+extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
+    FM_CHECK_ARG(p && p->A && p->B, "fm_gemm_tn: null pointer");
+    const bool grouped = p->groups != nullptr;
+    FM_CHECK_ARG(grouped || p->out, "fm_gemm_tn: out is null");
+    FM_CHECK_ARG(p->K > 0 && (grouped || (p->N > 0 && p->R > 0)), "fm_gemm_tn: bad shape");
+    FM_CHECK_ARG(grouped || p->R % BK == 0, "fm_gemm_tn: R=%d must be a multiple of %d (zero padded rows)", p->R, BK);
+    FM_CHECK_ARG(p->lda % 8 == 0 && p->ldb % 8 == 0, "fm_gemm_tn: leading dims must be multiples of 8");
+    TNArgs a{};
+    a.A = (const bf16_t*)p->A; a.B = (const bf16_t*)p->B; a.out = (float*)p->out;
+    a.R = p->R; a.N = p->N; a.K = p->K; a.lda = p->lda; a.ldb = p->ldb; a.ldo = p->ldo;
+    a.a_cols = p->a_cols > 0 ? p->a_cols : p->lda; a.b_cols = p->b_cols > 0 ? p->b_cols : p->ldb;
+    FM_CHECK_ARG(a.a_cols >= 8 && a.b_cols >= 8, "fm_gemm_tn: operands need at least 8 readable columns");
+    a.groups = p->groups; a.seg_start = p->seg_start; a.seg_count = p->seg_count;
+    const int max_n = grouped ? p->max_N : p->N;
+    a.n_tiles_a = (max_n + 127) / 128; a.n_tiles_b = (p->K + 127) / 128;
+    int splits = p->splits;
+    if (splits <= 0) {   // aim for >= 2 workgroups per CU
+        const int tiles = a.n_tiles_a * a.n_tiles_b * (grouped ? p->n_groups : 1);
+        const int nt = grouped ? (p->max_R + BK - 1) / BK : p->R / BK;
+        splits = (512 + tiles - 1) / tiles;
+        if (splits > nt) splits = nt;
+        if (splits < 1) splits = 1;
+    }
+    a.splits = splits;
+    const size_t lds = 2 * 2 * BK * TROWB;
+    dim3 grid(a.n_tiles_a * a.n_tiles_b, splits, grouped ? p->n_groups : 1);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_TN(TR, G)                                                                            \
+    {                                                                                               \
+        auto k = gemm_tn_kernel<TR, G>;                                                             \
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true); \
+        (void)once;                                                                                 \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                          \
+    }
+    const int tr = p->force_tr >= 0 ? p->force_tr : g_tn_use_tr;
+    if (tr) { if (grouped) LAUNCH_TN(true, true) else LAUNCH_TN(true, false) }
+    else { if (grouped) LAUNCH_TN(false, true) else LAUNCH_TN(false, false) }
+#undef LAUNCH_TN
+    FM_CHECK_LAUNCH("fm_gemm_tn");
+    return 0;
+}

@@ -1,0 +1,138 @@
+"""ctypes binding of libfourm_hip.so (include/fourm_hip.h).  No torch types cross this boundary:
+only device pointers, sizes and the raw hipStream_t.
+
+The library is built in-tree by ``ml-4m_amd/build_ext.py`` (``__graft_entry__.build()``).  Its
+absence is a hard error: there is no CPU or eager-PyTorch fallback for the hot path.
+"""
+import ctypes as C
+import os
+
+FM_MAX_MODS = 24
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_lib", "libfourm_hip.so")
+
+
+class FourmHipUnavailable(ImportError):
+    pass
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise FourmHipUnavailable(
+            f"{_LIB_PATH} is missing - build the gfx950 kernels first: python ml-4m_amd/build_ext.py "
+            "(the 4M hot path has no fallback implementation)")
+    return C.CDLL(_LIB_PATH)
+
+
+lib = _load()
+lib.fm_last_error.restype = C.c_char_p
+lib.fm_abi_version.restype = C.c_int
+ABI_VERSION = 1
+if lib.fm_abi_version() != ABI_VERSION:
+    raise FourmHipUnavailable(f"libfourm_hip.so ABI {lib.fm_abi_version()} != expected {ABI_VERSION}; rebuild")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# enums (keep in sync with the header; tests/test_abi.py cross-checks them against the header text)
+EPI_BF16, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = 0, 1, 2, 3, 4
+MASK_NONE, MASK_KEYPAD, MASK_DECODER, MASK_DENSE = 0, 1, 2, 3
+KIND_TOK, KIND_PATCH, KIND_SEQ, KIND_SEQ_EMB = 0, 1, 2, 3
+LOSS_MOD, LOSS_TOKEN = 0, 1
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [("W", vp), ("out", vp), ("N", i32), ("K", i32), ("ldw", i32), ("pad_", i32)]
+
+
+class GemmNTArgs(C.Structure):
+    _fields_ = [("W", vp), ("W2", vp), ("X", vp), ("out", vp), ("out2", vp), ("res", vp), ("bias", vp), ("bias2", vp),
+                ("M", i32), ("N", i32), ("K", i32), ("ldw", i32), ("ldx", i32), ("ldo", i32), ("ldo2", i32), ("ldr", i32),
+                ("Hp", i32), ("epilogue", i32), ("groups", vp), ("tile_group", vp), ("max_N", i32), ("pad_", i32)]
+
+
+class GemmTNArgs(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("out", vp), ("R", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32),
+                ("ldo", i32), ("a_cols", i32), ("b_cols", i32), ("splits", i32), ("force_tr", i32), ("groups", vp),
+                ("seg_start", vp), ("seg_count", vp), ("n_groups", i32), ("max_N", i32), ("max_R", i32), ("pad_", i32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("stat_m", vp), ("stat_l", vp),
+                ("ldq", i32), ("ldk", i32), ("ldv", i32), ("ldo", i32),
+                ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32), ("head_dim", i32), ("mask_kind", i32),
+                ("scale", f32), ("causal", i32),
+                ("kpad", vp), ("cs", vp), ("modq", vp), ("modk", vp), ("dense", vp),
+                ("dO", vp), ("dQ", vp), ("dK", vp), ("dV", vp),
+                ("lddo", i32), ("lddq", i32), ("lddk", i32), ("lddv", i32), ("force_tr", i32), ("pad_", i32)]
+
+
+class ModDesc(C.Structure):
+    _fields_ = [("ids", vp), ("mask", vp), ("dam", vp), ("table", vp), ("pos", vp), ("mod_emb", vp), ("proj_bias", vp),
+                ("L", i32), ("kind", i32), ("ids_are_i64", i32), ("mod_id", i32), ("max_len", i32), ("shifted", i32),
+                ("mask_stride", i32), ("id_stride", i32), ("patch", i32), ("channels", i32), ("grid_w", i32),
+                ("orig_dim", i32), ("head_index", i32), ("pad_", i32)]
+
+
+class SelectDesc(C.Structure):
+    _fields_ = [("mods", ModDesc * FM_MAX_MODS),
+                ("n_mods", i32), ("batch", i32), ("dim", i32), ("n_keep", i32), ("n_reg", i32), ("total_len", i32),
+                ("is_decoder", i32), ("pad_", i32),
+                ("reg_tokens", vp), ("mask_token", vp),
+                ("tokens", vp), ("emb", vp), ("x0", vp), ("out_mask", vp), ("out_mod", vp), ("slot_mod", vp),
+                ("slot_src", vp), ("slot_pos", vp), ("target_ids", vp), ("out_cs", vp), ("out_mod_pre", vp),
+                ("out_mod_index", vp), ("patch_rows", vp), ("seqemb_rows", vp), ("patch_ld", i32), ("seqemb_ld", i32)]
+
+
+class EmbedBwdMod(C.Structure):
+    _fields_ = [("d_table", vp), ("d_pos", vp), ("d_mod_emb", vp), ("d_proj_bias", vp),
+                ("kind", i32), ("has_padding_idx", i32), ("padding_idx", i32), ("pad_", i32)]
+
+
+class EmbedBwdDesc(C.Structure):
+    _fields_ = [("mods", EmbedBwdMod * FM_MAX_MODS), ("dx", vp), ("slot_mod", vp), ("slot_src", vp), ("slot_pos", vp),
+                ("d_mask_token", vp), ("d_reg_tokens", vp),
+                ("n_mods", i32), ("batch", i32), ("dim", i32), ("Nt", i32), ("lddx", i32), ("is_decoder", i32)]
+
+
+def _sig(name, *argtypes):
+    fn = getattr(lib, name)
+    fn.argtypes = list(argtypes)
+    fn.restype = C.c_int
+    return fn
+
+
+P = C.POINTER
+gemm_nt = _sig("fm_gemm_nt", P(GemmNTArgs), vp)
+gemm_tn = _sig("fm_gemm_tn", P(GemmTNArgs), vp)
+layernorm_fwd = _sig("fm_layernorm_fwd", vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, f32, vp)
+layernorm_bwd = _sig("fm_layernorm_bwd", vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, vp)
+attn_fwd = _sig("fm_attn_fwd", P(AttnArgs), vp)
+attn_bwd = _sig("fm_attn_bwd", P(AttnArgs), vp)
+select_embed = _sig("fm_select_embed", P(SelectDesc), vp)
+embed_bwd = _sig("fm_embed_bwd", P(EmbedBwdDesc), vp)
+dense_decoder_mask = _sig("fm_dense_decoder_mask", vp, vp, vp, i32, i32, i32, i32, i32, vp)
+segment_rows = _sig("fm_segment_rows", vp, i32, i32, vp, vp, vp, vp, vp, i32, vp)
+gather_rows = _sig("fm_gather_rows", vp, i32, vp, vp, i32, i32, i32, vp)
+cross_entropy = _sig("fm_cross_entropy", vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp)
+swiglu_bwd = _sig("fm_swiglu_bwd", vp, i32, vp, i32, vp, i32, i32, i32, i32, vp)
+gelu_bwd = _sig("fm_gelu_bwd", vp, i32, vp, i32, vp, i32, i32, i32, i32, vp)
+cast_pad = _sig("fm_cast_pad", vp, i32, vp, i32, i32, i32, vp)
+transpose_cast_pad = _sig("fm_transpose_cast_pad", vp, i32, vp, i32, i32, i32, vp)
+colsum = _sig("fm_colsum", vp, i32, vp, i32, i32, vp)
+f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
+adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp)
+sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
+clip_coef = _sig("fm_clip_coef", vp, f32, vp, vp, vp)
+lib.fm_set_tn_transpose_read.argtypes = [C.c_int]
+lib.fm_set_attn_transpose_read.argtypes = [C.c_int]
+
+EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_gemm_tn", "fm_set_tn_transpose_read",
+           "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
+           "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
+           "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
+           "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_colsum", "fm_f32_to_bf16", "fm_adamw",
+           "fm_sumsq", "fm_clip_coef"]
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError(f"libfourm_hip: {lib.fm_last_error().decode()} (rc={rc})")

@@ -1,0 +1,224 @@
+"""Thin torch-tensor front end over the C ABI: pointer extraction, shape checks, stream plumbing.
+torch is used here for device memory and streams only; every computation is a HIP kernel."""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+BK = 64          # reduction granularity of the GEMMs (zero padded)
+SEG = 128        # row-segment alignment of the grouped head GEMMs
+
+
+def ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libfourm_hip ops need device tensors (no CPU fallback exists)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and t.stride(1) == 1, "2-D row-major tensor expected"
+    return t.stride(0)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------
+def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bias2=None, out2=None, Hp=0, N=None, K=None, M=None):
+    """out[m][n] = sum_k x[m][k] w[n][k] (+ epilogue).  x: bf16 (M, >=K); w: bf16 (N, >=K)."""
+    a = L.GemmNTArgs()
+    a.W, a.W2, a.X, a.out, a.out2 = _p(w), _p(w2), _p(x), _p(out), _p(out2)
+    a.res, a.bias, a.bias2 = _p(res), _p(bias), _p(bias2)
+    a.M = x.shape[0] if M is None else M
+    a.N = w.shape[0] if N is None else N
+    a.K = w.shape[1] if K is None else K
+    a.ldw, a.ldx, a.ldo = _ld(w), _ld(x), _ld(out)
+    a.ldo2 = _ld(out2) if out2 is not None else 0
+    a.ldr = _ld(res) if res is not None else 0
+    a.Hp, a.epilogue = Hp, epilogue
+    L.check(L.gemm_nt(C.byref(a), _stream()))
+    return out
+
+
+def gemm_nt_grouped(x, groups, tile_group, out, max_N, M=None):
+    a = L.GemmNTArgs()
+    a.X, a.out = _p(x), _p(out)
+    a.M = x.shape[0] if M is None else M
+    a.ldx, a.ldo = _ld(x), _ld(out)
+    a.epilogue = L.EPI_BF16
+    a.groups, a.tile_group, a.max_N = _p(groups), _p(tile_group), max_N
+    L.check(L.gemm_nt(C.byref(a), _stream()))
+    return out
+
+
+def gemm_tn(a_mat, b_mat, out, *, N=None, K=None, R=None, splits=0, force_tr=-1, a_cols=0, b_cols=0):
+    """out[n][k] += sum_r a[r][n] b[r][k]; out fp32 (N, >=K)."""
+    a = L.GemmTNArgs()
+    a.A, a.B, a.out = _p(a_mat), _p(b_mat), _p(out)
+    a.R = a_mat.shape[0] if R is None else R
+    a.N = a_mat.shape[1] if N is None else N
+    a.K = b_mat.shape[1] if K is None else K
+    a.lda, a.ldb, a.ldo = _ld(a_mat), _ld(b_mat), _ld(out)
+    a.a_cols = a_cols or a_mat.shape[1]
+    a.b_cols = b_cols or b_mat.shape[1]
+    a.splits, a.force_tr = splits, force_tr
+    L.check(L.gemm_tn(C.byref(a), _stream()))
+    return out
+
+
+def gemm_tn_grouped(a_mat, b_mat, groups, seg_start, seg_count, n_groups, max_N, max_R, K, *, splits=0, force_tr=-1):
+    a = L.GemmTNArgs()
+    a.A, a.B = _p(a_mat), _p(b_mat)
+    a.K = K
+    a.lda, a.ldb, a.ldo = _ld(a_mat), _ld(b_mat), K
+    a.a_cols, a.b_cols = a_mat.shape[1], b_mat.shape[1]
+    a.splits, a.force_tr = splits, force_tr
+    a.groups, a.seg_start, a.seg_count = _p(groups), _p(seg_start), _p(seg_count)
+    a.n_groups, a.max_N, a.max_R = n_groups, max_N, max_R
+    L.check(L.gemm_tn(C.byref(a), _stream()))
+
+
+def make_groups(entries, device):
+    """entries: list of dicts(W=tensor|None, out=tensor|None, N, K, ldw) -> device byte tensor of fm_gemm_group."""
+    arr = (L.GemmGroup * len(entries))()
+    for i, e in enumerate(entries):
+        arr[i].W = e["W"].data_ptr() if e.get("W") is not None else None
+        arr[i].out = e["out"].data_ptr() if e.get("out") is not None else None
+        arr[i].N, arr[i].K, arr[i].ldw = e["N"], e.get("K", 0), e.get("ldw", 0)
+    host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return host.to(device)
+
+
+# ---------------------------------------------------------------------------------------------
+# LayerNorm
+# ---------------------------------------------------------------------------------------------
+def layernorm_fwd(x, w, b, y, mean=None, rstd=None, row_map=None, eps=1e-6, R=None):
+    R = x.shape[0] if R is None else R
+    L.check(L.layernorm_fwd(_p(x), _ld(x), _p(w), _p(b), _p(y), _ld(y), 1 if y.dtype == torch.float32 else 0,
+                            _p(mean), _p(rstd), _p(row_map), R, w.numel(), eps, _stream()))
+    return y
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dx, *, dres=None, dx_bf16=None, dw=None, db=None, dy_row_map=None, R=None):
+    R = x.shape[0] if R is None else R
+    L.check(L.layernorm_bwd(_p(dy), _ld(dy), _p(dy_row_map), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _ld(dx),
+                            _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0, _p(dw), _p(db), R, w.numel(), _stream()))
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr):
+    a = L.AttnArgs()
+    a.Q, a.K, a.V, a.O = _p(q), _p(k), _p(v), _p(o)
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    a.B, a.H, a.Nq, a.Nk, a.head_dim, a.mask_kind = B, H, Nq, Nk, 64, mask_kind
+    a.scale, a.causal = scale, 1 if causal else 0
+    a.kpad, a.cs, a.modq, a.modk, a.dense = _p(kpad), _p(cs), _p(modq), _p(modk), _p(dense)
+    a.stat_m, a.stat_l = _p(stat_m), _p(stat_l)
+    a.force_tr = force_tr
+    return a
+
+
+def attn_fwd(q, k, v, o, B, H, Nq, Nk, scale, *, mask_kind=L.MASK_NONE, kpad=None, cs=None, modq=None, modk=None, dense=None,
+             causal=False, stat_m=None, stat_l=None, force_tr=-1):
+    """q/k/v/o: 2-D bf16 views whose row t of sample b is row b*N + t; head h occupies columns [64h, 64h+64)."""
+    a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
+    L.check(L.attn_fwd(C.byref(a), _stream()))
+    return o
+
+
+def attn_bwd(q, k, v, o, do, dq, dk, dv, B, H, Nq, Nk, scale, stat_m, stat_l, *, mask_kind=L.MASK_NONE, kpad=None, cs=None,
+             modq=None, modk=None, dense=None, causal=False, force_tr=-1):
+    a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
+    a.dO, a.dQ, a.dK, a.dV = _p(do), _p(dq), _p(dk), _p(dv)
+    a.lddo, a.lddq, a.lddk, a.lddv = do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
+    L.check(L.attn_bwd(C.byref(a), _stream()))
+
+
+# ---------------------------------------------------------------------------------------------
+# heads / loss
+# ---------------------------------------------------------------------------------------------
+def padded_rows(R: int, n_heads: int) -> int:
+    return ru(R, SEG) + SEG * (n_heads - 1)
+
+
+def segment_rows(head_of_row, n_heads, seg_start, seg_count, perm, row_to_padded, tile_group):
+    L.check(L.segment_rows(_p(head_of_row), head_of_row.numel(), n_heads, _p(seg_start), _p(seg_count), _p(perm),
+                           _p(row_to_padded), _p(tile_group), perm.numel(), _stream()))
+
+
+def gather_rows(src, perm, dst, D):
+    L.check(L.gather_rows(_p(src), _ld(src), _p(perm), _p(dst), _ld(dst), perm.numel(), D, _stream()))
+
+
+def cross_entropy(logits, perm, tile_group, target_ids, vocab, seg_start, seg_count, n_heads, max_vocab, row_loss, head_loss,
+                  total_loss, *, loss_type=L.LOSS_MOD, grad_scale=None, write_grad=False):
+    L.check(L.cross_entropy(_p(logits), _ld(logits), _p(perm), _p(tile_group), _p(target_ids), _p(vocab), _p(seg_start),
+                            _p(seg_count), _p(grad_scale), loss_type, n_heads, perm.numel(), max_vocab, _p(row_loss),
+                            _p(head_loss), _p(total_loss), 1 if write_grad else 0, _stream()))
+
+
+# ---------------------------------------------------------------------------------------------
+# element-wise
+# ---------------------------------------------------------------------------------------------
+def swiglu_bwd(da, gu, dgu, H, Hp, R=None):
+    L.check(L.swiglu_bwd(_p(da), _ld(da), _p(gu), _ld(gu), _p(dgu), _ld(dgu), da.shape[0] if R is None else R, H, Hp, _stream()))
+
+
+def gelu_bwd(dh, pre, dpre, H, Hp, R=None):
+    L.check(L.gelu_bwd(_p(dh), _ld(dh), _p(pre), _ld(pre), _p(dpre), _ld(dpre), dh.shape[0] if R is None else R, H, Hp, _stream()))
+
+
+def cast_pad(src, dst):
+    """dst (rows, ld>=cols) bf16 <- src (rows, cols) f32, padding zeroed."""
+    s2 = src.reshape(src.shape[0], -1)
+    L.check(L.cast_pad(_p(s2), s2.stride(0), _p(dst), _ld(dst), s2.shape[0], s2.shape[1], _stream()))
+    return dst
+
+
+def transpose_cast_pad(src, dst):
+    """dst (cols, ld>=rows) bf16 <- src(rows, cols)^T, padding zeroed."""
+    s2 = src.reshape(src.shape[0], -1)
+    L.check(L.transpose_cast_pad(_p(s2), s2.stride(0), _p(dst), _ld(dst), s2.shape[0], s2.shape[1], _stream()))
+    return dst
+
+
+def colsum(dy, db, N, R=None):
+    L.check(L.colsum(_p(dy), _ld(dy), _p(db), dy.shape[0] if R is None else R, N, _stream()))
+
+
+def f32_to_bf16(src, dst):
+    L.check(L.f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()))
+    return dst
+
+
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None):
+    L.check(L.adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _stream()))
+
+
+def sumsq(x, out):
+    L.check(L.sumsq(_p(x), x.numel(), _p(out), _stream()))
+
+
+def clip_coef(ss, max_norm, norm_out, coef_out):
+    L.check(L.clip_coef(_p(ss), float(max_norm or 0.0), _p(norm_out), _p(coef_out), _stream()))
+
+
+def dense_decoder_mask(cs, mod, B, M, causal, use_sep):
+    out = torch.empty(B, M, M, dtype=torch.bool, device=(cs if cs is not None else mod).device)
+    L.check(L.dense_decoder_mask(_p(cs), _p(mod), _p(out), B, M, 1 if causal else 0, 1 if cs is not None else 0,
+                                 1 if use_sep else 0, _stream()))
+    return out

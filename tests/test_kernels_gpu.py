@@ -1,0 +1,396 @@
+"""Per-kernel numerics on a real MI355X: every HIP kernel against a plain fp32 PyTorch restatement of
+the same op on the same (bf16-rounded) inputs.  Integer outputs must match exactly; floating point
+within the tolerance written next to each check (bf16 output rounding = 2^-8 relative)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from fourm.hip import ops, _lib
+    return ops, _lib
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+def max_err(a, b):
+    return float((a.float() - b.float()).abs().max())
+
+
+def randn(*shape, scale=1.0, seed=None):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed if seed is not None else hash(shape) % (2 ** 31))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 260, 192), (1024, 768, 768), (70, 2304, 768)])
+def test_gemm_nt_plain(M, N, K):
+    ops, L = _ops()
+    # asymmetric operands (transposed outputs would not pass)
+    x = bf(randn(M, K, seed=1) + torch.arange(K, device=DEV)[None] * 0.01)
+    w = bf(randn(N, K, seed=2) * 0.1 + torch.arange(N, device=DEV)[:, None] * 0.001)
+    out = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(x, w, out)
+    ref = x.float() @ w.float().t()
+    assert rel_err(out, ref) < 4e-3, rel_err(out, ref)
+    assert max_err(out, bf(ref)) <= 2 ** -6 * float(ref.abs().max())
+
+
+def test_gemm_nt_identity_layout():
+    """A = I check with an asymmetric right operand: catches row/column swaps in the fragment maps."""
+    ops, L = _ops()
+    K = 128
+    x = torch.eye(K, device=DEV, dtype=torch.bfloat16)                       # (M=128, K)
+    w = bf(torch.arange(256 * K, device=DEV).reshape(256, K).float() % 251 - 125)  # (N=256, K), exact in bf16
+    out = torch.zeros(K, 256, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(x, w, out)
+    assert torch.equal(out.float(), w.float().t())
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "residual", "f32"])
+def test_gemm_nt_epilogues(epi):
+    ops, L = _ops()
+    M, N, K = 200, 320, 128
+    x, w = bf(randn(M, K, seed=3)), bf(randn(N, K, seed=4) * 0.2)
+    bias = randn(N, seed=5)
+    acc = x.float() @ w.float().t() + bf(bias).float()
+    if epi == "bias":
+        out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w, out, bias=bias)
+        assert rel_err(out, acc) < 4e-3
+    elif epi == "gelu":
+        out = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        pre = torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w, out, bias=bias, epilogue=L.EPI_GELU, out2=pre)
+        assert rel_err(pre, acc) < 4e-3
+        assert rel_err(out, torch.nn.functional.gelu(bf(acc).float())) < 6e-3
+    elif epi == "residual":
+        res = randn(M, N, seed=6)
+        buf = res.clone()
+        ops.gemm_nt(x, w, buf, bias=bias, epilogue=L.EPI_RESIDUAL, res=buf)     # in place
+        assert rel_err(buf, res + bf(acc).float()) < 3e-3
+    else:
+        bias32 = bias
+        out = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+        ops.gemm_nt(x, w, out, bias=bias32, epilogue=L.EPI_F32)
+        assert rel_err(out, x.float() @ w.float().t() + bias32) < 1e-5
+
+
+@pytest.mark.parametrize("H", [128, 170, 2048])
+def test_gemm_nt_swiglu(H):
+    ops, L = _ops()
+    M, K = 192, 128
+    Hp = ops.ru(H, 64)
+    x = bf(randn(M, K, seed=7))
+    w1, w3 = bf(randn(H, K, seed=8) * 0.2), bf(randn(H, K, seed=9) * 0.2)
+    gu = torch.full((M, 2 * Hp), 3.0, device=DEV, dtype=torch.bfloat16)
+    act = torch.full((M, Hp), 3.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(x, w1, act, epilogue=L.EPI_SWIGLU, w2=w3, out2=gu, Hp=Hp, N=H)
+    g, u = bf(x.float() @ w1.float().t()).float(), bf(x.float() @ w3.float().t()).float()
+    a = bf(torch.nn.functional.silu(g)).float() * u
+    assert rel_err(gu[:, :H], g) < 4e-3 and rel_err(gu[:, Hp:Hp + H], u) < 4e-3
+    assert rel_err(act[:, :H], a) < 8e-3
+    # columns past H inside the last written 4-group must be zero (GEMM K-padding contract)
+    last = min(Hp, ops.ru(H, 4))
+    assert float(act[:, H:last].float().abs().max() if last > H else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("tr", [0, 1])
+@pytest.mark.parametrize("R,N,K", [(64, 128, 128), (256, 200, 136), (1024, 768, 384)])
+def test_gemm_tn(tr, R, N, K):
+    ops, L = _ops()
+    a = bf(randn(R, N, seed=10) + torch.arange(N, device=DEV)[None] * 0.01)
+    b = bf(randn(R, K, seed=11))
+    out = torch.full((N, K), 1.0, device=DEV, dtype=torch.float32)
+    ops.gemm_tn(a, b, out, force_tr=tr)
+    ref = 1.0 + a.float().t() @ b.float()
+    assert rel_err(out, ref) < 1e-4, (tr, rel_err(out, ref))
+
+
+def test_gemm_tn_identity_layout():
+    ops, L = _ops()
+    R = 128
+    a = torch.eye(R, device=DEV, dtype=torch.bfloat16)                 # (R, N=128)
+    b = bf((torch.arange(R * 256, device=DEV).reshape(R, 256) % 251 - 125).float())
+    for tr in (0, 1):
+        out = torch.zeros(R, 256, device=DEV, dtype=torch.float32)
+        ops.gemm_tn(a, b, out, force_tr=tr, splits=1)
+        assert torch.equal(out, b.float()), f"tr={tr}"
+
+
+def test_gemm_grouped():
+    ops, L = _ops()
+    D = 128
+    vocabs = [320, 200, 64]
+    counts = [130, 0, 77]
+    n_heads = len(vocabs)
+    R = 256
+    head = torch.full((R,), -1, dtype=torch.int32)
+    idx = torch.randperm(R, generator=torch.Generator().manual_seed(0))
+    o = 0
+    for h, c in enumerate(counts):
+        head[idx[o:o + c]] = h
+        o += c
+    head = head.to(DEV)
+    Rp = ops.padded_rows(R, n_heads)
+    seg_start = torch.zeros(n_heads, dtype=torch.int32, device=DEV)
+    seg_count = torch.zeros_like(seg_start)
+    perm = torch.zeros(Rp, dtype=torch.int32, device=DEV)
+    r2p = torch.zeros(R, dtype=torch.int32, device=DEV)
+    tile_group = torch.zeros(Rp // 128, dtype=torch.int32, device=DEV)
+    ops.segment_rows(head, n_heads, seg_start, seg_count, perm, r2p, tile_group)
+    assert seg_count.tolist() == counts
+    assert seg_start.tolist() == [0, 256, 256]
+    for h in range(n_heads):
+        rows = torch.nonzero(head == h).flatten()
+        s = int(seg_start[h])
+        assert torch.equal(perm[s:s + len(rows)].long(), rows)          # stable order
+        assert torch.equal(r2p[rows].long(), torch.arange(s, s + len(rows), device=DEV))
+    assert int((perm >= 0).sum()) == sum(counts)
+    y = bf(randn(R, D, seed=12))
+    yp = torch.full((Rp, D), 5.0, device=DEV, dtype=torch.bfloat16)
+    ops.gather_rows(y, perm, yp, D)
+    ws = [bf(randn(v, D, seed=20 + i) * 0.3) for i, v in enumerate(vocabs)]
+    ldl = ops.ru(max(vocabs), 64)
+    logits = torch.zeros(Rp, ldl, device=DEV, dtype=torch.bfloat16)
+    groups = ops.make_groups([dict(W=w, N=v, K=D, ldw=D) for w, v in zip(ws, vocabs)], DEV)
+    ops.gemm_nt_grouped(yp, groups, tile_group, logits, max(vocabs))
+    for h in range(n_heads):
+        rows = torch.nonzero(head == h).flatten()
+        s = int(seg_start[h])
+        if len(rows):
+            ref = y[rows].float() @ ws[h].float().t()
+            assert rel_err(logits[s:s + len(rows), :vocabs[h]], ref) < 4e-3
+    # cross entropy on the segmented logits
+    tgt = torch.stack([torch.randint(0, 64, (R,), generator=torch.Generator().manual_seed(3))]).flatten().to(DEV)
+    vocab_t = torch.tensor(vocabs, dtype=torch.int32, device=DEV)
+    row_loss = torch.zeros(Rp, device=DEV); head_loss = torch.zeros(n_heads, device=DEV); total = torch.zeros(1, device=DEV)
+    saved = logits.clone()
+    for loss_type, name in ((L.LOSS_MOD, "mod"), (L.LOSS_TOKEN, "token")):
+        logits.copy_(saved)
+        gs = torch.tensor([0.5], device=DEV)
+        ops.cross_entropy(logits, perm, tile_group, tgt, vocab_t, seg_start, seg_count, n_heads, max(vocabs), row_loss, head_loss,
+                          total, loss_type=loss_type, grad_scale=gs, write_grad=True)
+        leafs, losses, numel = [], [], []
+        for h in range(n_heads):
+            rows = torch.nonzero(head == h).flatten()
+            s = int(seg_start[h])
+            lg = saved[s:s + len(rows), :vocabs[h]].float().clone().requires_grad_(True)
+            leafs.append(lg)
+            if len(rows):
+                losses.append(torch.nn.functional.cross_entropy(lg, tgt[rows])); numel.append(lg.numel())
+            else:
+                losses.append(torch.zeros((), device=DEV)); numel.append(0)
+        if name == "mod":
+            tot = sum(losses) / n_heads
+        else:
+            tot = sum(l * n for l, n in zip(losses, numel)) / sum(numel)
+        (tot * 0.5).backward()
+        assert abs(float(total) - float(tot)) < 2e-5 * max(1.0, abs(float(tot)))
+        for h in range(n_heads):
+            assert abs(float(head_loss[h]) - float(losses[h])) < 2e-5 * max(1.0, float(losses[h]))
+            rows = torch.nonzero(head == h).flatten()
+            s = int(seg_start[h])
+            if len(rows):
+                assert rel_err(logits[s:s + len(rows), :vocabs[h]], leafs[h].grad) < 6e-3
+                pad = logits[s + len(rows):s + ops.ru(len(rows), 128)]
+                assert float(pad[:, :ops.ru(vocabs[h], 64)].float().abs().max()) == 0.0 if pad.numel() else True
+    # grouped TN: per-head weight gradient
+    dws = [torch.zeros(v, D, device=DEV) for v in vocabs]
+    groups_tn = ops.make_groups([dict(out=dw, N=v) for dw, v in zip(dws, vocabs)], DEV)
+    for tr in (0, 1):
+        for dw in dws:
+            dw.zero_()
+        ops.gemm_tn_grouped(logits, yp, groups_tn, seg_start, seg_count, n_heads, max(vocabs), Rp, D, force_tr=tr)
+        for h in range(n_heads):
+            rows = torch.nonzero(head == h).flatten()
+            s = int(seg_start[h])
+            ref = logits[s:s + len(rows), :vocabs[h]].float().t() @ y[rows].float() if len(rows) else torch.zeros_like(dws[h])
+            assert rel_err(dws[h], ref) < 1e-4 or float(ref.norm()) == 0.0, (tr, h)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,D", [(64, 128), (300, 384), (512, 768), (33, 2048)])
+def test_layernorm(R, D):
+    ops, L = _ops()
+    x = randn(R, D, seed=30) * 2 + 0.5
+    w, b = randn(D, seed=31) * 0.2 + 1, randn(D, seed=32) * 0.1
+    y = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.zeros(R, device=DEV), torch.zeros(R, device=DEV)
+    ops.layernorm_fwd(x, w, b, y, mean, rstd)
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, eps=1e-6)
+    assert max_err(y, bf(ref)) <= 2 ** -7 * float(ref.abs().max())
+    y32 = torch.zeros(R, D, device=DEV)
+    ops.layernorm_fwd(x, w, None, y32)
+    assert max_err(y32, torch.nn.functional.layer_norm(x, (D,), w, None, eps=1e-6)) < 2e-5
+    # backward
+    dy = bf(randn(R, D, seed=33))
+    dres = randn(R, D, seed=34)
+    dx = torch.zeros(R, D, device=DEV); dxb = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    dw, db = torch.ones(D, device=DEV), torch.ones(D, device=DEV)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx, dres=dres, dx_bf16=dxb, dw=dw, db=db)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (D,), wr, br, eps=1e-6).backward(dy.float())
+    assert rel_err(dx, xr.grad + dres) < 1e-5
+    assert rel_err(dxb, xr.grad + dres) < 4e-3
+    assert rel_err(dw - 1, wr.grad) < 1e-4 and rel_err(db - 1, br.grad) < 1e-4
+    # in-place accumulation into dx
+    acc = dres.clone()
+    ops.layernorm_bwd(dy, x, w, mean, rstd, acc, dres=acc)
+    assert rel_err(acc, xr.grad + dres) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+NEG = -torch.finfo(torch.bfloat16).max
+
+
+def ref_attention(q, k, v, blocked, scale):
+    """fp32 restatement with upstream's rounding points (bf16 scores, fp32 softmax, bf16 probabilities)."""
+    s = bf(bf(q.float() @ k.float().transpose(-1, -2)).float() * scale).float()
+    if blocked is not None:
+        s = s.masked_fill(blocked, NEG)
+    p = torch.softmax(s, -1)
+    return bf(p).float() @ v.float(), p
+
+
+def make_masks(kind, B, Nq, Nk, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = dict(kpad=None, cs=None, modq=None, modk=None, dense=None, blocked=None)
+    if kind == "keypad":
+        kp = torch.rand(B, Nk, generator=g) < 0.3
+        kp[0] = True                      # one fully blocked sample: uniform attention rows
+        out["kpad"] = kp.to(DEV)
+        out["blocked"] = kp[:, None, None, :].to(DEV)
+    elif kind == "decoder":
+        assert Nq == Nk
+        dam = (torch.rand(B, Nq, generator=g) < 0.5).int() * torch.randint(1, 4, (B, Nq), generator=g).int()
+        dam[:, 0] = 0                     # rows before the first non-zero entry are fully blocked
+        cs = dam.cumsum(-1).int()
+        mod = torch.randint(0, 3, (B, Nq), generator=g).short().sort(-1).values
+        blk = (torch.arange(Nk)[None, None, :] >= cs[:, :, None]) | (mod[:, :, None] != mod[:, None, :])
+        out.update(cs=cs.to(DEV), modq=mod.to(DEV), modk=mod.to(DEV), blocked=blk[:, None].to(DEV))
+    elif kind == "dense":
+        d = torch.rand(B, Nq, Nk, generator=g) < 0.4
+        out.update(dense=d.to(DEV), blocked=d[:, None].to(DEV))
+    return out
+
+
+@pytest.mark.parametrize("tr", [0, 1])
+@pytest.mark.parametrize("kind,Nq,Nk", [("none", 128, 128), ("keypad", 128, 128), ("decoder", 128, 128), ("dense", 96, 160),
+                                        ("keypad", 40, 200), ("none", 196, 196), ("decoder", 256, 256)])
+def test_attention(kind, Nq, Nk, tr):
+    ops, L = _ops()
+    B, H = 3, 2
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = bf(randn(B * Nq, 3 * D, seed=40) * 1.5)
+    if Nq == Nk:
+        q2, k2, v2 = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        q2 = qkv[:, :D]
+        kv = bf(randn(B * Nk, 2 * D, seed=41) * 1.5)
+        k2, v2 = kv[:, :D], kv[:, D:]
+    mk = make_masks(kind, B, Nq, Nk, seed=42)
+    kinds = dict(none=L.MASK_NONE, keypad=L.MASK_KEYPAD, decoder=L.MASK_DECODER, dense=L.MASK_DENSE)
+    o = torch.zeros(B * Nq, D, device=DEV, dtype=torch.bfloat16)
+    sm, sl = torch.zeros(B, H, Nq, device=DEV), torch.zeros(B, H, Nq, device=DEV)
+    ops.attn_fwd(q2, k2, v2, o, B, H, Nq, Nk, scale, mask_kind=kinds[kind], kpad=mk["kpad"], cs=mk["cs"], modq=mk["modq"],
+                 modk=mk["modk"], dense=mk["dense"], stat_m=sm, stat_l=sl, force_tr=tr)
+    qh = q2.reshape(B, Nq, H, 64).transpose(1, 2).float().requires_grad_(True)
+    kh = k2.reshape(B, Nk, H, 64).transpose(1, 2).float().requires_grad_(True)
+    vh = v2.reshape(B, Nk, H, 64).transpose(1, 2).float().requires_grad_(True)
+    ref, p = ref_attention(qh, kh, vh, mk["blocked"], scale)
+    oh = o.reshape(B, Nq, H, 64).transpose(1, 2).float()
+    assert rel_err(oh, ref) < 8e-3, (kind, tr, rel_err(oh, ref))
+    assert max_err(oh, ref) < 0.06
+    # backward (straight-through the rounding points, like autograd upstream)
+    do = bf(randn(B * Nq, D, seed=43))
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if mk["blocked"] is not None:
+        s = s.masked_fill(mk["blocked"], NEG)
+    (torch.softmax(s, -1) @ vh).backward(do.reshape(B, Nq, H, 64).transpose(1, 2).float())
+    dq = torch.zeros(B * Nq, D, device=DEV, dtype=torch.bfloat16)
+    dk = torch.zeros(B * Nk, D, device=DEV, dtype=torch.bfloat16)
+    dv = torch.zeros(B * Nk, D, device=DEV, dtype=torch.bfloat16)
+    ops.attn_bwd(q2, k2, v2, o, do, dq, dk, dv, B, H, Nq, Nk, scale, sm, sl, mask_kind=kinds[kind], kpad=mk["kpad"], cs=mk["cs"],
+                 modq=mk["modq"], modk=mk["modk"], dense=mk["dense"], force_tr=tr)
+    for name, got, want, n in (("dq", dq, qh.grad, Nq), ("dk", dk, kh.grad, Nk), ("dv", dv, vh.grad, Nk)):
+        got = got.reshape(B, n, H, 64).transpose(1, 2).float()
+        assert rel_err(got, want) < 2e-2, (kind, tr, name, rel_err(got, want))
+
+
+# ------------------------------------------------------------------------------------------------
+# element-wise
+# ------------------------------------------------------------------------------------------------
+def test_swiglu_gelu_bwd():
+    ops, L = _ops()
+    R, H = 100, 170
+    Hp = ops.ru(H, 64)
+    gu = torch.zeros(R, 2 * Hp, device=DEV, dtype=torch.bfloat16)
+    g, u = bf(randn(R, H, seed=50)), bf(randn(R, H, seed=51))
+    gu[:, :H], gu[:, Hp:Hp + H] = g, u
+    da = torch.zeros(R, Hp, device=DEV, dtype=torch.bfloat16); da[:, :H] = bf(randn(R, H, seed=52))
+    dgu = torch.full((R, 2 * Hp), 9.0, device=DEV, dtype=torch.bfloat16)
+    ops.swiglu_bwd(da, gu, dgu, H, Hp)
+    gr, ur = g.float().requires_grad_(True), u.float().requires_grad_(True)
+    (torch.nn.functional.silu(gr) * ur).backward(da[:, :H].float())
+    assert rel_err(dgu[:, :H], gr.grad) < 8e-3 and rel_err(dgu[:, Hp:Hp + H], ur.grad) < 8e-3
+    assert float(dgu[:, H:Hp].float().abs().max()) == 0 and float(dgu[:, Hp + H:].float().abs().max()) == 0
+    pre = torch.zeros(R, Hp, device=DEV, dtype=torch.bfloat16); pre[:, :H] = g
+    dpre = torch.full((R, Hp), 9.0, device=DEV, dtype=torch.bfloat16)
+    ops.gelu_bwd(da, pre, dpre, H, Hp)
+    pr = g.float().requires_grad_(True)
+    torch.nn.functional.gelu(pr).backward(da[:, :H].float())
+    assert rel_err(dpre[:, :H], pr.grad) < 6e-3 and float(dpre[:, H:].float().abs().max()) == 0
+
+
+def test_weight_shadows_and_colsum():
+    ops, L = _ops()
+    w = randn(170, 128, seed=60)
+    a = torch.full((170, 192), 4.0, device=DEV, dtype=torch.bfloat16)
+    ops.cast_pad(w, a)
+    assert torch.equal(a[:, :128], bf(w)) and float(a[:, 128:].float().abs().max()) == 0
+    t = torch.full((128, 192), 4.0, device=DEV, dtype=torch.bfloat16)
+    ops.transpose_cast_pad(w, t)
+    assert torch.equal(t[:, :170], bf(w.t())) and float(t[:, 170:].float().abs().max()) == 0
+    dy = bf(randn(300, 200, seed=61))
+    db = torch.ones(200, device=DEV)
+    ops.colsum(dy, db, 200)
+    assert rel_err(db - 1, dy.float().sum(0)) < 1e-5
+
+
+def test_adamw_matches_torch():
+    ops, L = _ops()
+    n = 10007
+    p0, g = randn(n + 1, seed=70)[:n + 1], randn(n + 1, seed=71)
+    p = p0.clone(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.05)
+    for step in range(1, 4):
+        ref.grad = g.clone() * step
+        opt.step()
+        ops.adamw(p, g * step, m, v, p.numel(), 1e-3, 0.9, 0.95, 1e-8, 0.05, step)
+    assert max_err(p, ref.detach()) < 1e-6
+    ss = torch.zeros(1, device=DEV); nrm = torch.zeros(1, device=DEV); coef = torch.zeros(1, device=DEV)
+    ops.sumsq(g, ss)
+    ops.clip_coef(ss, 1.0, nrm, coef)
+    assert abs(float(nrm) - float(g.norm())) < 1e-3 * float(g.norm())
+    assert abs(float(coef) - min(1.0, 1.0 / (float(g.norm()) + 1e-6))) < 1e-6
