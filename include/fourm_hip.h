@@ -45,7 +45,9 @@ typedef struct fm_gemm_group {  /* one entry per row segment (modality) in group
 /* out[m][n] = sum_k X[m][k] * W[n][k]  (+ epilogue).
  * Replaces nn.Linear forward under bf16 autocast — fourm/models/fm_utils.py:116-126,137-144,155-157,
  * 190-194 — and, with a transposed weight shadow, its input gradient.
- * K % 64 == 0 (zero padded), ldw/ldx % 8 == 0, N % 4 == 0 (any N for FM_EPI_SWIGLU), ldo % 4 == 0.
+ * K % 64 == 0 (zero padded), ldw/ldx % 8 == 0, ldo % 4 == 0 and ldo >= roundup4(N): a lane stores 4
+ * consecutive features, so for N % 4 != 0 the columns [N, roundup4(N)) of out receive don't-care values
+ * (FM_EPI_SWIGLU writes zeros there instead).
  * Grouped mode (groups != NULL): rows of X are segmented in 128-row tiles, tile_group[tile] selects
  * the group (or -1 = skip); W/N/K/ldw come from the group record, max_N bounds the launch. */
 typedef struct fm_gemm_nt_args {
@@ -215,9 +217,10 @@ int fm_cross_entropy(void* logits, int ldl, const int32_t* perm, const int32_t* 
  * ---------------------------------------------------------------------------------------------- */
 int fm_swiglu_bwd(const void* da, int ldda, const void* gu, int ldgu, void* dgu, int lddgu, int R, int H, int Hp, void* stream);
 int fm_gelu_bwd(const void* dh, int lddh, const void* pre, int ldp, void* dpre, int lddp, int R, int H, int Hp, void* stream);
-/* bf16 weight shadows: dst[r][c] = src[r][c] (pad columns zero) / dst[c][r] = src[r][c] (pad columns zero) */
+/* bf16 weight shadows: dst[r][c] = src[r][c], columns [cols, ld_dst) zero /
+ * dst[c][r] = src[r][c], columns [rows, dst_cols) zero (dst_cols <= ld_dst) */
 int fm_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, void* stream);
-int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, void* stream);
+int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int dst_cols, int rows, int cols, void* stream);
 int fm_colsum(const void* dy, int ldy, void* db, int R, int N, void* stream);            /* db[n] += sum_r dy[r][n] */
 int fm_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream);
 /* torch.optim.AdamW update on a contiguous fp32 range (fourm/utils/optim_factory.py:239-240);

@@ -430,7 +430,7 @@ int fill(AttnArgs& a, const fm_attn_args* p, const char* who) {
     return 0;
 }
 
-int g_attn_tr = 0;
+int g_attn_tr = 1;   // transpose reads verified on hardware (tools/probe_gfx950.hip)
 
 }  // namespace
 

@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256) void cast_pad_kernel(const float* __restrict__
     }
 }
 
-// dst (cols_pad_rows = cols, ldd >= rows) bf16 <- transpose of src (rows, cols) f32; dst columns [rows, ldd) zero.
+// dst (cols, dst_cols >= rows; row stride ldd) bf16 <- transpose of src (rows, cols) f32; dst columns [rows, dst_cols) zero.
 // 64x64 tiles through LDS: coalesced on both sides.
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd, int rows, int cols) {
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, int ldd, int dst_cols, int rows, int cols) {
     __shared__ float tile[64][65];
     const int tr0 = blockIdx.y * 64, tc0 = blockIdx.x * 64;     // tile origin in src (row, col)
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int c = i / 64, r = i % 64;                     // dst row = src col
         const int gc = tc0 + c, gr = tr0 + r;
-        if (gc < cols && gr < ldd) dst[(size_t)gc * ldd + gr] = f2bf(tile[r][c]);
+        if (gc < cols && gr < dst_cols) dst[(size_t)gc * ldd + gr] = f2bf(tile[r][c]);
     }
 }
 
@@ -208,10 +208,10 @@ extern "C" int fm_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, i
     return 0;
 }
 
-extern "C" int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, void* stream) {
-    FM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_dst >= rows, "fm_transpose_cast_pad: bad argument");
-    dim3 grid((cols + 63) / 64, (ld_dst + 63) / 64);
-    hipLaunchKernelGGL(transpose_cast_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, (bf16_t*)dst, ld_dst, rows, cols);
+extern "C" int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int dst_cols, int rows, int cols, void* stream) {
+    FM_CHECK_ARG(src && dst && rows > 0 && cols > 0 && dst_cols >= rows && ld_dst >= dst_cols, "fm_transpose_cast_pad: bad argument");
+    dim3 grid((cols + 63) / 64, (dst_cols + 63) / 64);
+    hipLaunchKernelGGL(transpose_cast_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, (bf16_t*)dst, ld_dst, dst_cols, rows, cols);
     FM_CHECK_LAUNCH("fm_transpose_cast_pad");
     return 0;
 }

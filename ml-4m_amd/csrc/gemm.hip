@@ -337,7 +337,9 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     FM_CHECK_ARG(p->M > 0 && (grouped || (p->N > 0 && p->K > 0)), "fm_gemm_nt: bad shape M=%d N=%d K=%d", p->M, p->N, p->K);
     FM_CHECK_ARG(grouped || p->K % BK == 0, "fm_gemm_nt: K=%d must be a multiple of %d (zero padded)", p->K, BK);
     FM_CHECK_ARG(p->ldx % 8 == 0 && (grouped || p->ldw % 8 == 0), "fm_gemm_nt: leading dims must be multiples of 8");
-    FM_CHECK_ARG(grouped || p->N % 4 == 0, "fm_gemm_nt: N=%d must be a multiple of 4", p->N);
+    // a lane stores 4 consecutive features: when N % 4 != 0 the last group spills into [N, roundup4(N))
+    FM_CHECK_ARG(grouped || p->epilogue == FM_EPI_SWIGLU || p->ldo >= (p->N + 3) / 4 * 4, "fm_gemm_nt: ldo=%d too small for N=%d", p->ldo, p->N);
+    FM_CHECK_ARG(!p->bias || (((uintptr_t)p->bias) & 15) == 0, "fm_gemm_nt: bias must be 16-byte aligned");
     FM_CHECK_ARG(p->ldo % 4 == 0, "fm_gemm_nt: ldo must be a multiple of 4");
     NTArgs a{};
     a.W = (const bf16_t*)p->W; a.W2 = (const bf16_t*)p->W2; a.X = (const bf16_t*)p->X;
@@ -366,7 +368,7 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     return -1;
 }
 
-static int g_tn_use_tr = 0;
+static int g_tn_use_tr = 1;   // ds_read_b64_tr_b16 semantics verified on hardware (tools/probe_gfx950.hip)
 extern "C" void fm_set_tn_transpose_read(int on) { g_tn_use_tr = on; }
 extern "C" int fm_get_tn_transpose_read(void) { return g_tn_use_tr; }
 

@@ -116,7 +116,7 @@ cross_entropy = _sig("fm_cross_entropy", vp, i32, vp, vp, vp, vp, vp, vp, vp, i3
 swiglu_bwd = _sig("fm_swiglu_bwd", vp, i32, vp, i32, vp, i32, i32, i32, i32, vp)
 gelu_bwd = _sig("fm_gelu_bwd", vp, i32, vp, i32, vp, i32, i32, i32, i32, vp)
 cast_pad = _sig("fm_cast_pad", vp, i32, vp, i32, i32, i32, vp)
-transpose_cast_pad = _sig("fm_transpose_cast_pad", vp, i32, vp, i32, i32, i32, vp)
+transpose_cast_pad = _sig("fm_transpose_cast_pad", vp, i32, vp, i32, i32, i32, i32, vp)
 colsum = _sig("fm_colsum", vp, i32, vp, i32, i32, vp)
 f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
 adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp)

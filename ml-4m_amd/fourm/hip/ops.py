@@ -190,9 +190,10 @@ def cast_pad(src, dst):
 
 
 def transpose_cast_pad(src, dst):
-    """dst (cols, ld>=rows) bf16 <- src(rows, cols)^T, padding zeroed."""
+    """dst (cols, width>=rows) bf16 <- src(rows, cols)^T, columns [rows, width) zeroed (dst may be a
+    column slice of a wider buffer)."""
     s2 = src.reshape(src.shape[0], -1)
-    L.check(L.transpose_cast_pad(_p(s2), s2.stride(0), _p(dst), _ld(dst), s2.shape[0], s2.shape[1], _stream()))
+    L.check(L.transpose_cast_pad(_p(s2), s2.stride(0), _p(dst), _ld(dst), dst.shape[1], s2.shape[0], s2.shape[1], _stream()))
     return dst
 
 
