@@ -1,0 +1,725 @@
+"""Host-side executor of the 4M train step on one MI355X.
+
+Owns (a) the flat fp32 parameter / gradient stores, (b) the bf16 weight shadows in the layouts the
+GEMM kernels want (plain for y = x W^T, transposed for dX = dY W, both zero padded to multiples of
+64 on the reduction axis), (c) the static activation workspace, and (d) the launch sequence of the
+forward and of the hand-written backward.  There is no autograd graph inside the step: one
+``torch.autograd.Function`` (in fourm/models/fm.py) hands the upstream gradient of the loss to
+``train_backward`` which fills ``param.grad`` views of the flat gradient store.
+
+Every shape in a step is static and nothing synchronises with the host: ragged per-modality row
+counts are handled on the device (segment tables), so the whole step can be captured in a hipGraph.
+
+Numerics follow CUDA autocast(bf16) as used upstream (run_training_4m.py:723): GEMM operands and
+outputs bf16 with fp32 accumulation, LayerNorm / softmax / cross-entropy in fp32, fp32 residual
+stream, fp32 master weights and gradients.
+"""
+import math
+import random
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+
+_WEIGHT_EPOCH = 0
+
+
+def bump_weight_epoch():
+    """Called by optimizers that update parameters behind torch's version counters (FusedAdamW)."""
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+def ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class Shadow:
+    """bf16 copies of one Linear weight (out, in): ``w`` (out, in_p) and ``wt`` (in, out_p), each rebuilt
+    lazily when the fp32 master changed."""
+    __slots__ = ("param", "w", "wt", "stamp_w", "stamp_wt")
+
+    def __init__(self, param):
+        self.param, self.w, self.wt, self.stamp_w, self.stamp_wt = param, None, None, None, None
+
+
+class Workspace:
+    """Named device buffers, allocated (zero-filled) on first use and reused while the shape matches.
+    Padding rows / columns are never written by any kernel, so they stay zero for the GEMM contracts."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: Dict[tuple, torch.Tensor] = {}
+
+    def get(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        t = self.bufs.get(key)
+        if t is None:
+            t = self.bufs[key] = torch.zeros(shape, dtype=dtype, device=self.device)
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+class FourMEngine:
+    def __init__(self, model):
+        from fourm.models.fm_utils import GatedMlp, NormAttention, act_name
+        self.model = model
+        self.D = model.dim
+        blk = model.encoder[0] if len(model.encoder) else model.decoder[0]
+        attn0 = blk.attn if hasattr(blk, "attn") else blk.self_attn
+        self.H = attn0.num_heads
+        if self.D // self.H != 64:
+            raise NotImplementedError(f"head_dim {self.D // self.H}: the HIP attention kernels are built for head_dim 64")
+        if isinstance(attn0, NormAttention):
+            raise NotImplementedError("qk_norm=True (per-head LayerNorm on q/k) has no HIP kernel yet")
+        self.gated = isinstance(blk.mlp, GatedMlp)
+        self.act = act_name(blk.mlp.act)
+        if self.gated and self.act != "silu":
+            raise NotImplementedError("gated MLP is implemented for SiLU (SwiGLU) only")
+        if not self.gated and self.act != "gelu":
+            raise NotImplementedError("plain MLP is implemented for exact GELU only")
+        self.Hd = blk.mlp.hidden_features
+        self.Hp = ru(self.Hd, 64)
+        self.scale = 64 ** -0.5
+        self.eps = blk.norm1.eps
+        self.ws: Optional[Workspace] = None
+        self.shadows: Dict[int, Shadow] = {}
+        self.flat_params = self.flat_grads = None
+        self._slices = {}
+        self._ctx = None           # saved state of the last training forward
+        self._grad_zeroed_for = None
+
+    # ------------------------------------------------------------------------------------------
+    # flat parameter / gradient stores
+    # ------------------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.model.mask_token.device
+
+    def _unique_params(self):
+        seen, out = set(), []
+        for n, p in self.model.named_parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                out.append((n, p))
+        return out
+
+    def flatten(self):
+        """Move every parameter into one flat fp32 buffer (decay-type tensors first, then norm/bias
+        tensors, each 64-byte aligned) and create the gradient store with the same layout."""
+        named = self._unique_params()
+        dev = self.device
+
+        def nodecay(n):
+            return "norm." in n or ".norm" in n or n.endswith(".bias")
+        named.sort(key=lambda np_: (nodecay(np_[0]),))
+        off, slices = 0, {}
+        for n, p in named:
+            slices[id(p)] = (off, p.numel())
+            off += ru(p.numel(), 16)
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        for n, p in named:
+            o, k = slices[id(p)]
+            flat[o:o + k].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + k].view(p.shape)
+        self.flat_params, self._slices = flat, slices
+        self.flat_grads = torch.zeros_like(flat)
+        self._named = named
+        bump_weight_epoch()
+
+    def _ensure_flat(self):
+        if self.flat_params is None or self.flat_params.device != self.device:
+            self.flatten()
+            return
+        for n, p in self._named[:4] + self._named[-4:]:      # cheap check that nobody re-pointed .data
+            o, k = self._slices[id(p)]
+            if p.data_ptr() != self.flat_params.data_ptr() + 4 * o:
+                self.flatten()
+                return
+
+    def grad_view(self, p):
+        o, k = self._slices[id(p)]
+        return self.flat_grads[o:o + k].view(p.shape)
+
+    def attach_grads(self, zero: bool):
+        """param.grad := view into the flat gradient store.  ``zero`` clears the store first (a fresh
+        accumulation window: the trainer called optimizer.zero_grad())."""
+        if zero:
+            self.flat_grads.zero_()
+        for n, p in self._named:
+            if p.requires_grad:
+                p.grad = self.grad_view(p)
+
+    # ------------------------------------------------------------------------------------------
+    # weight shadows
+    # ------------------------------------------------------------------------------------------
+    def _shadow(self, p) -> Shadow:
+        s = self.shadows.get(id(p))
+        if s is None:
+            s = self.shadows[id(p)] = Shadow(p)
+        return s
+
+    def _stamp(self, p):
+        return (p._version, _WEIGHT_EPOCH, p.data_ptr())
+
+    def w(self, p):
+        """(out, in_p) bf16, pad columns zero: the W operand of y = x W^T."""
+        s = self._shadow(p)
+        stamp = self._stamp(p)
+        if s.stamp_w != stamp:
+            out_f, in_f = p.shape[0], p[0].numel()
+            if s.w is None or s.w.device != p.device:
+                s.w = torch.zeros(out_f, ru(in_f, 64), dtype=torch.bfloat16, device=p.device)
+            ops.cast_pad(p.detach(), s.w)
+            s.stamp_w = stamp
+        return s.w
+
+    def wt(self, p):
+        """(in, out_p) bf16, pad columns zero: the W operand of dX = dY W."""
+        s = self._shadow(p)
+        stamp = self._stamp(p)
+        if s.stamp_wt != stamp:
+            out_f, in_f = p.shape[0], p[0].numel()
+            if s.wt is None or s.wt.device != p.device:
+                s.wt = torch.zeros(in_f, ru(out_f, 64), dtype=torch.bfloat16, device=p.device)
+            ops.transpose_cast_pad(p.detach(), s.wt)
+            s.stamp_wt = stamp
+        return s.wt
+
+    def w13t(self, mlp):
+        """(D, 2*Hp) bf16 = [fc1^T | fc3^T]: the W operand of d(h2) = [dg | du] [fc1; fc3]."""
+        key = ("w13t", id(mlp))
+        ent = self.shadows.get(key)
+        stamp = (self._stamp(mlp.fc1.weight), self._stamp(mlp.fc3.weight))
+        if ent is None or ent[1] != stamp:
+            buf = ent[0] if ent is not None else torch.zeros(self.D, 2 * self.Hp, dtype=torch.bfloat16, device=self.device)
+            ops.transpose_cast_pad(mlp.fc1.weight.detach(), buf[:, :self.Hp])
+            ops.transpose_cast_pad(mlp.fc3.weight.detach(), buf[:, self.Hp:])
+            self.shadows[key] = ent = (buf, stamp)
+        return ent[0]
+
+    # ------------------------------------------------------------------------------------------
+    # selection + embedding
+    # ------------------------------------------------------------------------------------------
+    def _mod_desc(self, md: L.ModDesc, name, d, emb, is_dec, head_index=0):
+        info = self.model.modality_info[name]
+        kind = emb.kind
+        t = d["tensor"]
+        B = t.shape[0]
+        mask = d["target_mask" if is_dec else "input_mask"]
+        mask = mask.reshape(B, -1)
+        if mask.dtype != torch.bool:
+            mask = mask.bool()
+        mask = mask.contiguous()
+        keep = [mask]
+        md.mask, md.mask_stride = mask.data_ptr(), mask.shape[1]
+        md.kind, md.mod_id, md.head_index = kind, int(info["id"]), head_index
+        md.pos = emb.pos_emb.data_ptr()
+        md.mod_emb = emb.mod_emb.data_ptr()
+        md.shifted = 1 if (is_dec and kind == L.KIND_SEQ) else 0
+        md.max_len = getattr(emb, "max_length", 0) or 0
+        if kind in (L.KIND_TOK, L.KIND_SEQ):
+            ids = t.reshape(B, -1)
+            if ids.dtype not in (torch.int32, torch.int64):
+                ids = ids.long()
+            ids = ids.contiguous()
+            keep.append(ids)
+            md.ids, md.ids_are_i64, md.id_stride = ids.data_ptr(), 1 if ids.dtype == torch.int64 else 0, ids.shape[1]
+            md.table = emb.token_emb.weight.data_ptr()
+            md.L = ids.shape[1] - (1 if md.shifted else 0)
+            if ids.shape[1] != mask.shape[1]:
+                raise ValueError(f"{name}: tensor has {ids.shape[1]} positions but the mask has {mask.shape[1]}")
+        elif kind == L.KIND_PATCH:
+            px = t.float().contiguous()
+            keep.append(px)
+            _, C, Hh, Ww = px.shape
+            ps = emb.patch_size[0]
+            md.ids, md.id_stride = px.data_ptr(), C * Hh * Ww
+            md.patch, md.channels, md.grid_w = ps, C, Ww // ps
+            md.L = (Hh // ps) * (Ww // ps)
+        else:  # KIND_SEQ_EMB
+            e = t.float().contiguous()
+            keep.append(e)
+            md.ids, md.id_stride, md.orig_dim = e.data_ptr(), e.shape[1] * e.shape[2], e.shape[2]
+            md.proj_bias = emb.emb_proj.bias.data_ptr()
+            md.L = e.shape[1]
+        if is_dec:
+            dam = d["decoder_attention_mask"].reshape(B, -1)
+            if dam.dtype != torch.int32:
+                dam = dam.int()
+            dam = dam.contiguous()
+            keep.append(dam)
+            md.dam = dam.data_ptr()
+        return keep
+
+    def select(self, mod_dict, n_keep: int, is_dec: bool, order: List[str], prefix: str, want_x0=True, heads=None):
+        """Run the fused concat/partition/embed kernel for one side.  Returns a dict of device tensors.
+        With ``want_x0`` the dense projections (pixels, T5 embeddings) are added to ``x0 = tokens + emb``
+        (what the trunk consumes); without it they are added to ``tokens`` (the upstream sub-API view)."""
+        m = self.model
+        embs = m.decoder_embeddings if is_dec else m.encoder_embeddings
+        names = [n for n in order if n in embs]
+        if not names:
+            raise ValueError("no modality of mod_dict is known to the model")
+        if len(names) > L.FM_MAX_MODS:
+            raise ValueError(f"{len(names)} modalities exceed FM_MAX_MODS={L.FM_MAX_MODS}")
+        B = mod_dict[names[0]]["tensor"].shape[0]
+        D, ws = self.D, self.ws
+        n_reg = 0 if is_dec else m.num_register_tokens
+        Nt = n_reg + n_keep
+        R, Rp = B * Nt, ru(B * Nt, 128)
+        desc = L.SelectDesc()
+        keep, total = [], 0
+        # heads = decoder modalities present in this batch, in mod_dict order (fm.py:669-671, :590)
+        head_names = heads if heads is not None else [n for n in mod_dict if n in m.decoder_embeddings]
+        out_heads = head_names
+        patch_ld = seq_ld = 0
+        for i, n in enumerate(names):
+            keep += self._mod_desc(desc.mods[i], n, mod_dict[n], embs[n], is_dec, head_names.index(n) if is_dec else 0)
+            total += desc.mods[i].L
+            if desc.mods[i].kind == L.KIND_PATCH:
+                patch_ld = max(patch_ld, ru(embs[n].proj.weight.shape[1], 64))
+            if desc.mods[i].kind == L.KIND_SEQ_EMB:
+                seq_ld = max(seq_ld, ru(embs[n].orig_emb_dim, 64))
+        desc.n_mods, desc.batch, desc.dim, desc.n_keep, desc.n_reg = len(names), B, D, n_keep, n_reg
+        desc.total_len, desc.is_decoder = total, 1 if is_dec else 0
+        if n_keep > total:
+            raise ValueError(f"asked to keep {n_keep} tokens but the batch only has {total} positions")
+        out = dict(B=B, Nt=Nt, R=R, names=names, heads=out_heads)
+        f32, dev = torch.float32, self.device
+        out["tokens"] = ws.get(prefix + "tokens", (Rp, D), f32)
+        out["emb"] = ws.get(prefix + "emb", (Rp, D), f32)
+        out["x0"] = ws.get(prefix + "x0", (Rp, D), f32) if want_x0 else None
+        out["mask"] = ws.get(prefix + "mask", (B, Nt), torch.bool)
+        out["mod_mask"] = ws.get(prefix + "mod_mask", (B, Nt), torch.int16)
+        out["slot_mod"] = ws.get(prefix + "slot_mod", (B, Nt), torch.int32)
+        out["slot_src"] = ws.get(prefix + "slot_src", (B, Nt), torch.int32)
+        out["slot_pos"] = ws.get(prefix + "slot_pos", (B, Nt), torch.int32)
+        desc.tokens, desc.emb = out["tokens"].data_ptr(), out["emb"].data_ptr()
+        desc.x0 = out["x0"].data_ptr() if want_x0 else None
+        desc.out_mask, desc.out_mod = out["mask"].data_ptr(), out["mod_mask"].data_ptr()
+        desc.slot_mod, desc.slot_src, desc.slot_pos = out["slot_mod"].data_ptr(), out["slot_src"].data_ptr(), out["slot_pos"].data_ptr()
+        if n_reg:
+            desc.reg_tokens = m.register_tokens.data_ptr()
+        if is_dec:
+            out["target_ids"] = ws.get(prefix + "target_ids", (B, Nt), torch.int64)
+            out["cs"] = ws.get(prefix + "cs", (B, Nt), torch.int32)
+            out["mod_pre"] = ws.get(prefix + "mod_pre", (B, Nt), torch.int16)
+            out["head_of_row"] = ws.get(prefix + "head_of_row", (B, Nt), torch.int32)
+            desc.mask_token = m.mask_token.data_ptr()
+            desc.target_ids, desc.out_cs = out["target_ids"].data_ptr(), out["cs"].data_ptr()
+            desc.out_mod_pre, desc.out_mod_index = out["mod_pre"].data_ptr(), out["head_of_row"].data_ptr()
+        if patch_ld:
+            out["patch_rows"] = ws.get(prefix + "patch_rows", (Rp, patch_ld), torch.bfloat16)
+            desc.patch_rows, desc.patch_ld = out["patch_rows"].data_ptr(), patch_ld
+        if seq_ld:
+            out["seqemb_rows"] = ws.get(prefix + "seqemb_rows", (Rp, seq_ld), torch.bfloat16)
+            desc.seqemb_rows, desc.seqemb_ld = out["seqemb_rows"].data_ptr(), seq_ld
+        L.check(L.select_embed(ops.C.byref(desc), ops._stream()))
+        out["_keep"] = keep
+        # dense projections of pixel / embedding modalities, added onto the (zero) token rows
+        for n in names:
+            e = embs[n]
+            if e.kind == L.KIND_PATCH:
+                dst = out["x0"] if want_x0 else out["tokens"]
+                ops.gemm_nt(out["patch_rows"], self.w(e.proj.weight), dst, epilogue=L.EPI_RESIDUAL, res=dst, M=R, N=D)
+            elif e.kind == L.KIND_SEQ_EMB:
+                dst = out["x0"] if want_x0 else out["tokens"]
+                ops.gemm_nt(out["seqemb_rows"], self.w(e.emb_proj.weight), dst, epilogue=L.EPI_RESIDUAL, res=dst, M=R, N=D)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # building blocks (forward).  `sv` is the per-layer dict that keeps what backward needs.
+    # ------------------------------------------------------------------------------------------
+    def _ln(self, norm, x, y, R, sv=None, key=None, tag="", row_map=None):
+        mean = rstd = None
+        if sv is not None:
+            mean = self.ws.get(f"{tag}.{key}.mu", (x.shape[0],), torch.float32)
+            rstd = self.ws.get(f"{tag}.{key}.rs", (x.shape[0],), torch.float32)
+            sv[key + ".mu"], sv[key + ".rs"] = mean, rstd
+        ops.layernorm_fwd(x, norm.weight, norm.bias, y, mean, rstd, row_map=row_map, eps=norm.eps, R=R)
+        return y
+
+    def _buf(self, sv, tag, key, shape, dtype):
+        """Per-layer buffer when saving for backward, shared scratch otherwise."""
+        name = f"{tag}.{key}" if sv is not None else f"scratch.{key}"
+        t = self.ws.get(name, shape, dtype)
+        if sv is not None:
+            sv[key] = t
+        return t
+
+    def _mlp_fwd(self, mlp, h, x_res, x_out, R, Rp, sv, tag):
+        bf = torch.bfloat16
+        if self.gated:
+            gu = self._buf(sv, tag, "gu", (Rp, 2 * self.Hp), bf)
+            act = self._buf(sv, tag, "act", (Rp, self.Hp), bf)
+            ops.gemm_nt(h, self.w(mlp.fc1.weight), act, epilogue=L.EPI_SWIGLU, w2=self.w(mlp.fc3.weight), out2=gu, Hp=self.Hp,
+                        bias=mlp.fc1.bias, bias2=mlp.fc3.bias, M=R, N=self.Hd, K=self.D)
+        else:
+            pre = self._buf(sv, tag, "pre", (Rp, self.Hp), bf)
+            act = self._buf(sv, tag, "act", (Rp, self.Hp), bf)
+            ops.gemm_nt(h, self.w(mlp.fc1.weight), act, epilogue=L.EPI_GELU, out2=pre, bias=mlp.fc1.bias, M=R, N=self.Hd, K=self.D)
+        ops.gemm_nt(act, self.w(mlp.fc2.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=mlp.fc2.bias, M=R, N=self.D, K=self.Hp)
+
+    def _self_attn_fwd(self, attn, h, x_res, x_out, B, N, R, Rp, mask, sv, tag):
+        bf, D = torch.bfloat16, self.D
+        qkv = self._buf(sv, tag, "qkv", (Rp, 3 * D), bf)
+        o = self._buf(sv, tag, "o", (Rp, D), bf)
+        ops.gemm_nt(h, self.w(attn.qkv.weight), qkv, bias=attn.qkv.bias, M=R, N=3 * D, K=D)
+        sm = sl = None
+        if sv is not None:
+            sm = self._buf(sv, tag, "sm", (B, self.H, N), torch.float32)
+            sl = self._buf(sv, tag, "sl", (B, self.H, N), torch.float32)
+        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, self.H, N, N, self.scale, stat_m=sm, stat_l=sl, **mask)
+        ops.gemm_nt(o, self.w(attn.proj.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=attn.proj.bias, M=R, N=D, K=D)
+
+    def _cross_attn_fwd(self, attn, hq, hc, x_res, x_out, B, M, N, Rq, Rqp, Rc, Rcp, mask, sv, tag):
+        bf, D = torch.bfloat16, self.D
+        q = self._buf(sv, tag, "q", (Rqp, D), bf)
+        kv = self._buf(sv, tag, "kv", (Rcp, 2 * D), bf)
+        o = self._buf(sv, tag, "o2", (Rqp, D), bf)
+        ops.gemm_nt(hq, self.w(attn.q.weight), q, bias=attn.q.bias, M=Rq, N=D, K=D)
+        ops.gemm_nt(hc, self.w(attn.kv.weight), kv, bias=attn.kv.bias, M=Rc, N=2 * D, K=D)
+        sm = sl = None
+        if sv is not None:
+            sm = self._buf(sv, tag, "sm2", (B, self.H, M), torch.float32)
+            sl = self._buf(sv, tag, "sl2", (B, self.H, M), torch.float32)
+        ops.attn_fwd(q, kv[:, :D], kv[:, D:], o, B, self.H, M, N, self.scale, stat_m=sm, stat_l=sl, **mask)
+        ops.gemm_nt(o, self.w(attn.proj.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=attn.proj.bias, M=Rq, N=D, K=D)
+
+    def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag):
+        """x_in (Rp, D) f32 -> new (Rp, D) f32 buffer.  [upstream Block.forward, fm_utils.py:331-334]"""
+        R, Rp, D = B * N, x_in.shape[0], self.D
+        bf, f32 = torch.bfloat16, torch.float32
+        h1 = self._ln(blk.norm1, x_in, self._buf(sv, tag, "h1", (Rp, D), bf), R, sv, "n1", tag)
+        x_mid = self._buf(sv, tag, "x_mid", (Rp, D), f32)
+        self._self_attn_fwd(blk.attn, h1, x_in, x_mid, B, N, R, Rp, mask, sv, tag)
+        h2 = self._ln(blk.norm2, x_mid, self._buf(sv, tag, "h2", (Rp, D), bf), R, sv, "n2", tag)
+        x_out = self.ws.get(tag + ".x_out", (Rp, D), f32) if sv is not None else self.ws.get("scratch.x_out" + tag[-1:], (Rp, D), f32)
+        self._mlp_fwd(blk.mlp, h2, x_mid, x_out, R, Rp, sv, tag)
+        if sv is not None:
+            sv["x_in"] = x_in
+        return x_out
+
+    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag):
+        """[upstream DecoderBlock.forward, fm_utils.py:362-366]"""
+        Rq, Rqp, Rc, Rcp, D = B * M, y_in.shape[0], B * N, ctx.shape[0], self.D
+        bf, f32 = torch.bfloat16, torch.float32
+        h1 = self._ln(blk.norm1, y_in, self._buf(sv, tag, "h1", (Rqp, D), bf), Rq, sv, "n1", tag)
+        y1 = self._buf(sv, tag, "y1", (Rqp, D), f32)
+        self._self_attn_fwd(blk.self_attn, h1, y_in, y1, B, M, Rq, Rqp, sa_mask, sv, tag)
+        hq = self._ln(blk.query_norm, y1, self._buf(sv, tag, "hq", (Rqp, D), bf), Rq, sv, "nq", tag)
+        hc = self._ln(blk.context_norm, ctx, self._buf(sv, tag, "hc", (Rcp, D), bf), Rc, sv, "nc", tag)
+        y2 = self._buf(sv, tag, "y2", (Rqp, D), f32)
+        self._cross_attn_fwd(blk.cross_attn, hq, hc, y1, y2, B, M, N, Rq, Rqp, Rc, Rcp, xa_mask, sv, tag)
+        h2 = self._ln(blk.norm2, y2, self._buf(sv, tag, "h2", (Rqp, D), bf), Rq, sv, "n2", tag)
+        y_out = self.ws.get(tag + ".y_out", (Rqp, D), f32) if sv is not None else self.ws.get("scratch.y_out" + tag[-1:], (Rqp, D), f32)
+        self._mlp_fwd(blk.mlp, h2, y2, y_out, Rq, Rqp, sv, tag)
+        if sv is not None:
+            sv["y_in"] = y_in
+        return y_out
+
+    # ------------------------------------------------------------------------------------------
+    # whole-model forward
+    # ------------------------------------------------------------------------------------------
+    def prepare(self):
+        if self.ws is None or self.ws.device != self.device:
+            self.ws = Workspace(self.device)
+
+    @staticmethod
+    def keypad(mask_u8):
+        return dict(mask_kind=L.MASK_KEYPAD, kpad=mask_u8)
+
+    def decoder_mask(self, cs, mod_pre):
+        m = self.model
+        return dict(mask_kind=L.MASK_DECODER, cs=None if m.decoder_causal_mask else cs, causal=m.decoder_causal_mask,
+                    modq=mod_pre if m.decoder_sep_mask else None, modk=mod_pre if m.decoder_sep_mask else None)
+
+    def trunk_forward(self, enc, dec, save: bool):
+        """Encoder + context projection + decoder on the selected tokens.  Returns the final decoder
+        residual stream (f32) and, when saving, the per-layer state."""
+        m = self.model
+        B, N, Mt = enc["B"], enc["Nt"], dec["Nt"]
+        st = dict(enc_layers=[], dec_layers=[]) if save else None
+        emask = self.keypad(enc["mask"])
+        x = enc["x0"]
+        for i, blk in enumerate(m.encoder):
+            sv = {} if save else None
+            x = self.encoder_block_fwd(blk, x, B, N, emask, sv, f"enc{i}" if save else f"enc{i % 2}")
+            if save:
+                st["enc_layers"].append(sv)
+        R, Rp, D = B * N, x.shape[0], self.D
+        sv_top = {} if save else None
+        xn = self._ln(m.encoder_norm, x, self._buf(sv_top, "top", "xn", (Rp, D), torch.bfloat16), R, sv_top, "en", "top")
+        ctx = self._buf(sv_top, "top", "ctx", (Rp, D), torch.float32)
+        pc = m.decoder_proj_context
+        ops.gemm_nt(xn, self.w(pc.weight), ctx, epilogue=L.EPI_RESIDUAL, res=enc["emb"], bias=pc.bias, M=R, N=D, K=D)
+        y = dec["x0"]
+        smask = self.decoder_mask(dec["cs"], dec["mod_pre"]) if "cs" in dec else dec["sa_mask"]
+        for i, blk in enumerate(m.decoder):
+            sv = {} if save else None
+            y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, sv, f"dec{i}" if save else f"dec{i % 2}")
+            if save:
+                st["dec_layers"].append(sv)
+        if save:
+            st.update(top=sv_top, x_final=x, y_final=y, ctx=ctx, emask=emask, smask=smask)
+        return y, st
+
+    def heads_setup(self, dec, y_final, save):
+        """decoder_norm + bucketing of the decoder rows by modality head + grouped logits GEMM."""
+        m = self.model
+        heads = dec["heads"]
+        nH = len(heads)
+        B, Mt, D = dec["B"], dec["Nt"], self.D
+        R = B * Mt
+        Rp = ops.padded_rows(R, nH)
+        ws, dev, i32 = self.ws, self.device, torch.int32
+        hs = dict(n=nH, Rp=Rp, heads=heads)
+        hs["seg_start"], hs["seg_count"] = ws.get("heads.seg_start", (nH,), i32), ws.get("heads.seg_count", (nH,), i32)
+        hs["perm"], hs["r2p"] = ws.get("heads.perm", (Rp,), i32), ws.get("heads.r2p", (R,), i32)
+        hs["tile_group"] = ws.get("heads.tile_group", (Rp // 128,), i32)
+        ops.segment_rows(dec["head_of_row"].view(-1), nH, hs["seg_start"], hs["seg_count"], hs["perm"], hs["r2p"], hs["tile_group"])
+        sv = {} if save else None
+        yp = ws.get("heads.yp", (Rp, D), torch.bfloat16)
+        # decoder_norm writes straight into the segmented layout; pad rows are cleared first
+        yp.zero_()
+        self._ln(m.decoder_norm, y_final, yp, R, sv, "dn", "heads", row_map=hs["r2p"])
+        vocabs = [m.decoder_embeddings[h].vocab_size for h in heads]
+        hs["vocabs"], hs["maxV"] = vocabs, max(vocabs)
+        ldl = ru(hs["maxV"], 64)
+        key = tuple((self._stamp(m.decoder_embeddings[h].to_logits.weight)) for h in heads)
+        cache = getattr(self, "_head_groups", None)
+        if cache is None or cache[0] != key:
+            fwd = ops.make_groups([dict(W=self.w(m.decoder_embeddings[h].to_logits.weight), N=v, K=D, ldw=D) for h, v in zip(heads, vocabs)], dev)
+            bwd = ops.make_groups([dict(W=self.wt(m.decoder_embeddings[h].to_logits.weight), N=D, K=ru(v, 64), ldw=ru(v, 64))
+                                   for h, v in zip(heads, vocabs)], dev)
+            vt = torch.tensor(vocabs, dtype=i32, device=dev)
+            self._head_groups = cache = (key, fwd, bwd, vt)
+        hs["g_fwd"], hs["g_bwd"], hs["vocab_t"] = cache[1], cache[2], cache[3]
+        logits = ws.get("heads.logits", (Rp, ldl), torch.bfloat16)
+        ops.gemm_nt_grouped(yp, hs["g_fwd"], hs["tile_group"], logits, hs["maxV"])
+        hs.update(yp=yp, logits=logits, sv=sv)
+        hs["row_loss"] = ws.get("heads.row_loss", (Rp,), torch.float32)
+        hs["head_loss"] = ws.get("heads.head_loss", (nH,), torch.float32)
+        hs["total"] = ws.get("heads.total", (1,), torch.float32)
+        return hs
+
+    def loss_forward(self, dec, hs, loss_type):
+        lt = L.LOSS_MOD if loss_type in ("mod", "modality") else L.LOSS_TOKEN
+        hs["loss_type"] = lt
+        ops.cross_entropy(hs["logits"], hs["perm"], hs["tile_group"], dec["target_ids"].view(-1), hs["vocab_t"], hs["seg_start"],
+                          hs["seg_count"], hs["n"], hs["maxV"], hs["row_loss"], hs["head_loss"], hs["total"], loss_type=lt)
+        return hs["total"], hs["head_loss"]
+
+    def dec_order(self, mod_dict):
+        """Upstream shuffles the decoder modalities with random.sample at every forward (fm.py:306);
+        the same call on the same RNG state yields the same order here."""
+        names = [n for n in mod_dict if n in self.model.decoder_embeddings]
+        return random.sample(names, len(names))
+
+    def train_forward(self, mod_dict, n_enc, n_dec, loss_type, save=True):
+        if loss_type not in ("mod", "modality", "token"):
+            raise ValueError("Invalid loss type")
+        self.prepare()
+        if save:
+            self._ensure_flat()
+        enc_names = [n for n in mod_dict if n in self.model.encoder_embeddings]
+        enc = self.select(mod_dict, n_enc, False, enc_names, "enc.")
+        dec = self.select(mod_dict, n_dec, True, self.dec_order(mod_dict), "dec.")
+        y, st = self.trunk_forward(enc, dec, save)
+        hs = self.heads_setup(dec, y, save)
+        total, head_loss = self.loss_forward(dec, hs, loss_type)
+        if save:
+            self._ctx = dict(enc=enc, dec=dec, st=st, hs=hs)
+        return total, head_loss, hs["heads"], hs["seg_count"]
+
+    # ------------------------------------------------------------------------------------------
+    # backward
+    # ------------------------------------------------------------------------------------------
+    def _g(self, p):
+        """fp32 gradient accumulator of a parameter (view of the flat store), or None if frozen."""
+        return self.grad_view(p) if p.requires_grad else None
+
+    def _dW(self, dy, x, lin, R64, n_cols=None, dy_cols=None):
+        """lin.weight.grad += dy^T x ; lin.bias.grad += colsum(dy)."""
+        g = self._g(lin.weight)
+        N = lin.weight.shape[0] if n_cols is None else n_cols
+        if g is not None:
+            ops.gemm_tn(dy, x, g.view(g.shape[0], -1), N=N, K=lin.weight[0].numel(), R=R64)
+        if lin.bias is not None and lin.bias.requires_grad:
+            ops.colsum(dy, self.grad_view(lin.bias), N, R=R64)
+
+    def _ln_bwd(self, norm, dy, x, sv, key, g, g_bf, R, dres, dy_row_map=None):
+        dw = self._g(norm.weight)
+        db = self._g(norm.bias) if isinstance(norm.bias, nn.Parameter) else None
+        ops.layernorm_bwd(dy, x, norm.weight, sv[key + ".mu"], sv[key + ".rs"], g, dres=dres, dx_bf16=g_bf, dw=dw, db=db,
+                          dy_row_map=dy_row_map, R=R)
+
+    def _mlp_bwd(self, mlp, sv, g_bf, R, Rp):
+        """In: g_bf = d(out) bf16.  Out: dh (bf16 scratch) = gradient w.r.t. the norm2 output."""
+        bf, D, Hp, Hd = torch.bfloat16, self.D, self.Hp, self.Hd
+        R64 = ru(R, 64)
+        ws = self.ws
+        self._dW(g_bf, sv["act"], mlp.fc2, R64)
+        da = ws.get("bwd.da", (Rp, Hp), bf)
+        ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), da, M=R, N=Hd, K=D)
+        dh = ws.get("bwd.dh", (Rp, D), bf)
+        if self.gated:
+            dgu = ws.get("bwd.dgu", (Rp, 2 * Hp), bf)
+            ops.swiglu_bwd(da, sv["gu"], dgu, Hd, Hp, R=R)
+            self._dW(dgu[:, :Hp], sv["h2"], mlp.fc1, R64, n_cols=Hd)
+            self._dW(dgu[:, Hp:], sv["h2"], mlp.fc3, R64, n_cols=Hd)
+            ops.gemm_nt(dgu, self.w13t(mlp), dh, M=R, N=D, K=2 * Hp)
+        else:
+            dpre = ws.get("bwd.dpre", (Rp, Hp), bf)
+            ops.gelu_bwd(da, sv["pre"], dpre, Hd, Hp, R=R)
+            self._dW(dpre, sv["h2"], mlp.fc1, R64, n_cols=Hd)
+            ops.gemm_nt(dpre, self.wt(mlp.fc1.weight), dh, M=R, N=D, K=Hp)
+        return dh
+
+    def _self_attn_bwd(self, attn, sv, g_bf, B, N, R, Rp, mask):
+        bf, D = torch.bfloat16, self.D
+        R64, ws = ru(R, 64), self.ws
+        self._dW(g_bf, sv["o"], attn.proj, R64)
+        do = ws.get("bwd.do", (Rp, D), bf)
+        ops.gemm_nt(g_bf, self.wt(attn.proj.weight), do, M=R, N=D, K=D)
+        dqkv = ws.get("bwd.dqkv", (Rp, 3 * D), bf)
+        qkv = sv["qkv"]
+        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["o"], do, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                     B, self.H, N, N, self.scale, sv["sm"], sv["sl"], **mask)
+        self._dW(dqkv, sv["h1"], attn.qkv, R64)
+        dh = ws.get("bwd.dh", (Rp, D), bf)
+        ops.gemm_nt(dqkv, self.wt(attn.qkv.weight), dh, M=R, N=D, K=3 * D)
+        return dh
+
+    def encoder_block_bwd(self, blk, sv, g, g_bf, B, N, mask):
+        R, Rp = B * N, g.shape[0]
+        dh = self._mlp_bwd(blk.mlp, sv, g_bf, R, Rp)
+        self._ln_bwd(blk.norm2, dh, sv["x_mid"], sv, "n2", g, g_bf, R, dres=g)
+        dh = self._self_attn_bwd(blk.attn, sv, g_bf, B, N, R, Rp, mask)
+        self._ln_bwd(blk.norm1, dh, sv["x_in"], sv, "n1", g, g_bf, R, dres=g)
+
+    def decoder_block_bwd(self, blk, sv, g, g_bf, dctx, dctx_bf, ctx, B, M, N, sa_mask, xa_mask):
+        bf, D = torch.bfloat16, self.D
+        Rq, Rqp, Rc, Rcp = B * M, g.shape[0], B * N, ctx.shape[0]
+        ws = self.ws
+        dh = self._mlp_bwd(blk.mlp, sv, g_bf, Rq, Rqp)
+        self._ln_bwd(blk.norm2, dh, sv["y2"], sv, "n2", g, g_bf, Rq, dres=g)
+        # cross attention
+        xa = blk.cross_attn
+        self._dW(g_bf, sv["o2"], xa.proj, ru(Rq, 64))
+        do = ws.get("bwd.do", (Rqp, D), bf)
+        ops.gemm_nt(g_bf, self.wt(xa.proj.weight), do, M=Rq, N=D, K=D)
+        dq = ws.get("bwd.dq", (Rqp, D), bf)
+        dkv = ws.get("bwd.dkv", (Rcp, 2 * D), bf)
+        kv = sv["kv"]
+        ops.attn_bwd(sv["q"], kv[:, :D], kv[:, D:], sv["o2"], do, dq, dkv[:, :D], dkv[:, D:], B, self.H, M, N, self.scale,
+                     sv["sm2"], sv["sl2"], **xa_mask)
+        self._dW(dq, sv["hq"], xa.q, ru(Rq, 64))
+        dhq = ws.get("bwd.dh", (Rqp, D), bf)
+        ops.gemm_nt(dq, self.wt(xa.q.weight), dhq, M=Rq, N=D, K=D)
+        self._ln_bwd(blk.query_norm, dhq, sv["y1"], sv, "nq", g, g_bf, Rq, dres=g)
+        self._dW(dkv, sv["hc"], xa.kv, ru(Rc, 64))
+        dhc = ws.get("bwd.dhc", (Rcp, D), bf)
+        ops.gemm_nt(dkv, self.wt(xa.kv.weight), dhc, M=Rc, N=D, K=2 * D)
+        self._ln_bwd(blk.context_norm, dhc, ctx, sv, "nc", dctx, dctx_bf, Rc, dres=dctx)     # accumulates over layers
+        # self attention
+        dh = self._self_attn_bwd(blk.self_attn, sv, g_bf, B, M, Rq, Rqp, sa_mask)
+        self._ln_bwd(blk.norm1, dh, sv["y_in"], sv, "n1", g, g_bf, Rq, dres=g)
+
+    def _embed_bwd(self, sel, dx, dx_extra, is_dec):
+        m = self.model
+        embs = m.decoder_embeddings if is_dec else m.encoder_embeddings
+        d = L.EmbedBwdDesc()
+        for i, n in enumerate(sel["names"]):
+            e, md = embs[n], d.mods[i]
+            md.kind = e.kind
+            if e.kind in (L.KIND_TOK, L.KIND_SEQ) and not (is_dec and e.kind == L.KIND_TOK):
+                w = e.token_emb.weight
+                md.d_table = self.grad_view(w).data_ptr() if w.requires_grad else None
+                pad = e.token_emb.padding_idx
+                md.has_padding_idx, md.padding_idx = (1, pad) if pad is not None else (0, 0)
+            if isinstance(e.pos_emb, nn.Parameter) and e.pos_emb.requires_grad:
+                md.d_pos = self.grad_view(e.pos_emb).data_ptr()
+            if e.mod_emb.requires_grad:
+                md.d_mod_emb = self.grad_view(e.mod_emb).data_ptr()
+            if e.kind == L.KIND_SEQ_EMB and e.emb_proj.bias.requires_grad:
+                md.d_proj_bias = self.grad_view(e.emb_proj.bias).data_ptr()
+        d.dx, d.lddx = dx.data_ptr(), dx.stride(0)
+        d.slot_mod, d.slot_src, d.slot_pos = sel["slot_mod"].data_ptr(), sel["slot_src"].data_ptr(), sel["slot_pos"].data_ptr()
+        if is_dec and m.mask_token.requires_grad:
+            d.d_mask_token = self.grad_view(m.mask_token).data_ptr()
+        if not is_dec and m.num_register_tokens and m.register_tokens.requires_grad:
+            d.d_reg_tokens = self.grad_view(m.register_tokens).data_ptr()
+        d.n_mods, d.batch, d.dim, d.Nt, d.is_decoder = len(sel["names"]), sel["B"], self.D, sel["Nt"], 1 if is_dec else 0
+        L.check(L.embed_bwd(ops.C.byref(d), ops._stream()))
+        if dx_extra is not None:
+            # the context gradient reaches pos_emb / mod_emb only (context = proj(x) + encoder_emb, fm.py:679)
+            d2 = L.EmbedBwdDesc()
+            ops.C.memmove(ops.C.byref(d2), ops.C.byref(d), ops.C.sizeof(d))
+            for i in range(d.n_mods):
+                d2.mods[i].d_table = None
+                d2.mods[i].d_proj_bias = None
+            d2.d_reg_tokens = None
+            d2.dx, d2.lddx = dx_extra.data_ptr(), dx_extra.stride(0)
+            L.check(L.embed_bwd(ops.C.byref(d2), ops._stream()))
+
+    def train_backward(self, grad_scale: torch.Tensor):
+        """Backward of the last ``train_forward``.  ``grad_scale``: 1-element fp32 device tensor holding
+        d(objective)/d(loss) (loss scaling, 1/accum_iter, ...).  Accumulates into the flat gradient store."""
+        c = self._ctx
+        if c is None:
+            raise RuntimeError("train_backward without a preceding training forward")
+        self._ctx = None
+        m, ws = self.model, self.ws
+        enc, dec, st, hs = c["enc"], c["dec"], c["st"], c["hs"]
+        B, N, Mt, D = enc["B"], enc["Nt"], dec["Nt"], self.D
+        bf, f32 = torch.bfloat16, torch.float32
+        Rq, Rc = B * Mt, B * N
+        Rqp, Rcp = st["y_final"].shape[0], st["x_final"].shape[0]
+        # ---- heads: d(logits) in place, then dY (grouped NT) and dW_head (grouped TN) -----------------
+        ops.cross_entropy(hs["logits"], hs["perm"], hs["tile_group"], dec["target_ids"].view(-1), hs["vocab_t"], hs["seg_start"],
+                          hs["seg_count"], hs["n"], hs["maxV"], hs["row_loss"], hs["head_loss"], hs["total"], loss_type=hs["loss_type"],
+                          grad_scale=grad_scale, write_grad=True)
+        dyp = ws.get("bwd.dyp", (hs["Rp"], D), bf)
+        ops.gemm_nt_grouped(hs["logits"], hs["g_bwd"], hs["tile_group"], dyp, D)
+        heads = [m.decoder_embeddings[h] for h in hs["heads"]]
+        if any(h.to_logits.weight.requires_grad for h in heads):
+            tn = ops.make_groups([dict(out=self.grad_view(h.to_logits.weight) if h.to_logits.weight.requires_grad else None,
+                                       N=(v if h.to_logits.weight.requires_grad else 0)) for h, v in zip(heads, hs["vocabs"])], self.device)
+            ops.gemm_tn_grouped(hs["logits"], hs["yp"], tn, hs["seg_start"], hs["seg_count"], hs["n"], hs["maxV"], hs["Rp"], D)
+        g = ws.get("bwd.g_dec", (Rqp, D), f32)
+        g_bf = ws.get("bwd.g_dec_bf", (Rqp, D), bf)
+        self._ln_bwd(m.decoder_norm, dyp, st["y_final"], hs["sv"], "dn", g, g_bf, Rq, dres=None, dy_row_map=hs["r2p"])
+        # ---- decoder ----------------------------------------------------------------------------------
+        dctx = ws.get("bwd.dctx", (Rcp, D), f32)
+        dctx_bf = ws.get("bwd.dctx_bf", (Rcp, D), bf)
+        dctx.zero_()
+        for blk, sv in zip(reversed(m.decoder), reversed(st["dec_layers"])):
+            self.decoder_block_bwd(blk, sv, g, g_bf, dctx, dctx_bf, st["ctx"], B, Mt, N, st["smask"], st["emask"])
+        self._embed_bwd(dec, g, None, True)
+        # ---- context projection + encoder -------------------------------------------------------------
+        top = st["top"]
+        if len(m.decoder) == 0:
+            ops.f32_to_bf16(dctx, dctx_bf)
+        self._dW(dctx_bf, top["xn"], m.decoder_proj_context, ru(Rc, 64))
+        dxn = ws.get("bwd.dh", (Rcp, D), bf)
+        ops.gemm_nt(dctx_bf, self.wt(m.decoder_proj_context.weight), dxn, M=Rc, N=D, K=D)
+        ge = ws.get("bwd.g_enc", (Rcp, D), f32)
+        ge_bf = ws.get("bwd.g_enc_bf", (Rcp, D), bf)
+        self._ln_bwd(m.encoder_norm, dxn, st["x_final"], top, "en", ge, ge_bf, Rc, dres=None)
+        for blk, sv in zip(reversed(m.encoder), reversed(st["enc_layers"])):
+            self.encoder_block_bwd(blk, sv, ge, ge_bf, B, N, st["emask"])
+        # d(x0) -> token tables / projections / embeddings; d(ctx) also reaches the encoder embeddings
+        for n in enc["names"]:
+            e = m.encoder_embeddings[n]
+            if e.kind == L.KIND_PATCH and e.proj.weight.requires_grad:
+                ops.gemm_tn(ge_bf, enc["patch_rows"], self.grad_view(e.proj.weight), N=D, K=e.proj.weight.shape[1], R=ru(Rc, 64))
+            elif e.kind == L.KIND_SEQ_EMB and e.emb_proj.weight.requires_grad:
+                ops.gemm_tn(ge_bf, enc["seqemb_rows"], self.grad_view(e.emb_proj.weight), N=D, K=e.emb_proj.weight.shape[1], R=ru(Rc, 64))
+        self._embed_bwd(enc, ge, dctx, False)

@@ -1,0 +1,207 @@
+"""Optimizer construction with upstream's parameter grouping (``fourm/utils/optim_factory.py:111-244``)
+and a fused AdamW whose state is indistinguishable from ``torch.optim.AdamW``'s.
+
+FusedAdamW runs one HIP kernel per *contiguous run* of parameters that share a group: the engine lays
+parameters and gradients out in flat fp32 buffers, so a 360-tensor model updates in a handful of
+launches, each a single streaming pass over (param, grad, exp_avg, exp_avg_sq)."""
+import json
+
+import torch
+from torch import optim
+
+
+def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None, decoder_decay=None,
+                         decoder_list=(), no_lr_scale_list=()):
+    """norm / bias / skip-listed tensors get no decay; optional per-layer lr scale.  Group dicts carry
+    'lr_scale' (consumed by the trainer's schedule, run_training_4m.py:707-711)."""
+    names, groups = {}, {}
+    for name, p in model.named_parameters():
+        name = name.replace("_fsdp_wrapped_module.", "")
+        if not p.requires_grad:
+            continue
+        if ("norm." in name or ".norm" in name or name.endswith(".bias") or name.endswith(".lookup_table_weight")
+                or name.endswith(".gamma") or name in skip_list):
+            gname, wd = "no_decay", 0.
+        elif decoder_decay is not None and (name.startswith("decoder.") or name in decoder_list):
+            gname, wd = "decoder_decay", decoder_decay
+        else:
+            gname, wd = "decay", weight_decay
+        skip_scale = False
+        layer_id = None
+        if get_num_layer is not None:
+            layer_id = get_num_layer(name)
+            gname = "layer_%d_%s" % (layer_id, gname)
+            if name in no_lr_scale_list:
+                skip_scale = True
+                gname = f"{gname}_no_lr_scale"
+        if gname not in groups:
+            scale = get_layer_scale(layer_id) if (get_layer_scale is not None and not skip_scale) else 1.
+            names[gname] = {"weight_decay": wd, "params": [], "lr_scale": scale}
+            groups[gname] = {"weight_decay": wd, "params": [], "lr_scale": scale}
+        groups[gname]["params"].append(p)
+        names[gname]["params"].append(name)
+    print("Param groups = %s" % json.dumps(names, indent=2))
+    return list(groups.values())
+
+
+class FusedAdamW(optim.AdamW):
+    """torch.optim.AdamW with the update executed by ``fm_adamw`` (csrc/elementwise.hip).
+
+    ``state_dict()`` / ``load_state_dict()`` are the parent's: per-parameter 'step' (fp32 scalar tensor),
+    'exp_avg', 'exp_avg_sq'; param_groups keep their extra keys ('lr_scale').  amsgrad / maximize are
+    not supported."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
+        if kw.get("amsgrad") or kw.get("maximize"):
+            raise NotImplementedError("FusedAdamW: amsgrad / maximize are not implemented")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self._clip_coef = None        # device scalar set by fused_grad_norm(clip=...)
+        self._runs = None
+
+    # -- contiguous runs ------------------------------------------------------------------------
+    def _build_runs(self):
+        """Per group: maximal runs of parameters adjacent in memory (flat parameter store) whose gradients
+        are adjacent with the same spacing.  State tensors of a run are carved from one flat buffer."""
+        runs = []
+        for gi, g in enumerate(self.param_groups):
+            ps = [p for p in g["params"] if p.grad is not None]
+            ps.sort(key=lambda p: p.data_ptr())
+            cur = []
+            for p in ps:
+                if cur:
+                    q = cur[-1]
+                    adj = (p.data_ptr() == q.data_ptr() + q.numel() * 4 and p.grad.data_ptr() == q.grad.data_ptr() + q.numel() * 4
+                           and self._state_adjacent(q, p))
+                    if not adj:
+                        runs.append((gi, cur))
+                        cur = []
+                cur.append(p)
+            if cur:
+                runs.append((gi, cur))
+        return runs
+
+    def _state_adjacent(self, q, p):
+        sq, sp = self.state.get(q), self.state.get(p)
+        if not sq and not sp:
+            return True          # both uninitialised: will be carved adjacently
+        if not sq or not sp:
+            return False
+        return (sp["exp_avg"].data_ptr() == sq["exp_avg"].data_ptr() + q.numel() * 4
+                and sp["exp_avg_sq"].data_ptr() == sq["exp_avg_sq"].data_ptr() + q.numel() * 4
+                and float(sp["step"]) == float(sq["step"]))
+
+    def _init_state(self, run):
+        need = [p for p in run if len(self.state[p]) == 0]
+        if not need:
+            return
+        n = sum(p.numel() for p in run)
+        dev = run[0].device
+        m, v = torch.zeros(n, device=dev, dtype=torch.float32), torch.zeros(n, device=dev, dtype=torch.float32)
+        o = 0
+        for p in run:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = m[o:o + p.numel()].view_as(p)
+                st["exp_avg_sq"] = v[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    @torch.no_grad()
+    def fused_grad_norm(self, clip=None):
+        """L2 norm of every gradient, computed on the device; with ``clip`` the coefficient
+        min(1, clip / (norm + 1e-6)) is folded into the next step().  Returns a device scalar."""
+        from fourm.hip import ops
+        grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not grads:
+            return torch.tensor(0.)
+        dev = grads[0].device
+        ss, norm = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+        coef = torch.zeros(1, device=dev) if clip is not None else None
+        seen = set()
+        # merge adjacent gradient tensors so that a flat gradient buffer is one launch
+        grads.sort(key=lambda t: t.data_ptr())
+        start, n = None, 0
+        for t in grads:
+            if t.data_ptr() in seen:
+                continue
+            seen.add(t.data_ptr())
+            if start is not None and t.data_ptr() == start.data_ptr() + n * 4:
+                n += t.numel()
+                continue
+            if start is not None:
+                ops.sumsq(_flat_view(start, n), ss)
+            start, n = t, t.numel()
+        ops.sumsq(_flat_view(start, n), ss)
+        ops.clip_coef(ss, clip if clip is not None else 0.0, norm, coef)
+        self._clip_coef = coef
+        return norm[0]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from fourm.hip import engine, ops
+        loss = closure() if closure is not None else None
+        for gi, run in self._build_runs():
+            g = self.param_groups[gi]
+            self._init_state(run)
+            st0 = self.state[run[0]]
+            for p in run:
+                self.state[p]["step"] += 1
+            step = int(st0["step"])
+            n = sum(p.numel() for p in run)
+            if not self._state_adjacent_all(run):
+                for p in run:       # state loaded from a checkpoint (separate tensors): per-tensor launches
+                    st = self.state[p]
+                    ops.adamw(p, p.grad, st["exp_avg"], st["exp_avg_sq"], p.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                              g["weight_decay"], int(st["step"]), self._clip_coef)
+                continue
+            ops.adamw(run[0], run[0].grad, st0["exp_avg"], st0["exp_avg_sq"], n, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                      g["weight_decay"], step, self._clip_coef)
+        self._clip_coef = None
+        engine.bump_weight_epoch()
+        return loss
+
+    def _state_adjacent_all(self, run):
+        return all(self._state_adjacent(a, b) for a, b in zip(run[:-1], run[1:]))
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():      # keep the layout torch uses for non-capturable AdamW
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = st["step"].detach().float().cpu()
+
+
+def _flat_view(t: torch.Tensor, n: int) -> torch.Tensor:
+    return torch.as_strided(t, (n,), (1,))
+
+
+def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
+    opt_lower = args.opt.lower()
+    weight_decay = args.weight_decay
+    decoder_decay = getattr(args, "decoder_decay", None)
+    no_lr_scale_list = args.no_lr_scale_list.split("-") if getattr(args, "no_lr_scale_list", None) else []
+    if weight_decay and filter_bias_and_bn:
+        skip = skip_list if skip_list is not None else (model.no_weight_decay() if hasattr(model, "no_weight_decay") else {})
+        decoder = model.decoder_weight_decay() if hasattr(model, "decoder_weight_decay") else {}
+        parameters = get_parameter_groups(model, weight_decay, skip, get_num_layer, get_layer_scale, decoder_decay, decoder, no_lr_scale_list)
+        weight_decay = 0.
+    else:
+        parameters = model.parameters()
+    opt_args = dict(lr=args.lr, weight_decay=weight_decay)
+    if getattr(args, "opt_eps", None) is not None:
+        opt_args["eps"] = args.opt_eps
+    if getattr(args, "opt_betas", None) is not None:
+        opt_args["betas"] = tuple(args.opt_betas)
+    print("optimizer settings:", opt_args)
+    kind = opt_lower.split("_")[-1]
+    if kind in ("sgd", "nesterov"):
+        opt_args.pop("eps", None)
+        return optim.SGD(parameters, momentum=args.momentum, nesterov=True, **opt_args)
+    if kind == "momentum":
+        opt_args.pop("eps", None)
+        return optim.SGD(parameters, momentum=args.momentum, nesterov=False, **opt_args)
+    if kind == "adam":
+        return optim.Adam(parameters, **opt_args)
+    if kind == "adamw":
+        on_gpu = next(model.parameters()).is_cuda
+        return FusedAdamW(parameters, **opt_args) if on_gpu else optim.AdamW(parameters, **opt_args)
+    raise ValueError(f"Invalid optimizer {args.opt}")

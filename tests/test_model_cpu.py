@@ -1,0 +1,119 @@
+"""Host-side checks that need no GPU: parameter tree / state_dict layout against the upstream fixtures,
+registry, config parsing, optimizer grouping, checkpoint layout, C-ABI export list."""
+import ctypes
+import os
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.cases import CASES, build_case
+from tests.util_model import build_hip_model
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_state_dict_layout_matches_upstream(name):
+    """Keys, shapes, parameter-vs-buffer split and tying are those of the upstream model (fixture meta)."""
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    case = build_case(name)
+    model = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    sd = model.state_dict()
+    assert list(sd.keys()) == g["meta/keys"].tolist()
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == g["meta/shapes"].tolist()
+    assert [k for k, _ in model.named_parameters()] == g["meta/param_keys"].tolist()
+    assert [k for k, _ in model.named_buffers()] == g["meta/buffer_keys"].tolist()
+    missing = model.load_state_dict(case["sd"], strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    # fixed position tables are regenerated identically to upstream's
+    for k, v in model.state_dict().items():
+        if k.endswith("pos_emb"):
+            assert torch.equal(v, case["sd"][k]), k
+
+
+def test_named_factories_and_registry():
+    from fourm.utils import create_model, list_models
+    from fourm.data.modality_info import MODALITY_INFO
+    names = list_models("fm_*")
+    assert len(names) == 13 and "fm_base_12e_12d_swiglu_nobias" in names
+    mods_in = ["rgb@224", "tok_depth@224", "caption"]
+    enc = {m: MODALITY_INFO[m]["encoder_embedding"](**(dict(patch_size=16, image_size=224) if MODALITY_INFO[m]["type"] == "img" else {}))
+           for m in mods_in}
+    dec = {m: MODALITY_INFO[m]["decoder_embedding"](**(dict(patch_size=16, image_size=224) if MODALITY_INFO[m]["type"] == "img" else {}))
+           for m in ["tok_depth@224", "caption"]}
+    model = create_model("fm_tiny_6e_6d_swiglu_nobias", encoder_embeddings=enc, decoder_embeddings=dec,
+                         modality_info={m: MODALITY_INFO[m] for m in mods_in}, num_register_tokens=None)
+    assert model.dim == 384 and len(model.encoder) == 6 and model.encoder[0].mlp.fc1.weight.shape == (1024, 384)
+    assert model.decoder_embeddings["caption"].to_logits.weight is model.decoder_embeddings["caption"].token_emb.weight
+    assert model.decoder_embeddings["caption"].mod_emb is model.encoder_embeddings["caption"].mod_emb
+    assert model.encoder_embeddings["caption"].pos_emb.shape == (1, 512, 384)
+    assert MODALITY_INFO["caption"]["id"] == 32652 and MODALITY_INFO["tok_rgb@224"]["id"] == 11606
+
+
+def test_fm_config_wrapper():
+    from fourm.models.fm import FM
+    cfg = dict(domains_in=["rgb@224", "caption"], domains_out=["caption", "tok_rgb@224"], image_size=224, patch_size=16,
+               norm_bias=False, act_layer="SiLU", dim=384, encoder_depth=1, decoder_depth=1, num_heads=6, mlp_ratio=4,
+               qkv_bias=False, proj_bias=False, mlp_bias=False, gated_mlp=True)
+    m = FM(cfg)
+    assert "encoder.0.norm1.bias" in dict(m.named_buffers())
+    assert m.decoder_embeddings["caption"].to_logits.weight is not m.decoder_embeddings["caption"].token_emb.weight
+
+
+def test_cpu_forward_fails_loudly():
+    case = build_case("micro_swiglu")
+    model = build_hip_model(case["cfg"])
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        model(case["mod_dict"], case["N"], case["M"])
+
+
+def test_optimizer_groups_and_checkpoint_layout(tmp_path):
+    from fourm.utils import create_optimizer, save_model, auto_load_model, NativeScalerWithGradNormCount
+    case = build_case("micro_gelu")
+    model = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    args = SimpleNamespace(opt="adamw", weight_decay=0.05, lr=1e-3, opt_eps=1e-8, opt_betas=[0.9, 0.95], momentum=0.9,
+                           output_dir=str(tmp_path), auto_resume=True, resume="", start_epoch=0)
+    opt = create_optimizer(args, model)
+    assert isinstance(opt, torch.optim.AdamW)
+    groups = {g["weight_decay"]: g for g in opt.param_groups}
+    assert set(groups) == {0.0, 0.05} and all("lr_scale" in g for g in opt.param_groups)
+    nd = {id(p) for p in groups[0.0]["params"]}
+    for n, p in model.named_parameters():
+        assert (id(p) in nd) == ("norm." in n or ".norm" in n or n.endswith(".bias")), n
+    scaler = NativeScalerWithGradNormCount(enabled=False)
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    save_model(args, 3, model, model, opt, scaler)
+    blob = torch.load(tmp_path / "checkpoint-3.pth", weights_only=False)
+    assert set(blob) == {"model", "epoch", "args", "scaler", "optimizer"} and blob["epoch"] == 3
+    st = blob["optimizer"]["state"][0]
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq"}
+    model2 = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    opt2 = create_optimizer(args, model2)
+    auto_load_model(args, model2, model2, opt2, scaler)
+    assert args.start_epoch == 4
+    for a, b in zip(model.state_dict().values(), model2.state_dict().values()):
+        assert torch.equal(a, b)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libfourm_hip.so loads without a GPU and exports exactly what include/fourm_hip.h declares."""
+    from fourm.hip import _lib
+    header = open(os.path.join(ROOT, "include", "fourm_hip.h")).read()
+    declared = set(re.findall(r"\b(fm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"fm_last_error"} - {"fm_last_error"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(_lib.lib, sym), sym
+    assert _lib.lib.fm_abi_version() == int(re.search(r"#define FM_ABI_VERSION (\d+)", header).group(1))
+    # enum values used by the Python side
+    for name, val in dict(FM_EPI_SWIGLU=_lib.EPI_SWIGLU, FM_MASK_DECODER=_lib.MASK_DECODER, FM_KIND_SEQ_EMB=_lib.KIND_SEQ_EMB,
+                          FM_LOSS_TOKEN=_lib.LOSS_TOKEN, FM_MAX_MODS=_lib.FM_MAX_MODS).items():
+        assert re.search(rf"{name}\s*(=|\s)\s*{val}\b", header), name
+    # struct sizes agree with the C compiler's layout rules (natural alignment, no packing)
+    assert ctypes.sizeof(_lib.GemmGroup) == 32 and ctypes.sizeof(_lib.ModDesc) % 8 == 0

@@ -1,0 +1,168 @@
+"""End-to-end parity of the HIP model on a real MI355X:
+  * token selection / masks / ids: bit-exact against the upstream fixtures;
+  * loss, per-modality losses, logits, gradients: against the CPU oracle run with bf16 rounding at
+    upstream's autocast points (tight) and against the upstream fp32 fixture (bf16-level tolerance).
+Tolerances are stated at each assert."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fourm_oracle as O
+from tests.golden.cases import build_case
+from tests.util_model import build_hip_model, tie, to_device
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "ti_mod7"]
+
+
+def setup(name):
+    g = np.load(os.path.join(GOLD, f"{name}.npz"))
+    case = build_case(name)
+    model = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    model.load_state_dict(case["sd"], strict=True)
+    model = model.cuda().train()
+    return g, case, model
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_selection_bit_exact(name):
+    g, case, model = setup(name)
+    md = to_device(case["mod_dict"])
+    tok, emb, mask, mod = model.forward_mask_encoder(md, case["N"])
+    assert np.array_equal(mask.cpu().numpy(), g["enc/mask"])
+    assert np.array_equal(mod.cpu().numpy(), g["enc/mod_mask"])
+    random.seed(case["order_seed"])
+    dtok, demb, dmask, tgt, attn, dmod = model.forward_mask_decoder(md, case["M"])
+    assert np.array_equal(dmask.cpu().numpy(), g["dec/mask"])
+    assert np.array_equal(dmod.cpu().numpy(), g["dec/mod_mask"])
+    assert np.array_equal(tgt.cpu().numpy(), g["dec/target_ids"])
+    assert np.array_equal(np.packbits(attn.cpu().numpy(), axis=-1), g["dec/attn_mask"])
+    if "enc/emb" in g:
+        # gathered rows are copies of table rows: exact.  Rows produced by the pixel / T5 projections
+        # come from a bf16 GEMM: 2^-8 relative.
+        assert np.array_equal(emb.cpu().numpy(), g["enc/emb"])
+        assert np.array_equal(demb.cpu().numpy(), g["dec/emb"])
+        assert np.array_equal(dtok.cpu().numpy(), g["dec/tokens"])
+        ref = torch.from_numpy(g["enc/tokens"])
+        dense_ids = [m.id for m in case["cfg"].mods if m.kind in ("patch", "seq_emb")]
+        dense = torch.zeros_like(mod.cpu(), dtype=torch.bool)
+        for i in dense_ids:
+            dense |= mod.cpu() == i
+        assert torch.equal(tok.cpu()[~dense], ref[~dense])
+        if dense.any():
+            assert rel(tok.cpu()[dense], ref[dense]) < 8e-3
+    else:
+        np.testing.assert_allclose(emb.sum(-1).cpu().numpy(), g["enc/emb_rowsum"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(demb.sum(-1).cpu().numpy(), g["dec/emb_rowsum"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_loss_and_gradients(name):
+    g, case, model = setup(name)
+    cfg, md = case["cfg"], case["mod_dict"]
+    order = g["meta/order"].tolist()
+    # oracle with bf16 rounding at the autocast points, same weights, CPU autograd
+    P = tie({k: v.clone().requires_grad_(v.is_floating_point()) for k, v in case["sd"].items()}, cfg, case["share_embedding"])
+    o_loss, o_mod = O.fourm_forward(P, cfg, md, case["N"], case["M"], order, loss_type=case["loss_type"], emulate_bf16=True)
+    o_loss.sum().backward()
+    random.seed(case["order_seed"])
+    loss, mod_loss = model(to_device(md), case["N"], case["M"], loss_type=case["loss_type"])
+    loss.backward()
+    torch.cuda.synchronize()
+    # loss: bf16 pipeline vs bf16-emulating oracle 3e-3, vs upstream fp32 2e-2
+    assert abs(float(loss) - float(o_loss.sum())) < 3e-3 * abs(float(o_loss.sum())), (float(loss), float(o_loss.sum()))
+    assert abs(float(loss) - float(g["loss"][0])) < 2e-2 * abs(float(g["loss"][0]))
+    for k, v in mod_loss.items():
+        assert abs(float(v) - float(o_mod[k].sum())) < 5e-3 * max(1.0, abs(float(o_mod[k].sum()))), k
+    # gradients: relative Frobenius error per tensor vs the bf16-emulating oracle
+    worst = []
+    for n, p in model.named_parameters():
+        og = P[n].grad
+        if og is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert p.grad is not None, n
+        if float(og.norm()) < 1e-9:
+            assert float(p.grad.norm()) < 1e-6, n
+            continue
+        worst.append((rel(p.grad, og), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 6e-2, worst[:8]
+    assert float(np.median([w[0] for w in worst])) < 2e-2, worst[:8]
+
+
+@pytest.mark.parametrize("name", ["micro_swiglu", "ti_mod7"])
+def test_logits(name):
+    g, case, model = setup(name)
+    model.eval()
+    random.seed(case["order_seed"])
+    with torch.no_grad():
+        logits = model(to_device(case["mod_dict"]), case["N"], case["M"], return_logits=True)
+    for k, v in logits.items():
+        assert tuple(v.shape[:2]) == (case["mod_dict"][k]["tensor"].shape[0], case["M"])
+        fro = float(v.double().norm())
+        # "logits within 1e-3 rel" is not reachable in bf16 (the upstream model's own bf16 autocast
+        # misses its fp32 self by 7e-3); the bf16 pipeline is held to 2e-2 on the norm
+        # and, where the fixture keeps the values, on the relative Frobenius error.
+        assert abs(fro - float(g[f"logits_fro/{k}"])) < 2e-2 * float(g[f"logits_fro/{k}"]), k
+        head = torch.from_numpy(g[f"logits_head/{k}"])
+        mine = v.float().cpu() if head.shape == v.shape else v.float().cpu()[:, :8, :16]
+        assert rel(mine, head) < 3e-2, (k, rel(mine, head))
+
+
+def test_eval_forward_and_accumulation():
+    g, case, model = setup("micro_swiglu")
+    md = to_device(case["mod_dict"])
+    random.seed(1); l1, _ = model(md, case["N"], case["M"]); l1.backward()
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters()}
+    random.seed(1); l2, _ = model(md, case["N"], case["M"]); l2.backward()      # accumulates (no zero_grad between)
+    for n, p in model.named_parameters():
+        assert rel(p.grad, 2 * g1[n]) < 1e-3 or float(g1[n].norm()) == 0, n
+    for p in model.parameters():
+        p.grad = None
+    random.seed(1); l3, _ = model(md, case["N"], case["M"]); (0.5 * l3).backward()
+    for n, p in model.named_parameters():
+        assert rel(p.grad, 0.5 * g1[n]) < 2e-2 or float(g1[n].norm()) == 0, n
+    model.eval()
+    with torch.no_grad():
+        random.seed(1); l4, ml = model(md, case["N"], case["M"])
+    assert abs(float(l4) - float(l1)) < 1e-6 and not l4.requires_grad
+
+
+def test_unsupported_config_is_loud():
+    case = build_case("micro_qknorm")
+    model = build_hip_model(case["cfg"]).cuda()
+    with pytest.raises(NotImplementedError):
+        model(to_device(case["mod_dict"]), case["N"], case["M"])
+
+
+def test_fused_adamw_step_matches_torch():
+    from fourm.utils.optim_factory import FusedAdamW
+    g, case, model = setup("micro_swiglu")
+    md = to_device(case["mod_dict"])
+    ref = build_hip_model(case["cfg"]); ref.load_state_dict(case["sd"]); ref = ref.cuda()
+    opt = FusedAdamW([{"params": [p for n, p in model.named_parameters() if p.dim() > 1], "weight_decay": 0.05},
+                      {"params": [p for n, p in model.named_parameters() if p.dim() <= 1], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
+    ropt = torch.optim.AdamW([{"params": [p for n, p in ref.named_parameters() if p.dim() > 1], "weight_decay": 0.05},
+                              {"params": [p for n, p in ref.named_parameters() if p.dim() <= 1], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
+    for step in range(2):
+        random.seed(step); loss, _ = model(md, case["N"], case["M"]); loss.backward()
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            q.grad = p.grad.clone()
+        norm = opt.fused_grad_norm(clip=1.0)
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step(); ropt.step()
+        opt.zero_grad(); ropt.zero_grad()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert float((p - q).abs().max()) < 2e-6, n
+    sd = opt.state_dict()
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 2.0
