@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 4M-B (fm_base_12e_12d_swiglu_nobias, 7 modalities) masked-modeling TRAIN step on
+synthetic random-token multimodal batches, per-GPU batch 256, 128 input + 128 target tokens per sample
+(BASELINE.json configs[1]; configs[2] = the same per GPU on N GPUs, weak scaling).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = select+embed -> encoder -> decoder -> heads/CE -> hand-written backward -> (RCCL gradient
+mean, overlapped with backward) -> gradient norm -> fused AdamW.  Inputs are resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ml-4m_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MOD7_IN = ["caption", "det", "rgb@224", "tok_clip@224", "tok_depth@224", "tok_normal@224", "tok_rgb@224", "tok_semseg@224"]
+MOD7_OUT = [m for m in MOD7_IN if m != "rgb@224"]
+BF16_PEAK_TFLOPS = 2500.0          # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def build_model(name, device):
+    from fourm.data.modality_info import MODALITY_INFO
+    from fourm.utils import create_model
+    info = {m: dict(MODALITY_INFO[m]) for m in MOD7_IN}
+    for m in info:
+        if info[m]["type"] == "img":
+            info[m]["max_tokens"] = (224 // 16) ** 2
+
+    def embs(mods, key):
+        out = {}
+        for m in mods:
+            kw = dict(patch_size=16, image_size=224) if info[m]["type"] == "img" else {}
+            out[m] = info[m][key](**kw)
+        return out
+    model = create_model(name, encoder_embeddings=embs(MOD7_IN, "encoder_embedding"), decoder_embeddings=embs(MOD7_OUT, "decoder_embedding"),
+                         modality_info=info)
+    return model.to(device)
+
+
+def train_flops_per_sample(model, n_in, n_out, head_vocabs):
+    """Algorithmic FLOPs (2*MAC) of one sample's forward, x3 for the train step."""
+    D, Le, Ld = model.dim, len(model.encoder), len(model.decoder)
+    Hd = model.encoder[0].mlp.hidden_features
+    gated = hasattr(model.encoder[0].mlp, "fc3")
+    mlp = (6 if gated else 4) * D * Hd
+    N, M = n_in, n_out
+    f_enc = N * (6 * D * D + 2 * D * D + mlp) + 4 * N * N * D
+    f_dec = M * (6 * D * D + 2 * D * D + mlp) + 4 * M * M * D + M * 4 * D * D + N * 4 * D * D + 4 * M * N * D
+    f = Le * f_enc + Ld * f_dec + 2 * N * D * D
+    f += 2 * (N / 8) * 768 * D                                   # pixel patches actually selected (uniform split over 8 inputs)
+    f += sum(2 * D * v * (M / len(head_vocabs)) for v in head_vocabs)
+    return 3.0 * f
+
+
+class LaunchProfiler:
+    """Per-launch kernel timing with events recorded on the stream the kernels are enqueued on."""
+
+    def __init__(self):
+        self.recs = []
+
+    class _Ctx:
+        def __init__(self, prof, name, flops, nbytes):
+            self.p, self.name, self.flops, self.nbytes = prof, name, flops, nbytes
+
+        def __enter__(self):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+            return self
+
+        def __exit__(self, *exc):
+            self.b.record(torch.cuda.current_stream())
+            self.p.recs.append((self.name, self.flops, self.nbytes, self.a, self.b))
+            return False
+
+    def launch(self, name, flops, nbytes):
+        return self._Ctx(self, name, flops, nbytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, nb, a, b in self.recs:
+            d = agg.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+            d["ms"] += a.elapsed_time(b); d["flops"] += fl; d["bytes"] += nb; d["n"] += 1
+        return agg
+
+
+def cpu_baseline(batch=8, steps=2):
+    """The oracle port (plain fp32 PyTorch restatement of the upstream model) timed on the host cores:
+    forward + backward + AdamW on the same 4M-B mod7 shapes, small batch.  A reported baseline only."""
+    from oracle import fourm_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    cfg = O.named_cfg("base", O.mod7_specs())
+    sd = O.seeded_state_dict(cfg, seed=0)
+    def is_buffer(k):      # fixed sin-cos tables and the zero bias buffers of the bias-free LayerNorms
+        return "pos_emb" in k or ("norm" in k and k.endswith(".bias"))
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and not is_buffer(k)) for k, v in sd.items()}
+    for m in cfg.mods:
+        if m.in_enc and m.in_dec:
+            P[f"decoder_embeddings.{m.name}.mod_emb"] = P[f"encoder_embeddings.{m.name}.mod_emb"]
+        if m.in_dec:
+            P[f"decoder_embeddings.{m.name}.to_logits.weight"] = P[f"decoder_embeddings.{m.name}.token_emb.weight"]
+    leaves = list({id(v): v for v in P.values() if v.requires_grad}.values())
+    opt = torch.optim.AdamW(leaves, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    md = O.synthetic_mod_dict(cfg, batch, 128, 128, seed=0)
+    order = [m.name for m in cfg.mods if m.in_dec]
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        loss, _ = O.fourm_forward(P, cfg, md, 128, 128, order)
+        loss.sum().backward()
+        opt.step(); opt.zero_grad()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    model = ""
+    try:
+        model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": batch * 256 / t, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle fp32 PyTorch port, 4M-B mod7, batch {batch}, 128+128 tokens, fwd+bwd+AdamW, median of {steps} steps "
+                      f"after 1 warm-up, {t:.2f} s/step", "cpu": model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--model", default="fm_base_12e_12d_swiglu_nobias")
+    ap.add_argument("--n-in", type=int, default=128)
+    ap.add_argument("--n-out", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible: the 4M hot path has no CPU implementation"}))
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from fourm.data.synthetic import synthetic_batch
+    from fourm.hip import ops
+    from fourm.parallel import DataParallel
+    from fourm.utils.optim_factory import FusedAdamW, get_parameter_groups
+
+    torch.manual_seed(0)
+    model = build_model(a.model, dev).train()
+    dp = DataParallel(model) if world > 1 else None
+    fwd = dp if dp is not None else model
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        groups = get_parameter_groups(model, weight_decay=0.05, skip_list=model.no_weight_decay())
+    opt = FusedAdamW(groups, lr=1e-4 * a.batch * world / 256, betas=(0.9, 0.95), eps=1e-8)
+    batches = [synthetic_batch(model, a.batch, a.n_in, a.n_out, device=dev, seed=1000 * rank + i) for i in range(2)]
+    import random
+    random.seed(rank)
+
+    def step(i):
+        loss, mod_loss = fwd(batches[i % 2], a.n_in, a.n_out, loss_type="mod")
+        loss.backward()
+        norm = opt.fused_grad_norm()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss, norm
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        loss, norm = step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss, norm = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    last_loss = float(loss)
+
+    tokens_per_step = world * a.batch * (a.n_in + a.n_out)
+    value = tokens_per_step * a.steps / dt
+    head_vocabs = [model.decoder_embeddings[m].vocab_size for m in MOD7_OUT]
+    flops_step = train_flops_per_sample(model, a.n_in, a.n_out, head_vocabs) * a.batch
+    out = {
+        "metric": "multimodal tokens/sec (4M-B train step, whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "4M-B mod7 (fm_base_12e_12d_swiglu_nobias, 360.8M params) masked-modeling train step, 224^2 token grids, "
+                               "128 input + 128 target tokens/sample, AdamW", "model": a.model, "per_gpu_batch": a.batch,
+                   "global_batch": a.batch * world, "seq_len": a.n_in + a.n_out, "parallelism": f"dp{world}"},
+        "tokens_per_sec_per_gpu": value / world,
+        "mfu": flops_step * a.steps / dt / (BF16_PEAK_TFLOPS * 1e12),
+        "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12, "final_loss": last_loss,
+    }
+
+    # ---- dominant kernel vs its roofline, measured live with events on the launch stream (rank 0) ----------
+    if rank == 0 and not a.no_kernel_profile:
+        prof = LaunchProfiler()
+        ops.set_profiler(prof)
+        for i in range(2):
+            step(i)
+        ops.set_profiler(None)
+        agg = prof.summary()
+        tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
+        symbol = {"gemm_nt": "gemm_nt_kernel<128,128,2,2,{epi},false>", "gemm_tn": "gemm_tn_kernel<true,false>",
+                  "attn_fwd": "attn_fwd_kernel<true>", "attn_bwd": "attn_bwd_kernel<true>",
+                  "layernorm_fwd": "ln_fwd_kernel<bf16>", "layernorm_bwd": "ln_bwd_kernel"}
+        name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        fam, _, epi = name.partition("/epi")
+        common = {"kernel": symbol.get(fam, fam).format(epi=epi or "0"), "traffic": None, "launches_per_step": d["n"] // 2,
+                  "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms}
+        if d["flops"] > 0:
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS, **common}
+        else:
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, **common}
+        out["kernel_breakdown_ms_per_step"] = {k: round(v["ms"] / 2, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        out["kernel_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in agg.items() if v["flops"] > 0 and v["ms"] > 0}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline is informational; never lose the GPU result over it
+            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

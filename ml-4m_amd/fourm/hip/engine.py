@@ -92,7 +92,7 @@ class FourMEngine:
         self.flat_params = self.flat_grads = None
         self._slices = {}
         self._ctx = None           # saved state of the last training forward
-        self._grad_zeroed_for = None
+        self.reducer = None        # fourm.parallel.GradReducer when gradients are exchanged (data parallel)
 
     # ------------------------------------------------------------------------------------------
     # flat parameter / gradient stores
@@ -141,6 +141,41 @@ class FourMEngine:
             if p.data_ptr() != self.flat_params.data_ptr() + 4 * o:
                 self.flatten()
                 return
+
+    def grad_stages(self):
+        """{stage: [(offset, length)]} over the flat gradient store, keyed by the backward stage after
+        which those gradients are final.  Shared tensors (tied heads, shared mod_emb, norm weights in the
+        trailing no-decay region) belong to the last stage that touches them."""
+        m = self.model
+        owner = {}
+
+        def claim(stage, module_or_params):
+            ps = module_or_params.parameters() if isinstance(module_or_params, nn.Module) else module_or_params
+            for p in ps:
+                owner[id(p)] = stage          # later claims win
+        for i, blk in enumerate(m.decoder):
+            claim(f"dec{i}", blk)
+        claim("heads", [m.decoder_norm.weight] + ([m.decoder_norm.bias] if isinstance(m.decoder_norm.bias, nn.Parameter) else []))
+        claim("dec_emb", m.decoder_embeddings)
+        claim("dec_emb", [m.mask_token])
+        claim("ctx", m.decoder_proj_context)
+        claim("ctx", m.encoder_norm)
+        for i, blk in enumerate(m.encoder):
+            claim(f"enc{i}", blk)
+        claim("enc_emb", m.encoder_embeddings)       # includes the mod_emb shared with the decoder side
+        if m.register_tokens is not None:
+            claim("enc_emb", [m.register_tokens])
+        stages = {}
+        for n, p in self._named:
+            o, k = self._slices[id(p)]
+            # tiny tensors (norm weights, biases) all sit in the trailing no-decay region: one final slice
+            stage = owner.get(id(p), "enc_emb") if k >= 65536 else "tail"
+            stages.setdefault(stage, []).append((o, ru(k, 16)))
+        return stages
+
+    def _stage(self, name):
+        if self.reducer is not None:
+            self.reducer.stage_done(name)
 
     def grad_view(self, p):
         o, k = self._slices[id(p)]
@@ -676,6 +711,8 @@ class FourMEngine:
         if c is None:
             raise RuntimeError("train_backward without a preceding training forward")
         self._ctx = None
+        if self.reducer is not None:
+            self.reducer.begin()
         m, ws = self.model, self.ws
         enc, dec, st, hs = c["enc"], c["dec"], c["st"], c["hs"]
         B, N, Mt, D = enc["B"], enc["Nt"], dec["Nt"], self.D
@@ -696,13 +733,16 @@ class FourMEngine:
         g = ws.get("bwd.g_dec", (Rqp, D), f32)
         g_bf = ws.get("bwd.g_dec_bf", (Rqp, D), bf)
         self._ln_bwd(m.decoder_norm, dyp, st["y_final"], hs["sv"], "dn", g, g_bf, Rq, dres=None, dy_row_map=hs["r2p"])
+        self._stage("heads")
         # ---- decoder ----------------------------------------------------------------------------------
         dctx = ws.get("bwd.dctx", (Rcp, D), f32)
         dctx_bf = ws.get("bwd.dctx_bf", (Rcp, D), bf)
         dctx.zero_()
-        for blk, sv in zip(reversed(m.decoder), reversed(st["dec_layers"])):
-            self.decoder_block_bwd(blk, sv, g, g_bf, dctx, dctx_bf, st["ctx"], B, Mt, N, st["smask"], st["emask"])
+        for i in reversed(range(len(m.decoder))):
+            self.decoder_block_bwd(m.decoder[i], st["dec_layers"][i], g, g_bf, dctx, dctx_bf, st["ctx"], B, Mt, N, st["smask"], st["emask"])
+            self._stage(f"dec{i}")
         self._embed_bwd(dec, g, None, True)
+        self._stage("dec_emb")
         # ---- context projection + encoder -------------------------------------------------------------
         top = st["top"]
         if len(m.decoder) == 0:
@@ -713,8 +753,10 @@ class FourMEngine:
         ge = ws.get("bwd.g_enc", (Rcp, D), f32)
         ge_bf = ws.get("bwd.g_enc_bf", (Rcp, D), bf)
         self._ln_bwd(m.encoder_norm, dxn, st["x_final"], top, "en", ge, ge_bf, Rc, dres=None)
-        for blk, sv in zip(reversed(m.encoder), reversed(st["enc_layers"])):
-            self.encoder_block_bwd(blk, sv, ge, ge_bf, B, N, st["emask"])
+        self._stage("ctx")
+        for i in reversed(range(len(m.encoder))):
+            self.encoder_block_bwd(m.encoder[i], st["enc_layers"][i], ge, ge_bf, B, N, st["emask"])
+            self._stage(f"enc{i}")
         # d(x0) -> token tables / projections / embeddings; d(ctx) also reaches the encoder embeddings
         for n in enc["names"]:
             e = m.encoder_embeddings[n]
@@ -723,3 +765,5 @@ class FourMEngine:
             elif e.kind == L.KIND_SEQ_EMB and e.emb_proj.weight.requires_grad:
                 ops.gemm_tn(ge_bf, enc["seqemb_rows"], self.grad_view(e.emb_proj.weight), N=D, K=e.emb_proj.weight.shape[1], R=ru(Rc, 64))
         self._embed_bwd(enc, ge, dctx, False)
+        if self.reducer is not None:
+            self.reducer.finish()        # remaining slices + wait: gradients are averaged when backward returns

@@ -7,6 +7,31 @@ import torch
 
 from . import _lib as L
 
+# Optional per-launch timing (bench.py): an object with .launch(name, flops, bytes) -> context manager
+# that brackets the launch with events on the CURRENT stream (the one the kernels are enqueued on).
+_PROFILER = None
+
+
+def set_profiler(p):
+    global _PROFILER
+    _PROFILER = p
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _Null()
+
+
+def _prof(name, flops=0.0, nbytes=0.0):
+    return _NULL if _PROFILER is None else _PROFILER.launch(name, flops, nbytes)
+
+
 BK = 64          # reduction granularity of the GEMMs (zero padded)
 SEG = 128        # row-segment alignment of the grouped head GEMMs
 
@@ -47,7 +72,8 @@ def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bia
     a.ldo2 = _ld(out2) if out2 is not None else 0
     a.ldr = _ld(res) if res is not None else 0
     a.Hp, a.epilogue = Hp, epilogue
-    L.check(L.gemm_nt(C.byref(a), _stream()))
+    with _prof(f"gemm_nt/epi{epilogue}", 2.0 * a.M * a.N * a.K * (2 if epilogue == L.EPI_SWIGLU else 1)):
+        L.check(L.gemm_nt(C.byref(a), _stream()))
     return out
 
 
@@ -73,7 +99,8 @@ def gemm_tn(a_mat, b_mat, out, *, N=None, K=None, R=None, splits=0, force_tr=-1,
     a.a_cols = a_cols or a_mat.shape[1]
     a.b_cols = b_cols or b_mat.shape[1]
     a.splits, a.force_tr = splits, force_tr
-    L.check(L.gemm_tn(C.byref(a), _stream()))
+    with _prof("gemm_tn", 2.0 * a.R * a.N * a.K):
+        L.check(L.gemm_tn(C.byref(a), _stream()))
     return out
 
 
@@ -105,6 +132,11 @@ def make_groups(entries, device):
 # ---------------------------------------------------------------------------------------------
 def layernorm_fwd(x, w, b, y, mean=None, rstd=None, row_map=None, eps=1e-6, R=None):
     R = x.shape[0] if R is None else R
+    with _prof("layernorm_fwd", 0.0, R * w.numel() * (4 + y.element_size())):
+        return _ln_fwd(x, w, b, y, mean, rstd, row_map, eps, R)
+
+
+def _ln_fwd(x, w, b, y, mean, rstd, row_map, eps, R):
     L.check(L.layernorm_fwd(_p(x), _ld(x), _p(w), _p(b), _p(y), _ld(y), 1 if y.dtype == torch.float32 else 0,
                             _p(mean), _p(rstd), _p(row_map), R, w.numel(), eps, _stream()))
     return y
@@ -112,6 +144,11 @@ def layernorm_fwd(x, w, b, y, mean=None, rstd=None, row_map=None, eps=1e-6, R=No
 
 def layernorm_bwd(dy, x, w, mean, rstd, dx, *, dres=None, dx_bf16=None, dw=None, db=None, dy_row_map=None, R=None):
     R = x.shape[0] if R is None else R
+    with _prof("layernorm_bwd", 0.0, R * w.numel() * (2 + 4 + 4 + 4 + (2 if dx_bf16 is not None else 0))):
+        return _ln_bwd(dy, x, w, mean, rstd, dx, dres, dx_bf16, dw, db, dy_row_map, R)
+
+
+def _ln_bwd(dy, x, w, mean, rstd, dx, dres, dx_bf16, dw, db, dy_row_map, R):
     L.check(L.layernorm_bwd(_p(dy), _ld(dy), _p(dy_row_map), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _ld(dx),
                             _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0, _p(dw), _p(db), R, w.numel(), _stream()))
     return dx
@@ -136,7 +173,8 @@ def attn_fwd(q, k, v, o, B, H, Nq, Nk, scale, *, mask_kind=L.MASK_NONE, kpad=Non
              causal=False, stat_m=None, stat_l=None, force_tr=-1):
     """q/k/v/o: 2-D bf16 views whose row t of sample b is row b*N + t; head h occupies columns [64h, 64h+64)."""
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
-    L.check(L.attn_fwd(C.byref(a), _stream()))
+    with _prof("attn_fwd", 4.0 * B * H * Nq * Nk * 64):
+        L.check(L.attn_fwd(C.byref(a), _stream()))
     return o
 
 
@@ -145,7 +183,8 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, B, H, Nq, Nk, scale, stat_m, stat_l, *,
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
     a.dO, a.dQ, a.dK, a.dV = _p(do), _p(dq), _p(dk), _p(dv)
     a.lddo, a.lddq, a.lddk, a.lddv = do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
-    L.check(L.attn_bwd(C.byref(a), _stream()))
+    with _prof("attn_bwd", 10.0 * B * H * Nq * Nk * 64):
+        L.check(L.attn_bwd(C.byref(a), _stream()))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -149,7 +149,8 @@ def test_fused_adamw_step_matches_torch():
     from fourm.utils.optim_factory import FusedAdamW
     g, case, model = setup("micro_swiglu")
     md = to_device(case["mod_dict"])
-    ref = build_hip_model(case["cfg"]); ref.load_state_dict(case["sd"]); ref = ref.cuda()
+    ref = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    ref.load_state_dict(case["sd"]); ref = ref.cuda()
     opt = FusedAdamW([{"params": [p for n, p in model.named_parameters() if p.dim() > 1], "weight_decay": 0.05},
                       {"params": [p for n, p in model.named_parameters() if p.dim() <= 1], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
     ropt = torch.optim.AdamW([{"params": [p for n, p in ref.named_parameters() if p.dim() > 1], "weight_decay": 0.05},
