@@ -30,7 +30,7 @@ def modality_shapes(model, seq_tensor_len=None):
 def _split_budget(gen, batch, caps: torch.Tensor, total: int, device):
     """Per-sample multinomial split of ``total`` over len(caps) bins, clipped to caps, remainder handed
     to bins with room (in order)."""
-    n = caps.numel()
+    n = caps.shape[-1]
     draws = torch.multinomial(torch.ones(batch, n, device=device), total, replacement=True, generator=gen)
     k = torch.zeros(batch, n, dtype=torch.long, device=device).scatter_add_(1, draws, torch.ones_like(draws))
     caps_b = caps[None].expand(batch, n) if caps.dim() == 1 else caps
