@@ -97,11 +97,25 @@ class LaunchProfiler:
         return agg
 
 
-def cpu_baseline(batch=8, steps=2):
+def cpu_baseline(timeout_s=240):
+    """Run the CPU-oracle leg in a child process (bounded wall time, its own thread pool)."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True, text=True,
+                           timeout=timeout_s, env={**os.environ, "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:
+        return {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"CPU oracle leg did not finish within {timeout_s}s ({type(e).__name__})"}
+
+
+def cpu_baseline_worker(batch=8, steps=2):
     """The oracle port (plain fp32 PyTorch restatement of the upstream model) timed on the host cores:
     forward + backward + AdamW on the same 4M-B mod7 shapes, small batch.  A reported baseline only."""
     from oracle import fourm_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    threads = min(64, os.cpu_count() or 1)        # more threads than this only adds contention at batch 8
+    torch.set_num_threads(threads)
     cfg = O.named_cfg("base", O.mod7_specs())
     sd = O.seeded_state_dict(cfg, seed=0)
     def is_buffer(k):      # fixed sin-cos tables and the zero bias buffers of the bias-free LayerNorms
@@ -129,7 +143,7 @@ def cpu_baseline(batch=8, steps=2):
         model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    return {"value": batch * 256 / t, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": batch * 256 / t, "unit": "tokens/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
             "sample": f"oracle fp32 PyTorch port, 4M-B mod7, batch {batch}, 128+128 tokens, fwd+bwd+AdamW, median of {steps} steps "
                       f"after 1 warm-up, {t:.2f} s/step", "cpu": model}
 
@@ -145,7 +159,11 @@ def main():
     ap.add_argument("--n-out", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.cpu_baseline_worker:
+        print(json.dumps(cpu_baseline_worker()))
+        return
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
@@ -247,10 +265,8 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline()
-        except Exception as e:  # the baseline is informational; never lose the GPU result over it
-            out["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), file=sys.stderr)      # the GPU result is safe on stderr before the CPU leg starts
+        out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
