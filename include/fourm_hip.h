@@ -57,6 +57,10 @@ typedef struct fm_gemm_nt_args {
     const fm_gemm_group* groups; const int32_t* tile_group; int32_t max_N, pad_;
 } fm_gemm_nt_args;
 int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
+/* tile configuration of fm_gemm_nt: 0 = 128x128 workgroup tile (4 waves), 1 = 128 (features) x 256 (rows),
+ * 8 waves (default).  Both use a 3-stage LDS ring.  For A/B measurements. */
+void fm_set_gemm_nt_config(int cfg);
+int fm_get_gemm_nt_config(void);
 
 /* out[n][k] += sum_r A[r][n] * B[r][k]   (fp32 atomic accumulation, reduction split over blocks).
  * Replaces the weight-gradient matmul autograd runs for nn.Linear (dW = dY^T X).

@@ -67,32 +67,32 @@ __device__ __forceinline__ bf16x8_t pack8(const float* p) {
     return x.v;
 }
 
+template <int MASK>
 __device__ __forceinline__ bool blocked_qk(const AttnArgs& a, int b, int q, int k, int csq, int mq, int mk, bool kp) {
-    switch (a.mask_kind) {
-        case FM_MASK_KEYPAD: return kp;
-        case FM_MASK_DECODER: {
-            bool blk = false;
-            if (a.causal) blk = k > q;
-            else if (a.cs) blk = k >= csq;
-            if (a.modq) blk = blk || (mq != mk);
-            return blk;
-        }
-        case FM_MASK_DENSE: return a.dense[((size_t)b * a.Nq + q) * a.Nk + k] != 0;
-        default: return false;
-    }
+    if constexpr (MASK == FM_MASK_KEYPAD) return kp;
+    else if constexpr (MASK == FM_MASK_DECODER) {
+        bool blk = false;
+        if (a.causal) blk = k > q;
+        else if (a.cs) blk = k >= csq;
+        if (a.modq) blk = blk || (mq != mk);
+        return blk;
+    } else if constexpr (MASK == FM_MASK_DENSE) return a.dense[((size_t)b * a.Nq + q) * a.Nk + k] != 0;
+    else return false;
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward: grid (ceil(Nq/128), H, B), 4 waves x 32 queries, keys in tiles of 64 with online softmax
 // ------------------------------------------------------------------------------------------------
-template <bool TR>
+template <bool TR, int MASK>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     constexpr int KT = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [2 buffers][K tile 8 KB | V tile 8 KB] then per-buffer key metadata
+    // [2 buffers][K tile 8 KB | V tile 8 KB] then the key metadata of the whole sequence (one global
+    // round trip in the prologue instead of one per key tile)
     char* tiles = smem;
-    int16_t* kmod_l = (int16_t*)(smem + 2 * 2 * KT * ROWB);      // [2][64]
-    uint8_t* kpad_l = (uint8_t*)(kmod_l + 2 * KT);               // [2][64]
+    const int NkP = (a.Nk + KT - 1) / KT * KT;
+    int16_t* kmod_l = (int16_t*)(smem + 2 * 2 * KT * ROWB);      // [NkP]
+    uint8_t* kpad_l = (uint8_t*)(kmod_l + NkP);                  // [NkP]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -110,21 +110,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(Qb + (size_t)qc * a.ldq + (kk * 2 + fhi) * 8);
     int csq = 0, mq = 0;
-    if (a.mask_kind == FM_MASK_DECODER) {
+    if constexpr (MASK == FM_MASK_DECODER) {
         if (a.cs) csq = a.cs[(size_t)b * a.Nq + qc];
         if (a.modq) mq = a.modq[(size_t)b * a.Nq + qc];
+    }
+    if constexpr (MASK == FM_MASK_DECODER || MASK == FM_MASK_KEYPAD) {
+        for (int k = threadIdx.x; k < NkP; k += 256) {
+            const int kc = k < a.Nk ? k : a.Nk - 1;
+            if constexpr (MASK == FM_MASK_DECODER) kmod_l[k] = a.modk ? a.modk[(size_t)b * a.Nk + kc] : (int16_t)0;
+            else kpad_l[k] = a.kpad[(size_t)b * a.Nk + kc];
+        }
     }
 
     auto stage = [&](int t, int buf) {
         char* kt = tiles + buf * 2 * KT * ROWB;
         stage_rows<4>(Kb, a.ldk, t * KT, a.Nk, KT, kt, wave, lane);
         stage_rows<4>(Vb, a.ldv, t * KT, a.Nk, KT, kt + KT * ROWB, wave, lane);
-        if (threadIdx.x < KT) {
-            const int k = t * KT + threadIdx.x;
-            const int kc = k < a.Nk ? k : a.Nk - 1;
-            kmod_l[buf * KT + threadIdx.x] = (a.mask_kind == FM_MASK_DECODER && a.modk) ? a.modk[(size_t)b * a.Nk + kc] : (int16_t)0;
-            kpad_l[buf * KT + threadIdx.x] = (a.mask_kind == FM_MASK_KEYPAD) ? a.kpad[(size_t)b * a.Nk + kc] : (uint8_t)0;
-        }
     };
 
     f32x16_t o[2];
@@ -163,9 +164,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
                 const int k = t * KT + kl;
                 float s = bfround(bfround(st[kb][r]) * a.scale);
-                if (a.mask_kind != FM_MASK_NONE) {
-                    const bool blk = blocked_qk(a, b, qc, k < a.Nk ? k : a.Nk - 1, csq, mq, kmod_l[buf * KT + kl], kpad_l[buf * KT + kl] != 0);
-                    s = blk ? NEG_FILL : s;
+                if constexpr (MASK != FM_MASK_NONE) {
+                    int mk = 0; bool kp = false;
+                    if constexpr (MASK == FM_MASK_DECODER) mk = kmod_l[k];
+                    if constexpr (MASK == FM_MASK_KEYPAD) kp = kpad_l[k] != 0;
+                    s = blocked_qk<MASK>(a, b, qc, k < a.Nk ? k : a.Nk - 1, csq, mq, mk, kp) ? NEG_FILL : s;
                 }
                 s = k < a.Nk ? s : -INFINITY;
                 p[kb][r] = s;
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 //   pass B  (a wave owns 32 queries, loops over keys)   -> dQ
 // S and dP are recomputed in both passes, so no atomics and no register-tile transposes.
 // ------------------------------------------------------------------------------------------------
-template <bool TR>
+template <bool TR, int MASK>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
@@ -260,23 +263,40 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     stage_rows<4>(dOb, a.lddo, 0, a.Nq, NqP, dOl, wave, lane);
     stage_rows<4>(Kb, a.ldk, 0, a.Nk, NkP, Kl, wave, lane);
     stage_rows<4>(Vb, a.ldv, 0, a.Nk, NkP, Vl, wave, lane);
-    for (int q = wave; q < NqP; q += 4) {
+    // delta[q] = sum_d dO[q][d] * O[q][d]: two threads per query row, 4 x 16-byte loads each from O and dO,
+    // all independent (one memory round trip for the whole prologue)
+    for (int q0 = 0; q0 < NqP; q0 += 128) {
+        const int q = q0 + (threadIdx.x >> 1), half = threadIdx.x & 1;
         float dl = 0.f;
-        if (q < a.Nq) dl = bf2f(Ob[(size_t)q * a.ldo + lane]) * bf2f(dOb[(size_t)q * a.lddo + lane]);
-        dl = wave_sum(dl);
-        if (lane == 0) {
+        if (q < a.Nq) {
+            const uint4* op = (const uint4*)(Ob + (size_t)q * a.ldo + half * 32);
+            const uint4* gp = (const uint4*)(dOb + (size_t)q * a.lddo + half * 32);
+            uint4 ov[4], gv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ov[i] = op[i]; gv[i] = gp[i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t* o32 = (const uint32_t*)&ov[i];
+                const uint32_t* g32 = (const uint32_t*)&gv[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dl += bf2f((bf16_t)(o32[e] & 0xffff)) * bf2f((bf16_t)(g32[e] & 0xffff)) + bf2f((bf16_t)(o32[e] >> 16)) * bf2f((bf16_t)(g32[e] >> 16));
+            }
+        }
+        dl += __shfl_xor(dl, 1, 64);
+        if (half == 0 && q < NqP) {
             const size_t si = ((size_t)b * a.H + h) * a.Nq + (q < a.Nq ? q : 0);
             delta_l[q] = dl;
             m_l[q] = q < a.Nq ? a.stat_m[si] : 0.f;
             linv_l[q] = q < a.Nq ? 1.0f / a.stat_l[si] : 0.f;
-            cs_l[q] = (a.mask_kind == FM_MASK_DECODER && a.cs && q < a.Nq) ? a.cs[(size_t)b * a.Nq + q] : 0;
-            modq_l[q] = (a.mask_kind == FM_MASK_DECODER && a.modq && q < a.Nq) ? a.modq[(size_t)b * a.Nq + q] : (int16_t)0;
+            cs_l[q] = (MASK == FM_MASK_DECODER && a.cs && q < a.Nq) ? a.cs[(size_t)b * a.Nq + q] : 0;
+            modq_l[q] = (MASK == FM_MASK_DECODER && a.modq && q < a.Nq) ? a.modq[(size_t)b * a.Nq + q] : (int16_t)0;
         }
     }
     for (int k = threadIdx.x; k < NkP; k += 256) {
         const int kc = k < a.Nk ? k : a.Nk - 1;
-        modk_l[k] = (a.mask_kind == FM_MASK_DECODER && a.modk) ? a.modk[(size_t)b * a.Nk + kc] : (int16_t)0;
-        kpad_l[k] = (a.mask_kind == FM_MASK_KEYPAD) ? a.kpad[(size_t)b * a.Nk + kc] : (uint8_t)0;
+        modk_l[k] = (MASK == FM_MASK_DECODER && a.modk) ? a.modk[(size_t)b * a.Nk + kc] : (int16_t)0;
+        kpad_l[k] = (MASK == FM_MASK_KEYPAD) ? a.kpad[(size_t)b * a.Nk + kc] : (uint8_t)0;
     }
     __syncthreads();
 
@@ -314,7 +334,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
                 const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
                 const int qc = q < a.Nq ? q : a.Nq - 1;
                 float sc = bfround(bfround(s[r]) * a.scale);
-                const bool blk = a.mask_kind != FM_MASK_NONE && blocked_qk(a, b, qc, kc, cs_l[qc], modq_l[qc], mk, kp);
+                bool blk = false;
+                if constexpr (MASK != FM_MASK_NONE) blk = blocked_qk<MASK>(a, b, qc, kc, MASK == FM_MASK_DECODER ? cs_l[qc] : 0, MASK == FM_MASK_DECODER ? modq_l[qc] : 0, mk, kp);
                 sc = blk ? NEG_FILL : sc;
                 float pr = __expf(sc - m_l[q]) * linv_l[q];
                 pr = (q < a.Nq && k < a.Nk) ? pr : 0.f;
@@ -381,7 +402,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
                 const int k = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
                 const int kc = k < a.Nk ? k : a.Nk - 1;
                 float sc = bfround(bfround(s[r]) * a.scale);
-                const bool blk = a.mask_kind != FM_MASK_NONE && blocked_qk(a, b, qc, kc, csq, mq, modk_l[kc], kpad_l[kc] != 0);
+                bool blk = false;
+                if constexpr (MASK != FM_MASK_NONE) blk = blocked_qk<MASK>(a, b, qc, kc, csq, mq, MASK == FM_MASK_DECODER ? modk_l[kc] : 0, MASK == FM_MASK_KEYPAD ? kpad_l[kc] != 0 : false);
                 sc = blk ? NEG_FILL : sc;
                 float pr = __expf(sc - mq_) * li;
                 pr = (q < a.Nq && k < a.Nk) ? pr : 0.f;
@@ -441,11 +463,23 @@ extern "C" int fm_attn_fwd(const fm_attn_args* p, void* stream) {
     AttnArgs a{};
     if (int rc = fill(a, p, "fm_attn_fwd")) return rc;
     FM_CHECK_ARG((a.stat_m == nullptr) == (a.stat_l == nullptr), "fm_attn_fwd: stat_m and stat_l go together");
-    const size_t lds = 2 * 2 * 64 * ROWB + 2 * 64 * 2 + 2 * 64;
+    const int NkP = (a.Nk + 63) / 64 * 64;
+    const size_t lds = 2 * 2 * 64 * ROWB + (size_t)NkP * 3 + 16;
+    FM_CHECK_ARG(lds <= 150 * 1024, "fm_attn_fwd: Nk=%d too long for the key metadata buffer", a.Nk);
     dim3 grid((a.Nq + 127) / 128, a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
-    if (tr) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+#define FWD(TR, MK) hipLaunchKernelGGL((attn_fwd_kernel<TR, MK>), grid, dim3(256), lds, (hipStream_t)stream, a)
+#define FWD_MASK(TR)                                                        \
+    switch (a.mask_kind) {                                                  \
+        case FM_MASK_NONE: FWD(TR, FM_MASK_NONE); break;                    \
+        case FM_MASK_KEYPAD: FWD(TR, FM_MASK_KEYPAD); break;                \
+        case FM_MASK_DECODER: FWD(TR, FM_MASK_DECODER); break;              \
+        case FM_MASK_DENSE: FWD(TR, FM_MASK_DENSE); break;                  \
+        default: fm_set_error("fm_attn_fwd: unknown mask kind %d", a.mask_kind); return -1; \
+    }
+    if (tr) { FWD_MASK(true) } else { FWD_MASK(false) }
+#undef FWD_MASK
+#undef FWD
     FM_CHECK_LAUNCH("fm_attn_fwd");
     return 0;
 }
@@ -458,13 +492,26 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     FM_CHECK_ARG(p->lddo % 8 == 0 && p->lddq % 4 == 0 && p->lddk % 4 == 0 && p->lddv % 4 == 0, "fm_attn_bwd: leading dims");
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
     const size_t lds = (size_t)(2 * NqP + 2 * NkP) * ROWB + NqP * (3 * 4 + 4 + 2) + NkP * (2 + 1) + 64;
-    static bool once = (hipFuncSetAttribute((const void*)attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) &&
-                       (hipFuncSetAttribute((const void*)attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);
-    (void)once;
     dim3 grid(a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
-    if (tr) hipLaunchKernelGGL(attn_bwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_bwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+#define BWD(TR, MK)                                                                                                   \
+    {                                                                                                                 \
+        auto k = attn_bwd_kernel<TR, MK>;                                                                             \
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
+        (void)once;                                                                                                   \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, a);                                          \
+    }
+#define BWD_MASK(TR)                                                        \
+    switch (a.mask_kind) {                                                  \
+        case FM_MASK_NONE: BWD(TR, FM_MASK_NONE) break;                     \
+        case FM_MASK_KEYPAD: BWD(TR, FM_MASK_KEYPAD) break;                 \
+        case FM_MASK_DECODER: BWD(TR, FM_MASK_DECODER) break;               \
+        case FM_MASK_DENSE: BWD(TR, FM_MASK_DENSE) break;                   \
+        default: fm_set_error("fm_attn_bwd: unknown mask kind %d", a.mask_kind); return -1; \
+    }
+    if (tr) { BWD_MASK(true) } else { BWD_MASK(false) }
+#undef BWD_MASK
+#undef BWD
     FM_CHECK_LAUNCH("fm_attn_bwd");
     return 0;
 }

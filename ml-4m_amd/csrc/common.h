@@ -112,3 +112,21 @@ __device__ __forceinline__ bf16x8_t lds_col_frag(AddrFn addr_of, int rA, int rB,
     }
     return u.v;
 }
+
+// The same transpose-read fragment issued through inline asm: hipcc (ROCm 7.2) orders a ds_read_tr
+// *builtin* behind every outstanding LDS-DMA with a full `s_waitcnt vmcnt(0)`, which drains a
+// multi-stage prefetch ring.  The asm form is invisible to that pass; the caller owns the waits
+// (`wait_lgkmcnt<N>()` + `__builtin_amdgcn_sched_barrier(0)` before the first consumer, guide 5.7 / rule 18).
+template <typename AddrFn>
+__device__ __forceinline__ bf16x8_t lds_col_frag_tr_async(AddrFn addr_of, int rA, int rB, int col_base32) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 15;
+    const int c = col_base32 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+    union { bf16x8_t v; s16x4_t h[2]; } u;
+    const uint32_t a0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(addr_of(rA + (i >> 2), c));
+    const uint32_t a1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)(addr_of(rB + (i >> 2), c));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.h[0]) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(u.h[1]) : "v"(a1));
+    return u.v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }

@@ -39,9 +39,20 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // ------------------------------------------------------------------------------------------------
 // NT kernel
 // ------------------------------------------------------------------------------------------------
-template <int TW, int TX, int WW, int WX, int EPI, bool GROUPED>
+// wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// STAGES-deep LDS ring: the DMA of K-tile t+STAGES-1 is issued while tile t is being multiplied; waits are
+// counted (never a full drain inside the loop) and there is one workgroup barrier per K-tile.
+template <int TW, int TX, int WW, int WX, int STAGES, int EPI, bool GROUPED>
 __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     constexpr int NWAVES = WW * WX;
+    constexpr int LOADS = (TW + TX) / (8 * NWAVES);           // LDS-DMA instructions per wave per stage
     constexpr int FW = TW / WW / 32, FX = TX / WX / 32;      // 32x32 fragments per wave
     constexpr int STAGE = (TW + TX) * ROWB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -105,17 +116,24 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int KT = K / BK;
-    stage(0, 0);
-    __syncthreads();   // (drains the LDS-DMA: vmcnt(0) + barrier)
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (p < KT) stage(p, p);
 
     // per-lane constants of the fragment reads
     const int frow = lane & 31;                 // row inside a 32-row fragment
     const int fswz = (frow >> 1) & 7;           // swizzle key (fragment bases are multiples of 32)
     const int fhi = lane >> 5;
 
+    int buf = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) stage(kt + 1, buf ^ 1);
+        // tile kt has landed once at most min(STAGES-2, KT-1-kt) younger stages are still in flight
+        const int younger = KT - 1 - kt;
+        if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LOADS>();
+        else if (STAGES >= 3 && younger >= 1) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+        block_barrier();      // everyone's pieces of tile kt are in LDS; everyone is done reading tile kt-1
+        if (kt + STAGES - 1 < KT) stage(kt + STAGES - 1, (buf + STAGES - 1) % STAGES);
         const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * ROWB;
         const char* xt = smem + buf * STAGE + TW * ROWB + (wx * (TX / WX) + frow) * ROWB;
 #pragma unroll
@@ -132,7 +150,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                 for (int j = 0; j < FX; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
 
     // ---- epilogue: lane holds, per fragment, 4 groups of 4 consecutive features of one row ---
@@ -218,9 +236,10 @@ __device__ __forceinline__ const char* tn_addr(const char* tile, int row, int co
     return tile + row * TROWB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
 }
 
-template <bool TR, bool GROUPED>
+template <bool TR, bool GROUPED, int STAGES>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
     constexpr int TA = 128, TB = 128, NWAVES = 4;
+    constexpr int LOADS = 2 * BK / (4 * NWAVES);              // LDS-DMA instructions per wave per stage
     constexpr int STAGE = 2 * BK * TROWB;      // A tile + B tile, 64 reduction rows each
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -270,31 +289,64 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    stage(t_begin, 0);
-    __syncthreads();
+    const int NT_ = t_end - t_begin;
+#pragma unroll
+    for (int p = 0; p < STAGES - 1; ++p)
+        if (p < NT_) stage(t_begin + p, p);
     const int fhi = lane >> 5;
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) stage(t + 1, buf ^ 1);
+    int buf = 0;
+    for (int it = 0; it < NT_; ++it) {
+        const int younger = NT_ - 1 - it;
+        if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LOADS>();
+        else if (STAGES >= 3 && younger >= 1) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+        block_barrier();
+        if (it + STAGES - 1 < NT_) stage(t_begin + it + STAGES - 1, (buf + STAGES - 1) % STAGES);
         const char* at = smem + buf * STAGE;
         const char* bt = at + BK * TROWB;
+        if constexpr (TR) {
+            // fragments of step kk+1 are in flight while the MFMAs of step kk run (8 transpose reads per step)
+            bf16x8_t af[2][2], bfr[2][2];
+            auto load = [&](int kk, int par) {
+                const int rA = kk * 16 + fhi * 8, rB = rA + 4;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            const int rA = kk * 16 + fhi * 8, rB = rA + 4;
-            bf16x8_t af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = lds_col_frag<TR>([&](int r, int c) { return tn_addr(at, r, c); }, rA, rB, wa * 64 + i * 32);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bfr[j] = lds_col_frag<TR>([&](int r, int c) { return tn_addr(bt, r, c); }, rA, rB, wb * 64 + j * 32);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
+                    af[par][i] = lds_col_frag_tr_async([&](int r, int c) { return tn_addr(at, r, c); }, rA, rB, wa * 64 + i * 32);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    bfr[par][j] = lds_col_frag_tr_async([&](int r, int c) { return tn_addr(bt, r, c); }, rA, rB, wb * 64 + j * 32);
+            };
+            load(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                if (kk + 1 < BK / 16) { load(kk + 1, (kk + 1) & 1); wait_lgkmcnt<8>(); }
+                else wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bfr[kk & 1][j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const int rA = kk * 16 + fhi * 8, rB = rA + 4;
+                bf16x8_t af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    af[i] = lds_col_frag<false>([&](int r, int c) { return tn_addr(at, r, c); }, rA, rB, wa * 64 + i * 32);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bfr[j] = lds_col_frag<false>([&](int r, int c) { return tn_addr(bt, r, c); }, rA, rB, wb * 64 + j * 32);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
         }
-        __syncthreads();
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
     // accumulator: rows <-> n (A columns), cols <-> k (B columns); lane = k, regs = n
 #pragma unroll
@@ -311,21 +363,28 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
     }
 }
 
-template <int EPI, bool GROUPED>
-int launch_nt(const NTArgs& a0, int max_n, hipStream_t s) {
-    NTArgs a = a0;
-    constexpr int TW = 128, TX = 128;
+int g_nt_config = 1;   // 0: 128x128 tile, 4 waves, 2 stages;  1: 128(W) x 256(X) tile, 8 waves, 3 stages
+
+template <int TW, int TX, int WW, int WX, int STAGES, int EPI, bool GROUPED>
+int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (max_n + NPT - 1) / NPT;
     a.n_tiles_x = (a.M + TX - 1) / TX;
     const int grid = a.n_tiles_w * a.n_tiles_x;
-    const size_t lds = 2 * (TW + TX) * ROWB;
-    auto k = gemm_nt_kernel<TW, TX, 2, 2, EPI, GROUPED>;
+    const size_t lds = (size_t)STAGES * (TW + TX) * ROWB;
+    auto k = gemm_nt_kernel<TW, TX, WW, WX, STAGES, EPI, GROUPED>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(WW * WX * 64), lds, s, a);
     FM_CHECK_LAUNCH("fm_gemm_nt");
     return 0;
+}
+
+template <int EPI, bool GROUPED>
+int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
+    // grouped rows are segmented in 128-row tiles, so that path keeps the 128-row X tile
+    if (GROUPED || g_nt_config == 0 || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 3, EPI, GROUPED>(a, max_n, s);
+    return launch_nt_cfg<128, 256, 2, 4, 3, EPI, GROUPED>(a, max_n, s);
 }
 
 }  // namespace
@@ -368,6 +427,8 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     return -1;
 }
 
+extern "C" void fm_set_gemm_nt_config(int cfg) { g_nt_config = cfg; }
+extern "C" int fm_get_gemm_nt_config(void) { return g_nt_config; }
 static int g_tn_use_tr = 1;   // ds_read_b64_tr_b16 semantics verified on hardware (tools/probe_gfx950.hip)
 extern "C" void fm_set_tn_transpose_read(int on) { g_tn_use_tr = on; }
 extern "C" int fm_get_tn_transpose_read(void) { return g_tn_use_tr; }
@@ -396,12 +457,13 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
         if (splits < 1) splits = 1;
     }
     a.splits = splits;
-    const size_t lds = 2 * 2 * BK * TROWB;
+    constexpr int TN_STAGES = 3;
+    const size_t lds = (size_t)TN_STAGES * 2 * BK * TROWB;
     dim3 grid(a.n_tiles_a * a.n_tiles_b, splits, grouped ? p->n_groups : 1);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TN(TR, G)                                                                            \
     {                                                                                               \
-        auto k = gemm_tn_kernel<TR, G>;                                                             \
+        auto k = gemm_tn_kernel<TR, G, TN_STAGES>;                                                           \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true); \
         (void)once;                                                                                 \
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                          \
