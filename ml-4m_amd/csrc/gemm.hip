@@ -136,19 +136,24 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         if (kt + STAGES - 1 < KT) stage(kt + STAGES - 1, (buf + STAGES - 1) % STAGES);
         const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * ROWB;
         const char* xt = smem + buf * STAGE + TW * ROWB + (wx * (TX / WX) + frow) * ROWB;
+        // fragments of step kk+1 are read from LDS while the MFMAs of step kk execute
+        bf16x8_t wf[2][FW], xf[2][FX];
+        auto load_frags = [&](int kk, int par) {
+            const int off = ((kk * 2 + fhi) ^ fswz) * 16;
+#pragma unroll
+            for (int i = 0; i < FW; ++i) wf[par][i] = *(const bf16x8_t*)(wt + i * 32 * ROWB + off);
+#pragma unroll
+            for (int j = 0; j < FX; ++j) xf[par][j] = *(const bf16x8_t*)(xt + j * 32 * ROWB + off);
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            const int off = ((kk * 2 + fhi) ^ fswz) * 16;
-            bf16x8_t wf[FW], xf[FX];
-#pragma unroll
-            for (int i = 0; i < FW; ++i) wf[i] = *(const bf16x8_t*)(wt + i * 32 * ROWB + off);
-#pragma unroll
-            for (int j = 0; j < FX; ++j) xf[j] = *(const bf16x8_t*)(xt + j * 32 * ROWB + off);
+            if (kk + 1 < BK / 16) load_frags(kk + 1, (kk + 1) & 1);
 #pragma unroll
             for (int i = 0; i < FW; ++i)
 #pragma unroll
                 for (int j = 0; j < FX; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], xf[kk & 1][j], acc[i][j], 0, 0, 0);
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
@@ -230,21 +235,25 @@ struct TNArgs {
     int n_tiles_a, n_tiles_b;
 };
 
-constexpr int TROWB = 256;   // TN LDS tile row: 128 bf16 columns
-
+// element (row, col) of a row-major [64][cols] bf16 LDS tile with RB bytes per row; 16-byte chunks are
+// XOR-swizzled by (row & 3) << 2 so that the 4 rows a transpose read touches fall on different banks
+template <int RB>
 __device__ __forceinline__ const char* tn_addr(const char* tile, int row, int col) {
-    return tile + row * TROWB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
+    return tile + row * RB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
 }
 
-template <bool TR, bool GROUPED, int STAGES>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
-    constexpr int TA = 128, TB = 128, NWAVES = 4;
-    constexpr int LOADS = 2 * BK / (4 * NWAVES);              // LDS-DMA instructions per wave per stage
-    constexpr int STAGE = 2 * BK * TROWB;      // A tile + B tile, 64 reduction rows each
+template <bool TR, bool GROUPED, int TA, int TB, int WA, int WB, int STAGES>
+__global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
+    constexpr int NWAVES = WA * WB;
+    constexpr int RBA = TA * 2, RBB = TB * 2;                         // bytes per LDS tile row
+    constexpr int PA = BK * RBA / 1024, PB = BK * RBB / 1024;         // 1-KiB DMA pieces per tile
+    constexpr int LOADS = (PA + PB) / NWAVES;                         // LDS-DMA instructions per wave per stage
+    constexpr int STAGE = BK * (RBA + RBB);
+    static_assert(TA / WA == 64 && TB / WB == 64 && PA % NWAVES == 0 && PB % NWAVES == 0, "wave tile is 64x64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wa = wave >> 1, wb = wave & 1;
+    const int wa = wave / WB, wb = wave % WB;
 
     const int nwg = a.n_tiles_a * a.n_tiles_b;
     const int tile = xcd_remap(blockIdx.x, nwg);
@@ -269,15 +278,22 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
         char* base = smem + buf * STAGE;
         const int r0 = r_begin + t * BK;
 #pragma unroll
-        for (int p = 0; p < BK / (4 * NWAVES); ++p) {
-            const int row = p * 4 * NWAVES + wave * 4 + (lane >> 4);
-            const int lc = (lane & 15) ^ ((row & 3) << 2);
+        for (int p = 0; p < PA / NWAVES; ++p) {
+            constexpr int LPR = RBA / 16, RPP = 1024 / RBA;        // lanes per row, rows per piece
+            const int piece = p * NWAVES + wave;
+            const int row = piece * RPP + lane / LPR;
+            const int lc = (lane % LPR) ^ ((row & 3) << 2);
             int ca = n0 + lc * 8; ca = ca <= a.a_cols - 8 ? ca : a.a_cols - 8;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a.A + (size_t)(r0 + row) * a.lda + ca), LDS_PTR(base + piece * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < PB / NWAVES; ++p) {
+            constexpr int LPR = RBB / 16, RPP = 1024 / RBB;
+            const int piece = p * NWAVES + wave;
+            const int row = piece * RPP + lane / LPR;
+            const int lc = (lane % LPR) ^ ((row & 3) << 2);
             int cb = k0 + lc * 8; cb = cb <= a.b_cols - 8 ? cb : a.b_cols - 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a.A + (size_t)(r0 + row) * a.lda + ca),
-                                             LDS_PTR(base + (p * 4 * NWAVES + wave * 4) * TROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb),
-                                             LDS_PTR(base + BK * TROWB + (p * 4 * NWAVES + wave * 4) * TROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb), LDS_PTR(base + BK * RBA + piece * 1024), 16, 0, 0);
         }
     };
 
@@ -303,7 +319,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
         block_barrier();
         if (it + STAGES - 1 < NT_) stage(t_begin + it + STAGES - 1, (buf + STAGES - 1) % STAGES);
         const char* at = smem + buf * STAGE;
-        const char* bt = at + BK * TROWB;
+        const char* bt = at + BK * RBA;
         if constexpr (TR) {
             // fragments of step kk+1 are in flight while the MFMAs of step kk run (8 transpose reads per step)
             bf16x8_t af[2][2], bfr[2][2];
@@ -311,10 +327,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
                 const int rA = kk * 16 + fhi * 8, rB = rA + 4;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    af[par][i] = lds_col_frag_tr_async([&](int r, int c) { return tn_addr(at, r, c); }, rA, rB, wa * 64 + i * 32);
+                    af[par][i] = lds_col_frag_tr_async([&](int r, int c) { return tn_addr<RBA>(at, r, c); }, rA, rB, wa * 64 + i * 32);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    bfr[par][j] = lds_col_frag_tr_async([&](int r, int c) { return tn_addr(bt, r, c); }, rA, rB, wb * 64 + j * 32);
+                    bfr[par][j] = lds_col_frag_tr_async([&](int r, int c) { return tn_addr<RBB>(bt, r, c); }, rA, rB, wb * 64 + j * 32);
             };
             load(0, 0);
 #pragma unroll
@@ -335,10 +351,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
                 bf16x8_t af[2], bfr[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    af[i] = lds_col_frag<false>([&](int r, int c) { return tn_addr(at, r, c); }, rA, rB, wa * 64 + i * 32);
+                    af[i] = lds_col_frag<false>([&](int r, int c) { return tn_addr<RBA>(at, r, c); }, rA, rB, wa * 64 + i * 32);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    bfr[j] = lds_col_frag<false>([&](int r, int c) { return tn_addr(bt, r, c); }, rA, rB, wb * 64 + j * 32);
+                    bfr[j] = lds_col_frag<false>([&](int r, int c) { return tn_addr<RBB>(bt, r, c); }, rA, rB, wb * 64 + j * 32);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TNArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int k = k0 + wb * 64 + j * 32 + (lane & 31);
-        if (k >= a.K) continue;
+        if (k >= a.K) continue;   // (TB-wide tile: wb in [0, WB))
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -447,7 +463,8 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     FM_CHECK_ARG(a.a_cols >= 8 && a.b_cols >= 8, "fm_gemm_tn: operands need at least 8 readable columns");
     a.groups = p->groups; a.seg_start = p->seg_start; a.seg_count = p->seg_count;
     const int max_n = grouped ? p->max_N : p->N;
-    a.n_tiles_a = (max_n + 127) / 128; a.n_tiles_b = (p->K + 127) / 128;
+    constexpr int TN_TA = 128, TN_TB = 256, TN_STAGES = 3;
+    a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
     if (splits <= 0) {   // aim for >= 2 workgroups per CU
         const int tiles = a.n_tiles_a * a.n_tiles_b * (grouped ? p->n_groups : 1);
@@ -457,16 +474,15 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
         if (splits < 1) splits = 1;
     }
     a.splits = splits;
-    constexpr int TN_STAGES = 3;
-    const size_t lds = (size_t)TN_STAGES * 2 * BK * TROWB;
+    const size_t lds = (size_t)TN_STAGES * BK * (TN_TA + TN_TB) * 2;
     dim3 grid(a.n_tiles_a * a.n_tiles_b, splits, grouped ? p->n_groups : 1);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TN(TR, G)                                                                            \
     {                                                                                               \
-        auto k = gemm_tn_kernel<TR, G, TN_STAGES>;                                                           \
+        auto k = gemm_tn_kernel<TR, G, TN_TA, TN_TB, 2, 4, TN_STAGES>;                              \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true); \
         (void)once;                                                                                 \
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                          \
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a);                                          \
     }
     const int tr = p->force_tr >= 0 ? p->force_tr : g_tn_use_tr;
     if (tr) { if (grouped) LAUNCH_TN(true, true) else LAUNCH_TN(true, false) }
