@@ -8,7 +8,10 @@
 
 namespace {
 
-constexpr int MAXC = 8;   // float4 chunks per lane  ->  D <= 64 * 4 * 8 = 2048
+constexpr int MAXC_LIMIT = 8;   // float4 chunks per lane  ->  D <= 64 * 4 * 8 = 2048
+// The kernels are instantiated for 2 / 3 / 4 / 8 chunks per lane (D <= 512 / 768 / 1024 / 2048): the row
+// lives in registers, so a tight bound keeps the VGPR count low and the occupancy (= memory-level
+// parallelism of this HBM-bound kernel) high.
 
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
@@ -18,7 +21,7 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, f
     *(uint2*)p = make_uint2(pack2bf(a, b), pack2bf(c, d));
 }
 
-template <typename OutT>
+template <typename OutT, int MAXC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ b, OutT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
@@ -68,8 +71,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ;  dw += sum_r dy * xhat ;  db += sum_r dy
-constexpr int BWD_ROWS = 64;   // rows per workgroup (4 waves x 16)
+constexpr int BWD_ROWS = 32;   // rows per workgroup (4 waves x 8)
 
+template <int MAXC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const int* __restrict__ dy_row_map,
                                                      const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -147,19 +151,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 
 }  // namespace
 
+static int chunks_for(int D) { const int c = (D / 4 + 63) / 64; return c <= 2 ? 2 : c <= 3 ? 3 : c <= 4 ? 4 : 8; }
+
 extern "C" int fm_layernorm_fwd(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int y_is_f32,
                                 void* mean, void* rstd, const int32_t* row_map, int R, int D, float eps, void* stream) {
     FM_CHECK_ARG(x && w && y, "fm_layernorm_fwd: null pointer");
-    FM_CHECK_ARG(R > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC, "fm_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXC);
+    FM_CHECK_ARG(R > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC_LIMIT, "fm_layernorm_fwd: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXC_LIMIT);
     FM_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, "fm_layernorm_fwd: leading dims must be multiples of 4");
     int grid = (R + 3) / 4;
     if (grid > 256 * 16) grid = 256 * 16;
-    if (y_is_f32)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)w,
-                           (const float*)b, (float*)y, ldy, (float*)mean, (float*)rstd, row_map, R, D, eps);
-    else
-        hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)w,
-                           (const float*)b, (bf16_t*)y, ldy, (float*)mean, (float*)rstd, row_map, R, D, eps);
+#define LN_FWD(T, C)                                                                                                        \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, C>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)w, \
+                       (const float*)b, (T*)y, ldy, (float*)mean, (float*)rstd, row_map, R, D, eps)
+#define LN_FWD_C(T)                                    \
+    switch (chunks_for(D)) {                           \
+        case 2: LN_FWD(T, 2); break;                   \
+        case 3: LN_FWD(T, 3); break;                   \
+        case 4: LN_FWD(T, 4); break;                   \
+        default: LN_FWD(T, 8); break;                  \
+    }
+    if (y_is_f32) { LN_FWD_C(float) } else { LN_FWD_C(bf16_t) }
+#undef LN_FWD_C
+#undef LN_FWD
     FM_CHECK_LAUNCH("fm_layernorm_fwd");
     return 0;
 }
@@ -168,15 +181,26 @@ extern "C" int fm_layernorm_bwd(const void* dy, int lddy, const int32_t* dy_row_
                                 const void* mean, const void* rstd, const void* dres, void* dx, int lddx, void* dx_bf16,
                                 int lddxbf, void* dw, void* db, int R, int D, void* stream) {
     FM_CHECK_ARG(dy && x && w && mean && rstd && dx, "fm_layernorm_bwd: null pointer");
-    FM_CHECK_ARG(R > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC, "fm_layernorm_bwd: D=%d unsupported", D);
+    FM_CHECK_ARG(R > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC_LIMIT, "fm_layernorm_bwd: D=%d unsupported", D);
     FM_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddxbf % 4 == 0, "fm_layernorm_bwd: leading dims must be multiples of 4");
     const int grid = (R + BWD_ROWS - 1) / BWD_ROWS;
     const size_t lds = (size_t)8 * D * sizeof(float);
-    static bool once = (hipFuncSetAttribute((const void*)ln_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4) == hipSuccess);
-    (void)once;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, lddy, dy_row_map,
-                       (const float*)x, ldx, (const float*)w, (const float*)mean, (const float*)rstd, (const float*)dres, (float*)dx,
-                       lddx, (bf16_t*)dx_bf16, lddxbf, (float*)dw, (float*)db, R, D);
+#define LN_BWD(C)                                                                                                           \
+    {                                                                                                                       \
+        auto k = ln_bwd_kernel<C>;                                                                                          \
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4) == hipSuccess); \
+        (void)once;                                                                                                         \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, lddy, dy_row_map, (const float*)x, ldx, \
+                           (const float*)w, (const float*)mean, (const float*)rstd, (const float*)dres, (float*)dx, lddx,   \
+                           (bf16_t*)dx_bf16, lddxbf, (float*)dw, (float*)db, R, D);                                         \
+    }
+    switch (chunks_for(D)) {
+        case 2: LN_BWD(2) break;
+        case 3: LN_BWD(3) break;
+        case 4: LN_BWD(4) break;
+        default: LN_BWD(8) break;
+    }
+#undef LN_BWD
     FM_CHECK_LAUNCH("fm_layernorm_bwd");
     return 0;
 }
