@@ -33,7 +33,8 @@ enum fm_epilogue {
     FM_EPI_GELU = 1,     /* out(bf16)  = gelu(bf16(acc + bias)); out2(bf16, optional) = pre-activation */
     FM_EPI_RESIDUAL = 2, /* out(f32)   = res(f32) + bf16(acc + bias)      (out may alias res)         */
     FM_EPI_SWIGLU = 3,   /* W -> g, W2 -> u: out(bf16)[m][h] = silu(g)*u; out2(bf16)[m][h] = g, [m][Hp+h] = u */
-    FM_EPI_F32 = 4       /* out(f32)   = acc + bias                                                   */
+    FM_EPI_F32 = 4,      /* out(f32)   = acc + bias (+ res(f32) when given; no rounding)              */
+    FM_EPI_TANH = 5      /* out(bf16)  = tanh(bf16(acc + bias))                                       */
 };
 
 typedef struct fm_gemm_group {  /* one entry per row segment (modality) in grouped mode */
@@ -233,6 +234,21 @@ int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, floa
              float weight_decay, int64_t step, const void* grad_mult, void* stream);
 int fm_sumsq(const void* x, int64_t n, void* out, void* stream);                         /* out[0] += sum x^2 */
 int fm_clip_coef(const void* sumsq, float max_norm, void* norm_out, void* coef_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * VQ tokenizer front end (fourm/vq/vqvae.py:302-331)
+ * ---------------------------------------------------------------------------------------------- */
+/* out[(b*G + g)][c*P*P + py*P + px] (bf16, row stride ld_out, pad zero) <- img (B, C, H, W) f32: the operand
+ * of the patch-projection GEMM that replaces Conv2d(k = s = P)  (vq/models/vit_models.py:402-405,482) */
+int fm_vq_patchify(const void* img, void* out, int ld_out, int B, int C, int H, int W, int P, void* stream);
+int fm_l2norm_rows(const void* x, int ldx, void* y, int ldy, int R, int D, void* stream);   /* F.normalize(p=2, dim=-1) */
+/* Cosine-similarity nearest code (quantize_lucid.py:394-407): tokens[r] = argmax_c <zn[r], En[c]> with the
+ * first maximum winning; quant (optional, f32 (B, D, tokens_per_image)) = embed[tokens].  z: f32 (R, ldz),
+ * l2-normalised in-kernel when normalize_latents; codes_normalized / embed: f32 (K, D).  D == 32.
+ * ws_val / ws_idx: (R, splits) f32 / int32 scratch. */
+int fm_vq_assign(const void* z, int ldz, const void* codes_normalized, const void* embed, int K, int D, int R,
+                 int tokens_per_image, int normalize_latents, void* ws_val, void* ws_idx, int splits, int64_t* tokens,
+                 void* quant, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ constexpr int BK = 64;           // reduction elements per LDS stage
 constexpr int ROWB = BK * 2;     // bytes per LDS tile row (NT tiles)
 
 enum { EPI_BF16 = FM_EPI_BF16, EPI_GELU = FM_EPI_GELU, EPI_RES = FM_EPI_RESIDUAL, EPI_SWIGLU = FM_EPI_SWIGLU,
-       EPI_F32 = FM_EPI_F32 };
+       EPI_F32 = FM_EPI_F32, EPI_TANH = FM_EPI_TANH };
 
 struct NTArgs {
     const bf16_t* W; const bf16_t* W2; const bf16_t* X;
@@ -212,11 +212,19 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_f(bfround(v[e]));
                         *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    } else if constexpr (EPI == EPI_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = tanhf(bfround(v[e]));
+                        *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                     } else if constexpr (EPI == EPI_RES) {
                         const float4 r = *(const float4*)(a.res + (size_t)m * a.ldr + n);
                         float4 o = make_float4(r.x + bfround(v[0]), r.y + bfround(v[1]), r.z + bfround(v[2]), r.w + bfround(v[3]));
                         *(float4*)((float*)a.out + (size_t)m * a.ldo + n) = o;
-                    } else {  // EPI_F32
+                    } else {  // EPI_F32 (optionally + res, no rounding)
+                        if (a.res) {
+                            const float4 r = *(const float4*)(a.res + (size_t)m * a.ldr + n);
+                            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                        }
                         *(float4*)((float*)a.out + (size_t)m * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
@@ -438,6 +446,7 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
             FM_CHECK_ARG(p->W2 && p->out2 && p->Hp % 4 == 0 && p->ldo2 % 4 == 0, "fm_gemm_nt: SwiGLU epilogue needs W2, out2, Hp%%4==0");
             return launch_nt<EPI_SWIGLU, false>(a, max_n, s);
         case FM_EPI_F32: return launch_nt<EPI_F32, false>(a, max_n, s);
+        case FM_EPI_TANH: return launch_nt<EPI_TANH, false>(a, max_n, s);
     }
     fm_set_error("fm_gemm_nt: unknown epilogue %d", p->epilogue);
     return -1;

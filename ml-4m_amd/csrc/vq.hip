@@ -1,0 +1,146 @@
+// VQ tokenizer front end: conv-style patch gather and the cosine-similarity codebook search.
+//
+// fourm/vq/models/vit_models.py:402-405,482 (Conv2d(k=s=patch) == GEMM over (c, py, px)-ordered patches)
+// fourm/vq/quantizers/quantize_lucid.py:388-407 (l2norm latents and codes, dist = z @ E^T, argmax with
+// first-index tie break, quantize = embed[ind]).  Upstream materialises the (B*196, 16384) distance matrix
+// (and a one-hot of the same size); here a lane owns one latent row and scans the codebook from LDS with a
+// running arg-max: nothing of size rows x codes ever exists.  HBM/LDS-bound fp32 work (exact f32 FMAs in a
+// fixed order: code assignment is bit-reproducible).
+#include "common.h"
+#include "fourm_hip.h"
+
+namespace {
+
+// out[(b*G + g)][c*P*P + py*P + px] = img[b][c][gy*P + py][gx*P + px]     (bf16, pad columns zero)
+__global__ __launch_bounds__(256) void vq_patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int ldo, int B, int C,
+                                                          int H, int W, int P) {
+    const int gw = W / P, gh = H / P, F = C * P * P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < B * gh * gw; r += gridDim.x * 4) {
+        const int b = r / (gh * gw), g = r % (gh * gw), gy = g / gw, gx = g % gw;
+        const float* base = img + (size_t)b * C * H * W;
+        for (int f = lane; f < ldo; f += 64) {
+            float v = 0.f;
+            if (f < F) {
+                const int c = f / (P * P), py = (f / P) % P, px = f % P;
+                v = base[((size_t)c * H + gy * P + py) * W + gx * P + px];
+            }
+            out[(size_t)r * ldo + f] = f2bf(v);
+        }
+    }
+}
+
+// rows / max(||row||, 1e-12)   (F.normalize, p = 2)
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y, int ldy, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) { const float v = x[(size_t)r * ldx + d]; s += v * v; }
+        s = wave_sum(s);
+        const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+        for (int d = lane; d < D; d += 64) y[(size_t)r * ldy + d] = x[(size_t)r * ldx + d] * inv;
+    }
+}
+
+constexpr int VQ_D = 32;          // latent dimension handled by the register-resident search
+constexpr int VQ_CHUNK = 256;     // codes staged in LDS at a time (32 KB)
+
+// grid (ceil(R/256), splits): thread = latent row, codes [split*K/splits, ...) scanned in ascending order
+__global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ En, int K,
+                                                        int R, int codes_per_split, float* __restrict__ best_val, int* __restrict__ best_idx,
+                                                        int normalize_latents) {
+    __shared__ __attribute__((aligned(16))) float code[VQ_CHUNK * VQ_D];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int rc = r < R ? r : R - 1;
+    float zr[VQ_D];
+    float ss = 0.f;
+#pragma unroll
+    for (int d = 0; d < VQ_D; d += 4) {
+        const float4 v = *(const float4*)(z + (size_t)rc * ldz + d);
+        zr[d] = v.x; zr[d + 1] = v.y; zr[d + 2] = v.z; zr[d + 3] = v.w;
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (normalize_latents) {
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int d = 0; d < VQ_D; ++d) zr[d] *= inv;
+    }
+    const int c_begin = blockIdx.y * codes_per_split, c_end = min(K, c_begin + codes_per_split);
+    float bv = -INFINITY;
+    int bi = c_begin;
+    for (int c0 = c_begin; c0 < c_end; c0 += VQ_CHUNK) {
+        const int n = min(VQ_CHUNK, c_end - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n * VQ_D / 4; i += 256) *(float4*)(code + i * 4) = *(const float4*)(En + (size_t)c0 * VQ_D + i * 4);
+        __syncthreads();
+        for (int c = 0; c < n; ++c) {
+            const float* e = code + c * VQ_D;          // same address in every lane: LDS broadcast
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < VQ_D; ++d) acc = fmaf(zr[d], e[d], acc);
+            if (acc > bv) { bv = acc; bi = c0 + c; }   // strict: the first maximum wins (torch.argmax)
+        }
+    }
+    if (r < R) {
+        best_val[(size_t)r * gridDim.y + blockIdx.y] = bv;
+        best_idx[(size_t)r * gridDim.y + blockIdx.y] = bi;
+    }
+}
+
+// merge the per-split winners (ascending split order keeps the first-index tie break), emit the
+// token and the quantised vector embed[token] in (B, D, h, w) layout
+__global__ __launch_bounds__(256) void vq_merge_kernel(const float* __restrict__ best_val, const int* __restrict__ best_idx, int splits,
+                                                       const float* __restrict__ embed, long long* __restrict__ tokens,
+                                                       float* __restrict__ quant, int R, int D, int tokens_per_image) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= R) return;
+    float bv = best_val[(size_t)r * splits];
+    int bi = best_idx[(size_t)r * splits];
+    for (int s = 1; s < splits; ++s) {
+        const float v = best_val[(size_t)r * splits + s];
+        if (v > bv) { bv = v; bi = best_idx[(size_t)r * splits + s]; }
+    }
+    tokens[r] = bi;
+    if (quant) {
+        const int b = r / tokens_per_image, t = r % tokens_per_image;
+        for (int d = 0; d < D; ++d) quant[((size_t)b * D + d) * tokens_per_image + t] = embed[(size_t)bi * D + d];
+    }
+}
+
+// y = x + bf16->f32(t)   helpers for the fp32 tail are covered by the GEMM epilogues; nothing else here
+
+}  // namespace
+
+extern "C" int fm_vq_patchify(const void* img, void* out, int ld_out, int B, int C, int H, int W, int P, void* stream) {
+    FM_CHECK_ARG(img && out && B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0 && ld_out >= C * P * P, "fm_vq_patchify: bad argument");
+    int grid = (B * (H / P) * (W / P) + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(vq_patchify_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)img, (bf16_t*)out, ld_out, B, C, H, W, P);
+    FM_CHECK_LAUNCH("fm_vq_patchify");
+    return 0;
+}
+
+extern "C" int fm_l2norm_rows(const void* x, int ldx, void* y, int ldy, int R, int D, void* stream) {
+    FM_CHECK_ARG(x && y && R > 0 && D > 0, "fm_l2norm_rows: bad argument");
+    int grid = (R + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, R, D);
+    FM_CHECK_LAUNCH("fm_l2norm_rows");
+    return 0;
+}
+
+extern "C" int fm_vq_assign(const void* z, int ldz, const void* codes_normalized, const void* embed, int K, int D, int R,
+                            int tokens_per_image, int normalize_latents, void* ws_val, void* ws_idx, int splits, int64_t* tokens,
+                            void* quant, void* stream) {
+    FM_CHECK_ARG(z && codes_normalized && embed && ws_val && ws_idx && tokens, "fm_vq_assign: null pointer");
+    FM_CHECK_ARG(D == VQ_D, "fm_vq_assign: latent_dim=%d unsupported (this build handles %d)", D, VQ_D);
+    FM_CHECK_ARG(K > 0 && R > 0 && splits > 0 && splits <= 64 && ldz % 4 == 0 && tokens_per_image > 0, "fm_vq_assign: bad shape");
+    const int per = ((K + splits - 1) / splits + 3) / 4 * 4;
+    dim3 grid((R + 255) / 256, splits);
+    hipLaunchKernelGGL(vq_search_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)z, ldz, (const float*)codes_normalized, K, R, per,
+                       (float*)ws_val, (int*)ws_idx, normalize_latents);
+    hipLaunchKernelGGL(vq_merge_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws_val, (const int*)ws_idx, splits,
+                       (const float*)embed, (long long*)tokens, (float*)quant, R, D, tokens_per_image);
+    FM_CHECK_LAUNCH("fm_vq_assign");
+    return 0;
+}

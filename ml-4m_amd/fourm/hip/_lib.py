@@ -33,7 +33,7 @@ if lib.fm_abi_version() != ABI_VERSION:
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # enums (keep in sync with the header; tests/test_abi.py cross-checks them against the header text)
-EPI_BF16, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32 = 0, 1, 2, 3, 4
+EPI_BF16, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32, EPI_TANH = 0, 1, 2, 3, 4, 5
 MASK_NONE, MASK_KEYPAD, MASK_DECODER, MASK_DENSE = 0, 1, 2, 3
 KIND_TOK, KIND_PATCH, KIND_SEQ, KIND_SEQ_EMB = 0, 1, 2, 3
 LOSS_MOD, LOSS_TOKEN = 0, 1
@@ -122,6 +122,9 @@ f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
 adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp)
 sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
 clip_coef = _sig("fm_clip_coef", vp, f32, vp, vp, vp)
+vq_patchify = _sig("fm_vq_patchify", vp, vp, i32, i32, i32, i32, i32, i32, vp)
+l2norm_rows = _sig("fm_l2norm_rows", vp, i32, vp, i32, i32, i32, vp)
+vq_assign = _sig("fm_vq_assign", vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp)
 lib.fm_set_tn_transpose_read.argtypes = [C.c_int]
 lib.fm_set_attn_transpose_read.argtypes = [C.c_int]
 
@@ -131,7 +134,7 @@ EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_conf
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
            "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_colsum", "fm_f32_to_bf16", "fm_adamw",
-           "fm_sumsq", "fm_clip_coef"]
+           "fm_sumsq", "fm_clip_coef", "fm_vq_patchify", "fm_l2norm_rows", "fm_vq_assign"]
 
 
 def check(rc: int):

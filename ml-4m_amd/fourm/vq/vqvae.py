@@ -1,0 +1,98 @@
+"""``VQ``: tokenizer front half (image -> ViT encoder -> 1x1 projection -> nearest code), API of upstream
+``fourm/vq/vqvae.py`` (``VQ`` :39-331: constructor arguments, ``encode`` / ``tokenize`` / ``tokens_to_embedding``,
+state_dict keys).  Inference only; decoders, diffusion and tokenizer training are out of scope.
+
+Precision: the ViT runs with bf16 GEMM operands (fp32 accumulate, fp32 residual / LayerNorm / softmax),
+the codebook search in exact fp32.  Upstream's tokenization script runs everything in fp32; code
+assignment given identical latents is bit-identical (tests), end-to-end token agreement is reported by
+the tests against the fp32 oracle."""
+import copy
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from .models import vit_models
+from .quantizers import VectorQuantizerLucid
+
+try:
+    from huggingface_hub import PyTorchModelHubMixin
+except Exception:  # pragma: no cover
+    class PyTorchModelHubMixin:  # type: ignore
+        pass
+
+
+class VQ(nn.Module, PyTorchModelHubMixin):
+    def __init__(self, image_size: int = 224, image_size_enc: Optional[int] = None, n_channels: str = 3, n_labels: Optional[int] = None,
+                 enc_type: str = "vit_b_enc", patch_proj: bool = True, post_mlp: bool = False, patch_size: int = 16, quant_type: str = "lucid",
+                 codebook_size: Union[int, str] = 16384, num_codebooks: int = 1, latent_dim: int = 32, norm_codes: bool = True,
+                 norm_latents: bool = False, sync_codebook: bool = True, ema_decay: float = 0.99, threshold_ema_dead_code: float = 0.25,
+                 code_replacement_policy: str = "batch_random", commitment_weight: float = 1.0, kmeans_init: bool = False,
+                 ckpt_path: Optional[str] = None,
+                 ignore_keys: List[str] = ["decoder", "loss", "post_quant_conv", "post_quant_proj", "encoder.pos_emb"],
+                 freeze_enc: bool = False, undo_std: bool = False, config: Optional[Dict[str, Any]] = None, **kwargs):
+        if config is not None:
+            self.__init__(**copy.deepcopy(config))
+            return
+        super().__init__()
+        if n_labels is not None:
+            raise NotImplementedError("semantic-segmentation class embeddings (n_labels) are not implemented")
+        if undo_std:
+            raise NotImplementedError("undo_std=True is not implemented (normalise to [-1, 1] in the loader)")
+        if quant_type != "lucid":
+            raise NotImplementedError(f"quant_type {quant_type!r} has no HIP kernel")
+        if "vit" not in enc_type or not hasattr(vit_models, enc_type):
+            raise NotImplementedError(f"{enc_type} not implemented.")
+        for k, v in dict(image_size=image_size, n_channels=n_channels, n_labels=n_labels, enc_type=enc_type, patch_proj=patch_proj,
+                         post_mlp=post_mlp, patch_size=patch_size, quant_type=quant_type, codebook_size=codebook_size,
+                         num_codebooks=num_codebooks, latent_dim=latent_dim, norm_codes=norm_codes, norm_latents=norm_latents,
+                         sync_codebook=sync_codebook, ema_decay=ema_decay, threshold_ema_dead_code=threshold_ema_dead_code,
+                         code_replacement_policy=code_replacement_policy, commitment_weight=commitment_weight, kmeans_init=kmeans_init,
+                         ckpt_path=ckpt_path, ignore_keys=ignore_keys, freeze_enc=freeze_enc, undo_std=undo_std).items():
+            setattr(self, k, v)
+        self.cls_emb = None
+        self.encoder = getattr(vit_models, enc_type)(in_channels=n_channels, patch_size=patch_size, resolution=image_size_enc or image_size,
+                                                     patch_proj=patch_proj, post_mlp=post_mlp)
+        self.enc_dim = self.encoder.dim_tokens
+        self.quant_proj = torch.nn.Conv2d(self.enc_dim, self.latent_dim, 1)
+        self.quantize = VectorQuantizerLucid(dim=latent_dim, codebook_size=codebook_size, codebook_dim=latent_dim, heads=num_codebooks,
+                                             use_cosine_sim=norm_codes, threshold_ema_dead_code=threshold_ema_dead_code,
+                                             code_replacement_policy=code_replacement_policy, sync_codebook=sync_codebook, decay=ema_decay,
+                                             commitment_weight=commitment_weight, norm_latents=norm_latents, kmeans_init=kmeans_init)
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)
+        if freeze_enc:
+            for name in ("encoder", "quant_proj", "quantize", "cls_emb"):
+                mod = getattr(self, name, None)
+                if mod is not None:
+                    for p in mod.parameters():
+                        p.requires_grad = False
+
+    def init_from_ckpt(self, path: str, ignore_keys: List[str] = list()) -> "VQ":
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        sd = ckpt["model"] if "model" in ckpt else ckpt["state_dict"]
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                del sd[k]
+        print(self.load_state_dict(sd, strict=False))
+        return self
+
+    def prepare_input(self, x: torch.Tensor) -> torch.Tensor:
+        return x
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.LongTensor]:
+        """(quant (B, latent_dim, h, w) f32, code_loss (1,) zeros, tokens (B, h, w) int64)   [vqvae.py:302-318]"""
+        from .engine import vq_encode
+        if self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("VQ training (EMA codebook updates, commitment loss) is out of scope; call .eval()")
+        return vq_encode(self, self.prepare_input(x))
+
+    def tokenize(self, x: torch.Tensor) -> torch.LongTensor:
+        return self.encode(x)[2]
+
+    def tokens_to_embedding(self, tokens: torch.LongTensor) -> torch.Tensor:
+        return self.quantize.indices_to_embedding(tokens)
+
+    def forward(self, x: torch.Tensor):
+        return self.encode(x)

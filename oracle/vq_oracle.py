@@ -1,0 +1,120 @@
+"""CPU oracle for the VQ tokenizer front end (image -> codes).  TEST INFRASTRUCTURE ONLY (see
+fourm_oracle.py for the rules).  Functional fp32 PyTorch restatement of
+
+    VQ.encode ................ fourm/vq/vqvae.py:302-318
+    ViTEncoder.forward ....... fourm/vq/models/vit_models.py:465-501 (+ Attention :177-197, Mlp :155-162, Block :243-246)
+    VectorQuantize.forward ... fourm/vq/quantizers/quantize_lucid.py:504-568 (eval branch)
+    CosineSimCodebook.forward  fourm/vq/quantizers/quantize_lucid.py:388-407
+
+Parity status: PINNED by tests/golden/make_golden_vq.py against the unmodified upstream ``VQ`` (same seeded
+weights and images): tokens identical, latents to 1e-5."""
+import math
+from dataclasses import dataclass
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from .fourm_oracle import _Num, seeded_tensor, sincos_2d
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class VQCfg:
+    image: int = 224
+    patch: int = 16
+    channels: int = 3
+    dim: int = 768
+    depth: int = 12
+    heads: int = 12
+    mlp_ratio: float = 4.0
+    post_mlp: bool = True
+    codebook: int = 16384
+    latent: int = 32
+    eps: float = 1e-6
+
+    @property
+    def grid(self):
+        return self.image // self.patch
+
+
+def vq_cfg(enc_type: str, **kw) -> VQCfg:
+    dim, depth, heads = {"vit_s_enc": (512, 8, 8), "vit_b_enc": (768, 12, 12), "vit_l_enc": (1024, 24, 16)}[enc_type]
+    return VQCfg(dim=dim, depth=depth, heads=heads, **kw)
+
+
+def seeded_vq_state_dict(cfg: VQCfg, seed: int = 0) -> Dict[str, Tensor]:
+    D, Hd, g = cfg.dim, int(cfg.dim * cfg.mlp_ratio), cfg.grid
+    sd: Dict[str, Tensor] = {}
+
+    def lin(pre, o, i):
+        sd[pre + ".weight"] = seeded_tensor(pre + ".weight", (o, i), 1.0 / math.sqrt(i), seed)
+        sd[pre + ".bias"] = seeded_tensor(pre + ".bias", (o,), 0.02, seed)
+
+    def norm(pre):
+        sd[pre + ".weight"] = 1.0 + seeded_tensor(pre + ".weight", (D,), 0.1, seed)
+        sd[pre + ".bias"] = seeded_tensor(pre + ".bias", (D,), 0.05, seed)
+    sd["encoder.pos_emb"] = sincos_2d(g, g, D).reshape(g, g, D).permute(2, 0, 1)[None].contiguous()
+    f = cfg.channels * cfg.patch * cfg.patch
+    sd["encoder.proj.weight"] = seeded_tensor("encoder.proj.weight", (D, cfg.channels, cfg.patch, cfg.patch), 1.0 / math.sqrt(f), seed)
+    sd["encoder.proj.bias"] = seeded_tensor("encoder.proj.bias", (D,), 0.02, seed)
+    for i in range(cfg.depth):
+        p = f"encoder.blocks.{i}"
+        norm(p + ".norm1"); norm(p + ".norm2")
+        lin(p + ".attn.qkv", 3 * D, D); lin(p + ".attn.proj", D, D)
+        lin(p + ".mlp.fc1", Hd, D); lin(p + ".mlp.fc2", D, Hd)
+    if cfg.post_mlp:
+        norm("encoder.norm_mlp")
+        lin("encoder.post_mlp.fc1", Hd, D); lin("encoder.post_mlp.fc2", D, Hd)
+    sd["quant_proj.weight"] = seeded_tensor("quant_proj.weight", (cfg.latent, D, 1, 1), 1.0 / math.sqrt(D), seed)
+    sd["quant_proj.bias"] = seeded_tensor("quant_proj.bias", (cfg.latent,), 0.02, seed)
+    sd["quantize._codebook.initted"] = torch.Tensor([True])
+    sd["quantize._codebook.cluster_size"] = torch.zeros(cfg.codebook)
+    sd["quantize._codebook.embed"] = F.normalize(seeded_tensor("quantize._codebook.embed", (cfg.codebook, cfg.latent), 1.0, seed), dim=-1)
+    return sd
+
+
+def synthetic_images(cfg: VQCfg, batch: int, seed: int = 0) -> Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(batch, cfg.channels, cfg.image, cfg.image, generator=g) * 2 - 1
+
+
+def vq_encode(P: Dict[str, Tensor], cfg: VQCfg, x: Tensor, emulate_bf16: bool = False, emulate_tail: bool = False):
+    """Returns (quant (B, L, h, w), tokens (B, h, w) int64, latents z (B, h*w, L) before normalisation).
+    ``emulate_bf16`` rounds at the autocast points of the 12 blocks and the patch projection (the HIP
+    pipeline); ``emulate_tail`` also rounds the operands of the post-MLP and the 1x1 projection."""
+    num, tail = _Num(emulate_bf16), _Num(emulate_bf16 and emulate_tail)
+    B, C, H, W = x.shape
+    p, g = cfg.patch, H // cfg.patch
+    # Conv2d(k = s = p): patches ordered (c, py, px) against weight.view(D, -1)
+    patches = x.reshape(B, C, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * p * p)
+    t = num.linear(patches, P["encoder.proj.weight"].reshape(cfg.dim, -1), P["encoder.proj.bias"])
+    t = t + P["encoder.pos_emb"][0].permute(1, 2, 0).reshape(g * g, cfg.dim)
+    hd = cfg.dim // cfg.heads
+    for i in range(cfg.depth):
+        pre = f"encoder.blocks.{i}"
+        h = num.layer_norm(t, P[pre + ".norm1.weight"], P[pre + ".norm1.bias"], cfg.eps)
+        qkv = num.linear(h, P[pre + ".attn.qkv.weight"], P[pre + ".attn.qkv.bias"])
+        q, k, v = [a.reshape(B, -1, cfg.heads, hd).transpose(1, 2) for a in qkv.chunk(3, -1)]
+        s = num.r(num.r(num.r(q) @ num.r(k).transpose(-1, -2)) * hd ** -0.5)
+        o = num.r(num.r(torch.softmax(s, -1)) @ num.r(v)).transpose(1, 2).reshape(B, -1, cfg.dim)
+        t = t + num.linear(o, P[pre + ".attn.proj.weight"], P[pre + ".attn.proj.bias"])
+        h = num.layer_norm(t, P[pre + ".norm2.weight"], P[pre + ".norm2.bias"], cfg.eps)
+        h = num.act(num.linear(h, P[pre + ".mlp.fc1.weight"], P[pre + ".mlp.fc1.bias"]), "gelu")
+        t = t + num.linear(h, P[pre + ".mlp.fc2.weight"], P[pre + ".mlp.fc2.bias"])
+    if cfg.post_mlp:
+        h = tail.layer_norm(t, P["encoder.norm_mlp.weight"], P["encoder.norm_mlp.bias"], cfg.eps)
+        h = tail.r(torch.tanh(tail.linear(h, P["encoder.post_mlp.fc1.weight"], P["encoder.post_mlp.fc1.bias"])))
+        t = t + tail.linear(h, P["encoder.post_mlp.fc2.weight"], P["encoder.post_mlp.fc2.bias"])
+    wq = P["quant_proj.weight"].reshape(cfg.latent, cfg.dim)
+    z = tail.r(t) @ tail.r(wq).t() + P["quant_proj.bias"]
+    tokens, quant = assign_codes(z, P["quantize._codebook.embed"])
+    return quant.reshape(B, g, g, cfg.latent).permute(0, 3, 1, 2), tokens.reshape(B, g, g), z
+
+
+def assign_codes(z: Tensor, embed: Tensor):
+    """Nearest code by cosine similarity, first index on ties; quantised vector = the raw codebook row."""
+    zn, en = F.normalize(z.float(), dim=-1), F.normalize(embed, dim=-1)
+    ind = (zn @ en.t()).argmax(-1)
+    return ind, embed[ind]

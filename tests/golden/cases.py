@@ -51,3 +51,10 @@ def build_case(name: str):
     md = O.synthetic_mod_dict(cfg, c["B"], c["bud"][0], c["bud"][1], seed=seed, no_target=c.get("no_target", ()))
     return dict(cfg=cfg, sd=sd, mod_dict=md, N=c["N"], M=c["M"], loss_type=c.get("loss_type", "mod"),
                 order_seed=seed, share_embedding=share, norm_bias=nb, learned_pos=learned)
+
+
+# VQ tokenizer front end (BASELINE.json configs[4] and a small variant)
+VQ_CASES = {
+    "vq_small": dict(enc_type="vit_s_enc", image=64, patch=16, codebook=512, post_mlp=True, batch=3, seed=2),
+    "vq_rgb224": dict(enc_type="vit_b_enc", image=224, patch=16, codebook=16384, post_mlp=True, batch=2, seed=0),
+}
