@@ -475,12 +475,25 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     constexpr int TN_TA = 128, TN_TB = 256, TN_STAGES = 3;
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
-    if (splits <= 0) {   // aim for >= 2 workgroups per CU
+    if (splits <= 0) {
+        // One workgroup per CU (144 KB of LDS): pick the split count whose workgroup total fills whole
+        // rounds of the 256 CUs best; ties go to fewer splits (each split is one more atomic pass over dW).
         const int tiles = a.n_tiles_a * a.n_tiles_b * (grouped ? p->n_groups : 1);
         const int nt = grouped ? (p->max_R + BK - 1) / BK : p->R / BK;
-        splits = (512 + tiles - 1) / tiles;
-        if (splits > nt) splits = nt;
-        if (splits < 1) splits = 1;
+        double best = -1.0;
+        splits = 1;
+        for (int sgl = 1; sgl <= 64 && sgl <= nt; ++sgl) {
+            if (nt / sgl < 4 && sgl > 1) break;                         // keep the rings busy
+            const int wgs = tiles * sgl, rounds = (wgs + 255) / 256;
+            const double fill = (double)wgs / (rounds * 256.0);
+            const double score = fill - 0.002 * sgl - (rounds > 1 ? 0.0 : 0.0);
+            if (wgs >= 128 && score > best + 1e-9) { best = score; splits = sgl; }
+        }
+        if (best < 0) {                                                // tiny problems: just expose parallelism
+            splits = (256 + tiles - 1) / tiles;
+            if (splits > nt) splits = nt;
+            if (splits < 1) splits = 1;
+        }
     }
     a.splits = splits;
     const size_t lds = (size_t)TN_STAGES * BK * (TN_TA + TN_TB) * 2;
