@@ -20,7 +20,6 @@
 namespace {
 
 constexpr int BK = 64;           // reduction elements per LDS stage
-constexpr int ROWB = BK * 2;     // bytes per LDS tile row (NT tiles)
 
 enum { EPI_BF16 = FM_EPI_BF16, EPI_GELU = FM_EPI_GELU, EPI_RES = FM_EPI_RESIDUAL, EPI_SWIGLU = FM_EPI_SWIGLU,
        EPI_F32 = FM_EPI_F32, EPI_TANH = FM_EPI_TANH };
@@ -49,12 +48,20 @@ __device__ __forceinline__ void block_barrier() {
 
 // STAGES-deep LDS ring: the DMA of K-tile t+STAGES-1 is issued while tile t is being multiplied; waits are
 // counted (never a full drain inside the loop) and there is one workgroup barrier per K-tile.
-template <int TW, int TX, int WW, int WX, int STAGES, int EPI, bool GROUPED>
+// KB = reduction elements per stage (64 or 32): LDS rows are KB*2 bytes, 16-byte chunks XOR-swizzled so that
+// the 16 rows a ds_read_b128 lane group touches fall on 16 different 16-byte bank slots.
+template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED>
 __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     constexpr int NWAVES = WW * WX;
-    constexpr int LOADS = (TW + TX) / (8 * NWAVES);           // LDS-DMA instructions per wave per stage
-    constexpr int FW = TW / WW / 32, FX = TX / WX / 32;      // 32x32 fragments per wave
-    constexpr int STAGE = (TW + TX) * ROWB;
+    constexpr int RB = KB * 2;                                 // bytes per LDS row
+    constexpr int CPR = RB / 16;                               // 16-byte chunks per row (8 or 4)
+    constexpr int RPP = 1024 / RB;                             // rows per 1-KiB DMA piece (8 or 16)
+    constexpr int SWSH = (RB == 128) ? 1 : 2;                  // rows per 256-byte bank row = 1 << SWSH
+    constexpr int LOADS = (TW + TX) / (RPP * NWAVES);          // LDS-DMA instructions per wave per stage
+    constexpr int FW = TW / WW / 32, FX = TX / WX / 32;        // 32x32 fragments per wave
+    constexpr int STAGE = (TW + TX) * RB;
+    static_assert(TW % (RPP * NWAVES) == 0 && TX % (RPP * NWAVES) == 0, "tile rows must split evenly over the DMA pieces");
+    static_assert(EPI != EPI_SWIGLU || FW % 2 == 0, "SwiGLU needs (g,u) fragment pairs per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -76,16 +83,17 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     const int n0 = tw * NPT, m0 = tx * TX;
     if (n0 >= N) return;
 
-    // ---- staging: each wave-instruction moves 8 rows x 128 B ---------------------------------
+    // ---- staging: each wave-instruction moves RPP rows x RB bytes ------------------------------
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * STAGE;
-        const int k0 = kt * BK;
+        const int k0 = kt * KB;
 #pragma unroll
-        for (int p = 0; p < TW / (8 * NWAVES); ++p) {
-            const int t = p * 8 * NWAVES + wave * 8 + (lane >> 3);
-            const int lc = (lane & 7) ^ ((t >> 1) & 7);
+        for (int p = 0; p < TW / (RPP * NWAVES); ++p) {
+            const int t = (p * NWAVES + wave) * RPP + lane / CPR;
+            const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
             const bf16_t* src;
             if constexpr (EPI == EPI_SWIGLU) {
+                // rows [0,32) of every 64-row group come from W (g), rows [32,64) from W2 (u), same hidden units
                 int n = n0 + (t >> 6) * 32 + (t & 31);
                 n = n < N ? n : N - 1;
                 src = (((t >> 5) & 1) ? a.W2 : Wp) + (size_t)n * ldw + k0 + lc * 8;
@@ -94,16 +102,16 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                 n = n < N ? n : N - 1;
                 src = Wp + (size_t)n * ldw + k0 + lc * 8;
             }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + (p * 8 * NWAVES + wave * 8) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + (p * NWAVES + wave) * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int p = 0; p < TX / (8 * NWAVES); ++p) {
-            const int t = p * 8 * NWAVES + wave * 8 + (lane >> 3);
-            const int lc = (lane & 7) ^ ((t >> 1) & 7);
+        for (int p = 0; p < TX / (RPP * NWAVES); ++p) {
+            const int t = (p * NWAVES + wave) * RPP + lane / CPR;
+            const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
             int m = m0 + t;
             m = m < a.M ? m : a.M - 1;
             const bf16_t* src = a.X + (size_t)m * a.ldx + k0 + lc * 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + TW * ROWB + (p * 8 * NWAVES + wave * 8) * ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + TW * RB + (p * NWAVES + wave) * 1024), 16, 0, 0);
         }
     };
 
@@ -115,14 +123,14 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT = K / BK;
+    const int KT = K / KB;
 #pragma unroll
     for (int p = 0; p < STAGES - 1; ++p)
         if (p < KT) stage(p, p);
 
     // per-lane constants of the fragment reads
-    const int frow = lane & 31;                 // row inside a 32-row fragment
-    const int fswz = (frow >> 1) & 7;           // swizzle key (fragment bases are multiples of 32)
+    const int frow = lane & 31;                          // row inside a 32-row fragment
+    const int fswz = (frow >> SWSH) & (CPR - 1);         // swizzle key (fragment bases are multiples of 32)
     const int fhi = lane >> 5;
 
     int buf = 0;
@@ -134,21 +142,21 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         else wait_vmcnt<0>();
         block_barrier();      // everyone's pieces of tile kt are in LDS; everyone is done reading tile kt-1
         if (kt + STAGES - 1 < KT) stage(kt + STAGES - 1, (buf + STAGES - 1) % STAGES);
-        const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * ROWB;
-        const char* xt = smem + buf * STAGE + TW * ROWB + (wx * (TX / WX) + frow) * ROWB;
+        const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * RB;
+        const char* xt = smem + buf * STAGE + TW * RB + (wx * (TX / WX) + frow) * RB;
         // fragments of step kk+1 are read from LDS while the MFMAs of step kk execute
         bf16x8_t wf[2][FW], xf[2][FX];
         auto load_frags = [&](int kk, int par) {
             const int off = ((kk * 2 + fhi) ^ fswz) * 16;
 #pragma unroll
-            for (int i = 0; i < FW; ++i) wf[par][i] = *(const bf16x8_t*)(wt + i * 32 * ROWB + off);
+            for (int i = 0; i < FW; ++i) wf[par][i] = *(const bf16x8_t*)(wt + i * 32 * RB + off);
 #pragma unroll
-            for (int j = 0; j < FX; ++j) xf[par][j] = *(const bf16x8_t*)(xt + j * 32 * ROWB + off);
+            for (int j = 0; j < FX; ++j) xf[par][j] = *(const bf16x8_t*)(xt + j * 32 * RB + off);
         };
         load_frags(0, 0);
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            if (kk + 1 < BK / 16) load_frags(kk + 1, (kk + 1) & 1);
+        for (int kk = 0; kk < KB / 16; ++kk) {
+            if (kk + 1 < KB / 16) load_frags(kk + 1, (kk + 1) & 1);
 #pragma unroll
             for (int i = 0; i < FW; ++i)
 #pragma unroll
@@ -164,10 +172,12 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         const int m = m0 + wx * (TX / WX) + j * 32 + frow;
         if (m >= a.M) continue;
         if constexpr (EPI == EPI_SWIGLU) {
-            static_assert(EPI != EPI_SWIGLU || FW == 2, "SwiGLU tile needs a (g,u) fragment pair per wave");
+#pragma unroll
+            for (int ip = 0; ip < FW / 2; ++ip)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int h = n0 + ww * 32 + 8 * g + 4 * fhi;      // hidden index of the 4-group
+                // fragment pair (2ip, 2ip+1) = (g, u) of hidden units n0 + (tile row / 64) * 32 + ...
+                const int h = n0 + (ww * (TW / WW) / 64 + ip) * 32 + 8 * g + 4 * fhi;
                 if (h >= N) continue;
                 float gv[4], uv[4], av[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
                 if (a.bias) {
@@ -181,8 +191,8 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const bool live = h + e < N;          // hidden sizes need not be multiples of 4 (2730)
-                    gv[e] = live ? bfround(acc[0][j][4 * g + e] + b1[e]) : 0.f;
-                    uv[e] = live ? bfround(acc[1][j][4 * g + e] + b2[e]) : 0.f;
+                    gv[e] = live ? bfround(acc[2 * ip][j][4 * g + e] + b1[e]) : 0.f;
+                    uv[e] = live ? bfround(acc[2 * ip + 1][j][4 * g + e] + b2[e]) : 0.f;
                     av[e] = bfround(silu_f(gv[e])) * uv[e];
                 }
                 bf16_t* gu = (bf16_t*)a.out2 + (size_t)m * a.ldo2;
@@ -387,16 +397,16 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     }
 }
 
-int g_nt_config = 1;   // 0: 128x128 tile, 4 waves, 2 stages;  1: 128(W) x 256(X) tile, 8 waves, 3 stages
+int g_nt_config = 1;
 
-template <int TW, int TX, int WW, int WX, int STAGES, int EPI, bool GROUPED>
+template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED>
 int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (max_n + NPT - 1) / NPT;
     a.n_tiles_x = (a.M + TX - 1) / TX;
     const int grid = a.n_tiles_w * a.n_tiles_x;
-    const size_t lds = (size_t)STAGES * (TW + TX) * ROWB;
-    auto k = gemm_nt_kernel<TW, TX, WW, WX, STAGES, EPI, GROUPED>;
+    const size_t lds = (size_t)STAGES * (TW + TX) * KB * 2;
+    auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WW * WX * 64), lds, s, a);
@@ -404,11 +414,27 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     return 0;
 }
 
+// Tile configurations (fm_set_gemm_nt_config):
+//   0  128(feat) x 128(rows), 4 waves, K-step 64, 3 stages                 (grouped path; small problems)
+//   1  128 x 256, 8 waves (64x64 wave tiles), K-step 64, 3 stages, 144 KB  (1 workgroup / CU)
+//   2  128 x 256, 8 waves, K-step 32, 3 stages, 72 KB                      (2 workgroups / CU: epilogue overlap)
+//   3  128 x 256, 4 waves (64x128 wave tiles), K-step 64, 3 stages
+//   4  256 x 256, 8 waves (128x64 wave tiles), K-step 64, 2 stages, 128 KB
+//   5  128 x 256, 4 waves (64x128 wave tiles), K-step 32, 3 stages, 72 KB  (2 workgroups / CU)
 template <int EPI, bool GROUPED>
 int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     // grouped rows are segmented in 128-row tiles, so that path keeps the 128-row X tile
-    if (GROUPED || g_nt_config == 0 || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 3, EPI, GROUPED>(a, max_n, s);
-    return launch_nt_cfg<128, 256, 2, 4, 3, EPI, GROUPED>(a, max_n, s);
+    if (GROUPED || g_nt_config == 0 || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, GROUPED>(a, max_n, s);
+    if constexpr (!GROUPED) {
+        switch (g_nt_config) {
+            case 2: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false>(a, max_n, s);
+            case 3: return launch_nt_cfg<128, 256, 2, 2, 64, 3, EPI, false>(a, max_n, s);
+            case 4: return launch_nt_cfg<256, 256, 2, 4, 64, 2, EPI, false>(a, max_n, s);
+            case 5: return launch_nt_cfg<128, 256, 2, 2, 32, 3, EPI, false>(a, max_n, s);
+            default: break;
+        }
+    }
+    return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, GROUPED>(a, max_n, s);
 }
 
 }  // namespace

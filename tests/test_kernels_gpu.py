@@ -37,6 +37,35 @@ def randn(*shape, scale=1.0, seed=None):
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_gemm_nt_tile_configs(cfg):
+    """Every tile configuration of fm_gemm_nt (fm_set_gemm_nt_config) on ragged shapes and all epilogue kinds."""
+    ops, L = _ops()
+    L.lib.fm_set_gemm_nt_config(cfg)
+    try:
+        for M, N, K in [(300, 260, 192), (1000, 768, 768), (513, 2304, 64)]:
+            x = bf(randn(M, K, seed=1) + torch.arange(K, device=DEV)[None] * 0.01)
+            w = bf(randn(N, K, seed=2) * 0.1 + torch.arange(N, device=DEV)[:, None] * 0.001)
+            out = torch.full((M, N), 7.0, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt(x, w, out)
+            assert rel_err(out, x.float() @ w.float().t()) < 4e-3, (cfg, M, N, K)
+        M, K, H = 700, 128, 170
+        Hp = ops.ru(H, 64)
+        x, w1, w3 = bf(randn(M, K, seed=7)), bf(randn(H, K, seed=8) * 0.2), bf(randn(H, K, seed=9) * 0.2)
+        gu = torch.full((M, 2 * Hp), 3.0, device=DEV, dtype=torch.bfloat16)
+        act = torch.full((M, Hp), 3.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w1, act, epilogue=L.EPI_SWIGLU, w2=w3, out2=gu, Hp=Hp, N=H)
+        g, u = bf(x.float() @ w1.float().t()).float(), bf(x.float() @ w3.float().t()).float()
+        assert rel_err(gu[:, :H], g) < 4e-3 and rel_err(gu[:, Hp:Hp + H], u) < 4e-3, cfg
+        assert rel_err(act[:, :H], bf(torch.nn.functional.silu(g)).float() * u) < 8e-3, cfg
+        res = randn(M, 320, seed=6); buf = res.clone()
+        w = bf(randn(320, K, seed=4) * 0.2)
+        ops.gemm_nt(x, w, buf, epilogue=L.EPI_RESIDUAL, res=buf)
+        assert rel_err(buf, res + bf(x.float() @ w.float().t()).float()) < 3e-3, cfg
+    finally:
+        L.lib.fm_set_gemm_nt_config(1)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 260, 192), (1024, 768, 768), (70, 2304, 768)])
 def test_gemm_nt_plain(M, N, K):
     ops, L = _ops()

@@ -36,7 +36,7 @@ def report(name, sec, flops=0, nbytes=0):
 
 
 x = rnd(R, D)
-for cfg in (0, 1):
+for cfg in (1, 2, 3, 4, 5):
     L.lib.fm_set_gemm_nt_config(cfg)
     for name, N, K in (("qkv", 3 * D, D), ("proj", D, D), ("dX fc13 (K=4096)", D, 2 * Hd)):
         w, xin = rnd(N, K), rnd(R, K)
