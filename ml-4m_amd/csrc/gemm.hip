@@ -33,7 +33,7 @@ struct NTArgs {
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel
@@ -260,13 +260,13 @@ __device__ __forceinline__ const char* tn_addr(const char* tile, int row, int co
     return tile + row * RB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
 }
 
-template <bool TR, bool GROUPED, int TA, int TB, int WA, int WB, int STAGES>
+template <bool TR, bool GROUPED, int TA, int TB, int WA, int WB, int KB, int STAGES>
 __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     constexpr int NWAVES = WA * WB;
     constexpr int RBA = TA * 2, RBB = TB * 2;                         // bytes per LDS tile row
-    constexpr int PA = BK * RBA / 1024, PB = BK * RBB / 1024;         // 1-KiB DMA pieces per tile
+    constexpr int PA = KB * RBA / 1024, PB = KB * RBB / 1024;         // 1-KiB DMA pieces per tile
     constexpr int LOADS = (PA + PB) / NWAVES;                         // LDS-DMA instructions per wave per stage
-    constexpr int STAGE = BK * (RBA + RBB);
+    constexpr int STAGE = KB * (RBA + RBB);
     static_assert(TA / WA == 64 && TB / WB == 64 && PA % NWAVES == 0 && PB % NWAVES == 0, "wave tile is 64x64");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -283,18 +283,18 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
         const int g = blockIdx.z;
         N = a.groups[g].N; out = (float*)a.groups[g].out;
         r_begin = a.seg_start[g];
-        r_end = r_begin + ((a.seg_count[g] + BK - 1) / BK) * BK;
+        r_end = r_begin + ((a.seg_count[g] + 63) / 64) * 64;
     }
     const int n0 = ta * TA, k0 = tb * TB;
     if (n0 >= N || k0 >= a.K) return;
-    const int nt = (r_end - r_begin) / BK;                      // reduction tiles in total
+    const int nt = (r_end - r_begin) / KB;                      // reduction tiles in total
     const int per = (nt + a.splits - 1) / a.splits;
     const int t_begin = split * per, t_end = min(nt, t_begin + per);
     if (t_begin >= t_end) return;
 
     auto stage = [&](int t, int buf) {
         char* base = smem + buf * STAGE;
-        const int r0 = r_begin + t * BK;
+        const int r0 = r_begin + t * KB;
 #pragma unroll
         for (int p = 0; p < PA / NWAVES; ++p) {
             constexpr int LPR = RBA / 16, RPP = 1024 / RBA;        // lanes per row, rows per piece
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
             const int row = piece * RPP + lane / LPR;
             const int lc = (lane % LPR) ^ ((row & 3) << 2);
             int cb = k0 + lc * 8; cb = cb <= a.b_cols - 8 ? cb : a.b_cols - 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb), LDS_PTR(base + BK * RBA + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
         }
     };
 
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
         block_barrier();
         if (it + STAGES - 1 < NT_) stage(t_begin + it + STAGES - 1, (buf + STAGES - 1) % STAGES);
         const char* at = smem + buf * STAGE;
-        const char* bt = at + BK * RBA;
+        const char* bt = at + KB * RBA;
         if constexpr (TR) {
             // fragments of step kk+1 are in flight while the MFMAs of step kk run (8 transpose reads per step)
             bf16x8_t af[2][2], bfr[2][2];
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
             };
             load(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                if (kk + 1 < BK / 16) { load(kk + 1, (kk + 1) & 1); wait_lgkmcnt<8>(); }
+            for (int kk = 0; kk < KB / 16; ++kk) {
+                if (kk + 1 < KB / 16) { load(kk + 1, (kk + 1) & 1); wait_lgkmcnt<8>(); }
                 else wait_lgkmcnt<0>();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
             }
         } else {
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
+            for (int kk = 0; kk < KB / 16; ++kk) {
                 const int rA = kk * 16 + fhi * 8, rB = rA + 4;
                 bf16x8_t af[2], bfr[2];
 #pragma unroll
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     }
 }
 
-int g_nt_config = 1;
+int g_nt_config = 2;
 
 template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED>
 int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
@@ -427,14 +427,14 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     if (GROUPED || g_nt_config == 0 || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, GROUPED>(a, max_n, s);
     if constexpr (!GROUPED) {
         switch (g_nt_config) {
-            case 2: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false>(a, max_n, s);
             case 3: return launch_nt_cfg<128, 256, 2, 2, 64, 3, EPI, false>(a, max_n, s);
             case 4: return launch_nt_cfg<256, 256, 2, 4, 64, 2, EPI, false>(a, max_n, s);
             case 5: return launch_nt_cfg<128, 256, 2, 2, 32, 3, EPI, false>(a, max_n, s);
             default: break;
         }
     }
-    return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, GROUPED>(a, max_n, s);
+    if (g_nt_config == 1) return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, GROUPED>(a, max_n, s);
+    return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, GROUPED>(a, max_n, s);
 }
 
 }  // namespace
@@ -498,22 +498,22 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     FM_CHECK_ARG(a.a_cols >= 8 && a.b_cols >= 8, "fm_gemm_tn: operands need at least 8 readable columns");
     a.groups = p->groups; a.seg_start = p->seg_start; a.seg_count = p->seg_count;
     const int max_n = grouped ? p->max_N : p->N;
-    constexpr int TN_TA = 128, TN_TB = 256, TN_STAGES = 3;
+    constexpr int TN_TA = 128, TN_TB = 256, TN_KB = 32, TN_STAGES = 3;   // 72 KB of LDS: two workgroups per CU
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
     if (splits <= 0) {
-        // One workgroup per CU (144 KB of LDS): pick the split count whose workgroup total fills whole
-        // rounds of the 256 CUs best; ties go to fewer splits (each split is one more atomic pass over dW).
+        // Two workgroups per CU (72 KB of LDS each): pick the split count whose workgroup total fills whole
+        // rounds of 512 resident workgroups best; ties go to fewer splits (each split is one more atomic pass over dW).
         const int tiles = a.n_tiles_a * a.n_tiles_b * (grouped ? p->n_groups : 1);
-        const int nt = grouped ? (p->max_R + BK - 1) / BK : p->R / BK;
+        const int nt = grouped ? (p->max_R + TN_KB - 1) / TN_KB : p->R / TN_KB;
         double best = -1.0;
         splits = 1;
         for (int sgl = 1; sgl <= 64 && sgl <= nt; ++sgl) {
-            if (nt / sgl < 4 && sgl > 1) break;                         // keep the rings busy
-            const int wgs = tiles * sgl, rounds = (wgs + 255) / 256;
-            const double fill = (double)wgs / (rounds * 256.0);
+            if (nt / sgl < 8 && sgl > 1) break;                         // keep the rings busy
+            const int wgs = tiles * sgl, rounds = (wgs + 511) / 512;
+            const double fill = (double)wgs / (rounds * 512.0);
             const double score = fill - 0.002 * sgl - (rounds > 1 ? 0.0 : 0.0);
-            if (wgs >= 128 && score > best + 1e-9) { best = score; splits = sgl; }
+            if (wgs >= 256 && score > best + 1e-9) { best = score; splits = sgl; }
         }
         if (best < 0) {                                                // tiny problems: just expose parallelism
             splits = (256 + tiles - 1) / tiles;
@@ -522,12 +522,12 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
         }
     }
     a.splits = splits;
-    const size_t lds = (size_t)TN_STAGES * BK * (TN_TA + TN_TB) * 2;
+    const size_t lds = (size_t)TN_STAGES * TN_KB * (TN_TA + TN_TB) * 2;
     dim3 grid(a.n_tiles_a * a.n_tiles_b, splits, grouped ? p->n_groups : 1);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TN(TR, G)                                                                            \
     {                                                                                               \
-        auto k = gemm_tn_kernel<TR, G, TN_TA, TN_TB, 2, 4, TN_STAGES>;                              \
+        auto k = gemm_tn_kernel<TR, G, TN_TA, TN_TB, 2, 4, TN_KB, TN_STAGES>;                              \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true); \
         (void)once;                                                                                 \
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a);                                          \
