@@ -58,8 +58,8 @@ typedef struct fm_gemm_nt_args {
     const fm_gemm_group* groups; const int32_t* tile_group; int32_t max_N, pad_;
 } fm_gemm_nt_args;
 int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
-/* tile configuration of fm_gemm_nt: 0 = 128x128 workgroup tile (4 waves), 1 = 128 (features) x 256 (rows),
- * 8 waves (default).  Both use a 3-stage LDS ring.  For A/B measurements. */
+/* tile configuration of fm_gemm_nt, for A/B measurements (table in csrc/gemm.hip): low byte 0-6 = fixed
+ * configuration, 9 = automatic (default); +256 = raise the wave priority around the MFMA clusters. */
 void fm_set_gemm_nt_config(int cfg);
 int fm_get_gemm_nt_config(void);
 

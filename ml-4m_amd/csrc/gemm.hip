@@ -30,6 +30,7 @@ struct NTArgs {
     int M, N, K, ldw, ldx, ldo, ldo2, ldr, Hp;
     const fm_gemm_group* groups; const int* tile_group;   // grouped mode (may be null)
     int n_tiles_w, n_tiles_x;
+    int prio;                                             // raise the wave priority around the MFMA clusters
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -157,11 +158,13 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
         for (int kk = 0; kk < KB / 16; ++kk) {
             if (kk + 1 < KB / 16) load_frags(kk + 1, (kk + 1) & 1);
+            if (a.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < FW; ++i)
 #pragma unroll
                 for (int j = 0; j < FX; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], xf[kk & 1][j], acc[i][j], 0, 0, 0);
+            if (a.prio) __builtin_amdgcn_s_setprio(0);
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
@@ -273,10 +276,20 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wa = wave / WB, wb = wave % WB;
 
+    // Workgroups that reduce the same rows (same split) read the same A / B row panels, each a different
+    // column slice pair: they are placed on ONE XCD (dispatch puts workgroup b on XCD b % 8) and run
+    // concurrently, so a panel is fetched from HBM once and shared through that XCD's L2.
     const int nwg = a.n_tiles_a * a.n_tiles_b;
-    const int tile = xcd_remap(blockIdx.x, nwg);
+    int tile, split;
+    if (a.splits % 8 == 0) {
+        const int xcd = blockIdx.x % 8, i = blockIdx.x / 8;
+        split = xcd + 8 * (i / nwg);
+        tile = i % nwg;
+    } else {
+        split = blockIdx.x / nwg;
+        tile = blockIdx.x % nwg;
+    }
     const int ta = tile / a.n_tiles_b, tb = tile % a.n_tiles_b;
-    const int split = blockIdx.y;
     int N = a.N, r_begin = 0, r_end = a.R;
     float* out = a.out;
     if constexpr (GROUPED) {
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     }
 }
 
-int g_nt_config = 2;
+int g_nt_config = 9, g_nt_prio = 1;
 
 template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED>
 int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
@@ -421,15 +434,23 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
 //   3  128 x 256, 4 waves (64x128 wave tiles), K-step 64, 3 stages
 //   4  256 x 256, 8 waves (128x64 wave tiles), K-step 64, 2 stages, 128 KB
 //   5  128 x 256, 4 waves (64x128 wave tiles), K-step 32, 3 stages, 72 KB  (2 workgroups / CU)
+//   6  128 x 128, 4 waves, K-step 32, 3 stages, 48 KB                      (3 workgroups / CU)
+//   +256: s_setprio(1) around the MFMA clusters
+//   9  automatic (default): configuration 1 for long reductions (K >= 1536), else 2
 template <int EPI, bool GROUPED>
 int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     // grouped rows are segmented in 128-row tiles, so that path keeps the 128-row X tile
     if (GROUPED || g_nt_config == 0 || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, GROUPED>(a, max_n, s);
+    if (g_nt_config == 9) {
+        if (a.K >= 1536) return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, GROUPED>(a, max_n, s);
+        return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, GROUPED>(a, max_n, s);
+    }
     if constexpr (!GROUPED) {
         switch (g_nt_config) {
             case 3: return launch_nt_cfg<128, 256, 2, 2, 64, 3, EPI, false>(a, max_n, s);
             case 4: return launch_nt_cfg<256, 256, 2, 4, 64, 2, EPI, false>(a, max_n, s);
             case 5: return launch_nt_cfg<128, 256, 2, 2, 32, 3, EPI, false>(a, max_n, s);
+            case 6: return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, false>(a, max_n, s);
             default: break;
         }
     }
@@ -455,6 +476,7 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     a.out = p->out; a.out2 = p->out2; a.res = (const float*)p->res; a.bias = (const float*)p->bias; a.bias2 = (const float*)p->bias2;
     a.M = p->M; a.N = p->N; a.K = p->K; a.ldw = p->ldw; a.ldx = p->ldx; a.ldo = p->ldo; a.ldo2 = p->ldo2; a.ldr = p->ldr; a.Hp = p->Hp;
     a.groups = p->groups; a.tile_group = p->tile_group;
+    a.prio = g_nt_prio;
     hipStream_t s = (hipStream_t)stream;
     const int max_n = grouped ? p->max_N : p->N;
     if (grouped) {
@@ -478,7 +500,7 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     return -1;
 }
 
-extern "C" void fm_set_gemm_nt_config(int cfg) { g_nt_config = cfg; }
+extern "C" void fm_set_gemm_nt_config(int cfg) { g_nt_config = cfg & 0xff; g_nt_prio = (cfg >> 8) & 1; }
 extern "C" int fm_get_gemm_nt_config(void) { return g_nt_config; }
 static int g_tn_use_tr = 1;   // ds_read_b64_tr_b16 semantics verified on hardware (tools/probe_gfx950.hip)
 extern "C" void fm_set_tn_transpose_read(int on) { g_tn_use_tr = on; }
@@ -502,28 +524,17 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
     if (splits <= 0) {
-        // Two workgroups per CU (72 KB of LDS each): pick the split count whose workgroup total fills whole
-        // rounds of 512 resident workgroups best; ties go to fewer splits (each split is one more atomic pass over dW).
-        const int tiles = a.n_tiles_a * a.n_tiles_b * (grouped ? p->n_groups : 1);
+        // One split (or several) per XCD: 32 CUs x 2 resident workgroups = 64 slots per XCD
+        const int tiles = a.n_tiles_a * a.n_tiles_b;
         const int nt = grouped ? (p->max_R + TN_KB - 1) / TN_KB : p->R / TN_KB;
-        double best = -1.0;
-        splits = 1;
-        for (int sgl = 1; sgl <= 64 && sgl <= nt; ++sgl) {
-            if (nt / sgl < 8 && sgl > 1) break;                         // keep the rings busy
-            const int wgs = tiles * sgl, rounds = (wgs + 511) / 512;
-            const double fill = (double)wgs / (rounds * 512.0);
-            const double score = fill - 0.002 * sgl - (rounds > 1 ? 0.0 : 0.0);
-            if (wgs >= 256 && score > best + 1e-9) { best = score; splits = sgl; }
-        }
-        if (best < 0) {                                                // tiny problems: just expose parallelism
-            splits = (256 + tiles - 1) / tiles;
-            if (splits > nt) splits = nt;
-            if (splits < 1) splits = 1;
-        }
+        int per_xcd = tiles >= 64 ? 1 : 64 / tiles;
+        while (per_xcd > 1 && nt / (8 * per_xcd) < 8) --per_xcd;      // keep >= 8 reduction tiles per workgroup
+        splits = 8 * per_xcd;
+        if (nt < 16) splits = 1;                                       // tiny problems
     }
     a.splits = splits;
     const size_t lds = (size_t)TN_STAGES * TN_KB * (TN_TA + TN_TB) * 2;
-    dim3 grid(a.n_tiles_a * a.n_tiles_b, splits, grouped ? p->n_groups : 1);
+    dim3 grid(a.n_tiles_a * a.n_tiles_b * splits, 1, grouped ? p->n_groups : 1);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TN(TR, G)                                                                            \
     {                                                                                               \

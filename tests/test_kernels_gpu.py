@@ -63,7 +63,7 @@ def test_gemm_nt_tile_configs(cfg):
         ops.gemm_nt(x, w, buf, epilogue=L.EPI_RESIDUAL, res=buf)
         assert rel_err(buf, res + bf(x.float() @ w.float().t()).float()) < 3e-3, cfg
     finally:
-        L.lib.fm_set_gemm_nt_config(1)
+        L.lib.fm_set_gemm_nt_config(9 + 256)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 260, 192), (1024, 768, 768), (70, 2304, 768)])

@@ -36,7 +36,7 @@ def report(name, sec, flops=0, nbytes=0):
 
 
 x = rnd(R, D)
-for cfg in (1, 2, 3, 4, 5):
+for cfg in (9 + 256,):
     L.lib.fm_set_gemm_nt_config(cfg)
     for name, N, K in (("qkv", 3 * D, D), ("proj", D, D), ("dX fc13 (K=4096)", D, 2 * Hd)):
         w, xin = rnd(N, K), rnd(R, K)
@@ -48,7 +48,7 @@ for cfg in (1, 2, 3, 4, 5):
     w1, w3 = rnd(Hd, D), rnd(Hd, D)
     gu, act = torch.empty(R, 2 * Hd, device=dev, dtype=torch.bfloat16), torch.empty(R, Hd, device=dev, dtype=torch.bfloat16)
     report(f"nt cfg{cfg} swiglu fc1|fc3 N=2x{Hd} K={D}", timeit(lambda: ops.gemm_nt(x, w1, act, epilogue=L.EPI_SWIGLU, w2=w3, out2=gu, Hp=Hd)), 4.0 * R * Hd * D)
-L.lib.fm_set_gemm_nt_config(1)
+L.lib.fm_set_gemm_nt_config(9 + 256)
 
 for name, N, K in (("dW qkv", 3 * D, D), ("dW proj", D, D), ("dW fc2", D, Hd), ("dW fc1", Hd, D)):
     a_, b_ = rnd(R, N), rnd(R, K)
