@@ -247,9 +247,10 @@ def main():
         ops.set_profiler(None)
         agg = prof.summary()
         tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
-        symbol = {"gemm_nt": "gemm_nt_kernel<128,128,2,2,{epi},false>", "gemm_tn": "gemm_tn_kernel<true,false>",
-                  "attn_fwd": "attn_fwd_kernel<true>", "attn_bwd": "attn_bwd_kernel<true>",
-                  "layernorm_fwd": "ln_fwd_kernel<bf16>", "layernorm_bwd": "ln_bwd_kernel"}
+        symbol = {"gemm_nt": "gemm_nt_kernel<128,256,2,4,{{32|64}},3,EPI={epi},false>  (csrc/gemm.hip)",
+                  "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,32,3>  (csrc/gemm.hip)",
+                  "attn_fwd": "attn_fwd_kernel<true,MASK>", "attn_bwd": "attn_bwd_kernel<true,MASK>",
+                  "layernorm_fwd": "ln_fwd_kernel<bf16,3>", "layernorm_bwd": "ln_bwd_kernel<3>"}
         name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
         fam, _, epi = name.partition("/epi")
         common = {"kernel": symbol.get(fam, fam).format(epi=epi or "0"), "traffic": None, "launches_per_step": d["n"] // 2,

@@ -12,7 +12,9 @@
 //   FM_MASK_DENSE    blocked[b][q][k] = dense[b][q][k]                           (arbitrary (B,n1,n2) bool)
 //
 // Scores are computed transposed (S^T = K Q^T) so that a lane owns one query: the online-softmax
-// statistics are lane-local and P^T feeds the PV MFMA straight from registers.  V (and, in the
+// statistics are lane-local and P^T feeds the PV MFMA straight from registers.  Softmax runs in the
+// base-2 domain (t = s * scale * log2 e, p = exp2(t - max)): one FMA + one v_exp per score; stat_m holds
+// the row maximum of t, stat_l the row sum of p (a private fwd -> bwd convention).  V (and, in the
 // backward, K / Q / dO) are consumed "column-wise" from row-major LDS tiles through lds_col_frag.
 #include "common.h"
 #include "fourm_hip.h"
@@ -67,18 +69,21 @@ __device__ __forceinline__ bf16x8_t pack8(const float* p) {
     return x.v;
 }
 
+// blocked(q, k) for lane-owned q and key index k = k0 + c (c = position inside a 64-key window):
+//   KEYPAD : bit c of `bits` (bit mask of the window's padded keys, pre-shifted by 4*fhi)
+//   DECODER: (c >= cs_rel) | (mk != mq)   with cs_rel = cs[q] - k0 (or the causal bound q + 1 - k0)
+//   DENSE  : byte load
 template <int MASK>
-__device__ __forceinline__ bool blocked_qk(const AttnArgs& a, int b, int q, int k, int csq, int mq, int mk, bool kp) {
-    if constexpr (MASK == FM_MASK_KEYPAD) return kp;
+__device__ __forceinline__ bool blocked_at(const AttnArgs& a, int b, int q, int k, int c, unsigned long long bits, int cs_rel, int mq, int mk) {
+    if constexpr (MASK == FM_MASK_KEYPAD) return (bits >> c) & 1ull;
     else if constexpr (MASK == FM_MASK_DECODER) {
-        bool blk = false;
-        if (a.causal) blk = k > q;
-        else if (a.cs) blk = k >= csq;
+        bool blk = c >= cs_rel;
         if (a.modq) blk = blk || (mq != mk);
         return blk;
     } else if constexpr (MASK == FM_MASK_DENSE) return a.dense[((size_t)b * a.Nq + q) * a.Nk + k] != 0;
     else return false;
 }
+constexpr float LOG2E = 1.4426950408889634f;
 
 // ------------------------------------------------------------------------------------------------
 // forward: grid (ceil(Nq/128), H, B), 4 waves x 32 queries, keys in tiles of 64 with online softmax
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = a.scale * LOG2E;
 
     const int NT = (a.Nk + KT - 1) / KT;
     stage(0, 0);
@@ -154,43 +160,52 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int kk = 0; kk < 4; ++kk)
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, kb * 32 + (lane & 31), kk, fhi), qf[kk], st[kb], 0, 0, 0);
         }
-        // ---- mask + running max ---------------------------------------------------------------
+        // ---- mask + running max (base-2 domain) ------------------------------------------------
         float p[2][16];
         float tmax = -INFINITY;
+        unsigned long long bits = 0;
+        int cs_rel = 0x7fffffff;
+        if constexpr (MASK == FM_MASK_KEYPAD) bits = __ballot(kpad_l[t * KT + lane] != 0) >> (4 * fhi);
+        if constexpr (MASK == FM_MASK_DECODER) {
+            if (a.causal) cs_rel = qc + 1 - t * KT - 4 * fhi;
+            else if (a.cs) cs_rel = csq - t * KT - 4 * fhi;
+        }
+        const bool full_tile = (t + 1) * KT <= a.Nk;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-                const int k = t * KT + kl;
-                float s = bfround(bfround(st[kb][r]) * a.scale);
+                const int c = kb * 32 + (r & 3) + 8 * (r >> 2);          // compile-time; key = t*KT + c + 4*fhi
+                float sv = st[kb][r] * c2;
                 if constexpr (MASK != FM_MASK_NONE) {
-                    int mk = 0; bool kp = false;
-                    if constexpr (MASK == FM_MASK_DECODER) mk = kmod_l[k];
-                    if constexpr (MASK == FM_MASK_KEYPAD) kp = kpad_l[k] != 0;
-                    s = blocked_qk<MASK>(a, b, qc, k < a.Nk ? k : a.Nk - 1, csq, mq, mk, kp) ? NEG_FILL : s;
+                    int mk = 0;
+                    if constexpr (MASK == FM_MASK_DECODER) mk = kmod_l[t * KT + c + 4 * fhi];
+                    const int k = t * KT + c + 4 * fhi;
+                    sv = blocked_at<MASK>(a, b, qc, k < a.Nk ? k : a.Nk - 1, c, bits, cs_rel, mq, mk) ? NEG_FILL : sv;
                 }
-                s = k < a.Nk ? s : -INFINITY;
-                p[kb][r] = s;
-                tmax = fmaxf(tmax, s);
+                if (!full_tile) sv = (t * KT + c + 4 * fhi) < a.Nk ? sv : -INFINITY;
+                p[kb][r] = sv;
+                tmax = fmaxf(tmax, sv);
             }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);     // first tile: exp(-inf) = 0
+        const float alpha = exp2f(m_run - m_new);      // first tile: exp2(-inf) = 0
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[kb][r] = __expf(p[kb][r] - m_new);
+                p[kb][r] = __builtin_amdgcn_exp2f(p[kb][r] - m_new);
                 psum += p[kb][r];
             }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
         // ---- O^T += V^T P^T ---------------------------------------------------------------------
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -240,12 +255,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     char* dOl = Ql + NqP * ROWB;
     char* Kl = dOl + NqP * ROWB;
     char* Vl = Kl + NkP * ROWB;
-    float* m_l = (float*)(Vl + NkP * ROWB);
-    float* linv_l = m_l + NqP;
-    float* delta_l = linv_l + NqP;
-    int32_t* cs_l = (int32_t*)(delta_l + NqP);
-    int16_t* modq_l = (int16_t*)(cs_l + NqP);
-    int16_t* modk_l = modq_l + NqP;
+    float4* qs_l = (float4*)(Vl + NkP * ROWB);          // per query: {row max (base 2), 1/row sum, delta, cs | mod}
+    int16_t* modk_l = (int16_t*)(qs_l + NqP);
     uint8_t* kpad_l = (uint8_t*)(modk_l + NkP);
 
     const int lane = threadIdx.x & 63;
@@ -286,11 +297,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         dl += __shfl_xor(dl, 1, 64);
         if (half == 0 && q < NqP) {
             const size_t si = ((size_t)b * a.H + h) * a.Nq + (q < a.Nq ? q : 0);
-            delta_l[q] = dl;
-            m_l[q] = q < a.Nq ? a.stat_m[si] : 0.f;
-            linv_l[q] = q < a.Nq ? 1.0f / a.stat_l[si] : 0.f;
-            cs_l[q] = (MASK == FM_MASK_DECODER && a.cs && q < a.Nq) ? a.cs[(size_t)b * a.Nq + q] : 0;
-            modq_l[q] = (MASK == FM_MASK_DECODER && a.modq && q < a.Nq) ? a.modq[(size_t)b * a.Nq + q] : (int16_t)0;
+            int csv = 0x7fff, modv = 0;
+            if constexpr (MASK == FM_MASK_DECODER) {
+                if (q < a.Nq) {
+                    if (a.causal) csv = q + 1;
+                    else if (a.cs) csv = min(a.cs[(size_t)b * a.Nq + q], 0x7fff);
+                    if (a.modq) modv = (uint16_t)a.modq[(size_t)b * a.Nq + q];
+                }
+            }
+            // out-of-range queries get linv = 0: their probabilities vanish
+            qs_l[q] = make_float4(q < a.Nq ? a.stat_m[si] : 0.f, q < a.Nq ? 1.0f / a.stat_l[si] : 0.f, dl,
+                                  __int_as_float((csv << 16) | modv));
         }
     }
     for (int k = threadIdx.x; k < NkP; k += 256) {
@@ -301,6 +318,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     __syncthreads();
 
     const int nQB = NqP / 32, nKB = NkP / 32;
+    const float c2 = a.scale * LOG2E;
 
     // ---- pass A: dK, dV -------------------------------------------------------------------------
     for (int kb = wave; kb < nKB; kb += 4) {
@@ -332,16 +350,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-                const int qc = q < a.Nq ? q : a.Nq - 1;
-                float sc = bfround(bfround(s[r]) * a.scale);
+                const float4 qs = qs_l[q];                                   // one 16-byte broadcast read
+                float sc = s[r] * c2;
                 bool blk = false;
-                if constexpr (MASK != FM_MASK_NONE) blk = blocked_qk<MASK>(a, b, qc, kc, MASK == FM_MASK_DECODER ? cs_l[qc] : 0, MASK == FM_MASK_DECODER ? modq_l[qc] : 0, mk, kp);
+                if constexpr (MASK == FM_MASK_KEYPAD) blk = kp;
+                if constexpr (MASK == FM_MASK_DECODER) {
+                    const int w = __float_as_int(qs.w);
+                    blk = kc >= (w >> 16);
+                    if (a.modq) blk = blk || ((w & 0xffff) != (mk & 0xffff));
+                }
+                if constexpr (MASK == FM_MASK_DENSE) blk = a.dense[((size_t)b * a.Nq + (q < a.Nq ? q : a.Nq - 1)) * a.Nk + kc] != 0;
                 sc = blk ? NEG_FILL : sc;
-                float pr = __expf(sc - m_l[q]) * linv_l[q];
-                pr = (q < a.Nq && k < a.Nk) ? pr : 0.f;
+                float pr = __builtin_amdgcn_exp2f(sc - qs.x) * qs.y;
+                pr = k < a.Nk ? pr : 0.f;
                 pv[r] = pr;
                 // masked_fill stops the gradient at blocked scores (they matter only in fully blocked rows)
-                dsv[r] = blk ? 0.f : pr * (dp[r] - delta_l[q]) * a.scale;
+                dsv[r] = blk ? 0.f : pr * (dp[r] - qs.z) * a.scale;
             }
 #pragma unroll
             for (int sblk = 0; sblk < 2; ++sblk) {
@@ -374,8 +398,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
     for (int qb = wave; qb < nQB; qb += 4) {
         const int q = qb * 32 + (lane & 31);
         const int qc = q < a.Nq ? q : a.Nq - 1;
-        const float mq_ = m_l[q], li = linv_l[q], dl = delta_l[q];
-        const int csq = cs_l[qc], mq = modq_l[qc];
+        const float4 qs = qs_l[q];
+        const float mq_ = qs.x, li = qs.y, dl = qs.z;
+        const int csq = __float_as_int(qs.w) >> 16, mq = __float_as_int(qs.w) & 0xffff;
         bf16x8_t qf[4], dof[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -397,16 +422,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vl, kb * 32 + (lane & 31), kk, fhi), dof[kk], dp, 0, 0, 0);
             }
             float dsv[16];
+            unsigned long long bits = 0;
+            if constexpr (MASK == FM_MASK_KEYPAD) bits = (kb * 32 < NkP ? __ballot(kpad_l[min(kb * 32 + (lane & 31), NkP - 1)] != 0) : 0ull) >> (4 * fhi);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                const int c = (r & 3) + 8 * (r >> 2);
+                const int k = kb * 32 + c + 4 * fhi;
                 const int kc = k < a.Nk ? k : a.Nk - 1;
-                float sc = bfround(bfround(s[r]) * a.scale);
+                float sc = s[r] * c2;
                 bool blk = false;
-                if constexpr (MASK != FM_MASK_NONE) blk = blocked_qk<MASK>(a, b, qc, kc, csq, mq, MASK == FM_MASK_DECODER ? modk_l[kc] : 0, MASK == FM_MASK_KEYPAD ? kpad_l[kc] != 0 : false);
+                if constexpr (MASK == FM_MASK_KEYPAD) blk = (bits >> c) & 1ull;
+                if constexpr (MASK == FM_MASK_DECODER) {
+                    blk = kc >= csq;
+                    if (a.modq) blk = blk || (mq != (modk_l[kc] & 0xffff));
+                }
+                if constexpr (MASK == FM_MASK_DENSE) blk = a.dense[((size_t)b * a.Nq + qc) * a.Nk + kc] != 0;
                 sc = blk ? NEG_FILL : sc;
-                float pr = __expf(sc - mq_) * li;
-                pr = (q < a.Nq && k < a.Nk) ? pr : 0.f;
+                float pr = __builtin_amdgcn_exp2f(sc - mq_) * li;
+                pr = k < a.Nk ? pr : 0.f;
                 dsv[r] = blk ? 0.f : pr * (dp[r] - dl) * a.scale;
             }
 #pragma unroll
@@ -491,7 +524,7 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     FM_CHECK_ARG(a.Nq <= 256 && a.Nk <= 256, "fm_attn_bwd: Nq=%d Nk=%d exceed the 256-token training budget of this kernel", a.Nq, a.Nk);
     FM_CHECK_ARG(p->lddo % 8 == 0 && p->lddq % 4 == 0 && p->lddk % 4 == 0 && p->lddv % 4 == 0, "fm_attn_bwd: leading dims");
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
-    const size_t lds = (size_t)(2 * NqP + 2 * NkP) * ROWB + NqP * (3 * 4 + 4 + 2) + NkP * (2 + 1) + 64;
+    const size_t lds = (size_t)(2 * NqP + 2 * NkP) * ROWB + NqP * 16 + NkP * (2 + 1) + 64;
     dim3 grid(a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
 #define BWD(TR, MK)                                                                                                   \

@@ -35,17 +35,15 @@ void fm_set_error(const char* fmt, ...);
     } while (0)
 
 // ---- bf16 <-> f32 ---------------------------------------------------------------------------
+// float -> bf16 uses the hardware converter (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved —
+// the same rounding as torch's .to(bfloat16)); bf16 -> float is a 16-bit shift.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    // round-to-nearest-even (matches torch .to(bfloat16)); NaN stays NaN
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float bfround(float f) { return (float)(__bf16)f; }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // ---- wave / block reductions -----------------------------------------------------------------
