@@ -34,7 +34,10 @@ enum fm_epilogue {
     FM_EPI_RESIDUAL = 2, /* out(f32)   = res(f32) + bf16(acc + bias)      (out may alias res)         */
     FM_EPI_SWIGLU = 3,   /* W -> g, W2 -> u: out(bf16)[m][h] = silu(g)*u; out2(bf16)[m][h] = g, [m][Hp+h] = u */
     FM_EPI_F32 = 4,      /* out(f32)   = acc + bias (+ res(f32) when given; no rounding)              */
-    FM_EPI_TANH = 5      /* out(bf16)  = tanh(bf16(acc + bias))                                       */
+    FM_EPI_TANH = 5,     /* out(bf16)  = tanh(bf16(acc + bias))                                       */
+    FM_EPI_SWIGLU_BWD = 6, /* acc = d(silu(g)*u); res(bf16,(M,2*Hp)) = g|u saved by FM_EPI_SWIGLU;
+                              out(bf16,(M,2*Hp)) = dg | du.  Columns [roundup4(N), Hp) of each half are not written */
+    FM_EPI_GELU_BWD = 7  /* acc = d(gelu(pre)); res(bf16) = pre saved by FM_EPI_GELU; out(bf16) = d(pre) */
 };
 
 typedef struct fm_gemm_group {  /* one entry per row segment (modality) in grouped mode */
@@ -209,19 +212,32 @@ enum fm_loss_type { FM_LOSS_MOD = 0, FM_LOSS_TOKEN = 1 };
 int fm_segment_rows(const int32_t* head_of_row, int R, int n_heads, int32_t* seg_start, int32_t* seg_count,
                     int32_t* perm, int32_t* row_to_padded, int32_t* tile_group, int Rp, void* stream);
 int fm_gather_rows(const void* src, int ld_src, const int32_t* perm, void* dst, int ld_dst, int Rp, int D, void* stream);
-/* logits: bf16 (Rp, ldl) produced by the grouped fm_gemm_nt.  Writes row_loss (Rp) f32, head_loss
- * (n_heads) f32 and total_loss (1) f32.  With write_grad the logits are replaced in place by
- * d(total)/d(logits) * grad_scale[0] (bf16; pad rows and columns up to roundup64(vocab) zeroed). */
+/* logits: bf16 (Rp, ldl) produced by the grouped fm_gemm_nt (16-byte aligned, ldl % 8 == 0).
+ * write_grad == 0 (forward): one streaming pass; writes row_loss (Rp), row_lse (Rp), head_loss (n_heads) and
+ *   total_loss (1), all f32.
+ * write_grad == 1 (backward): the logits are replaced in place by d(total)/d(logits) * grad_scale[0] (bf16; pad
+ *   rows and the columns up to roundup64(vocab) zeroed) using the row_lse of the forward call. */
 int fm_cross_entropy(void* logits, int ldl, const int32_t* perm, const int32_t* tile_group, const int64_t* target_ids,
                      const int32_t* vocab, const int32_t* seg_start, const int32_t* seg_count, const void* grad_scale,
-                     int loss_type, int n_heads, int Rp, int max_vocab, void* row_loss, void* head_loss, void* total_loss,
-                     int write_grad, void* stream);
+                     int loss_type, int n_heads, int Rp, int max_vocab, void* row_loss, void* row_lse, void* head_loss,
+                     void* total_loss, int write_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise / reductions
  * ---------------------------------------------------------------------------------------------- */
 int fm_swiglu_bwd(const void* da, int ldda, const void* gu, int ldgu, void* dgu, int lddgu, int R, int H, int Hp, void* stream);
 int fm_gelu_bwd(const void* dh, int lddh, const void* pre, int ldp, void* dpre, int lddp, int R, int H, int Hp, void* stream);
+/* One launch refreshing many bf16 weight shadows from their fp32 masters (what autocast's per-call weight
+ * casts amount to, fm_utils.py Linear layers under torch.autocast).  Job i covers the 64x64 tiles
+ * [tile_start_i, tile_start_{i+1}) of its (rows, cols) source, tiles_i = ceil(rows/64)*ceil(cols/64);
+ * transpose == 0: dst[r][c] = bf16(src[r][c]);  transpose == 1: dst[c][r] = bf16(src[r][c]).
+ * Destination padding is not written.  descs: DEVICE pointer, sorted by tile_start (first = 0). */
+typedef struct fm_shadow_desc {
+    const void* src; void* dst;
+    int32_t ld_src, ld_dst, rows, cols, transpose, tile_start;
+} fm_shadow_desc;
+int fm_shadow_refresh(const fm_shadow_desc* descs, int n_descs, int total_tiles, void* stream);
+
 /* bf16 weight shadows: dst[r][c] = src[r][c], columns [cols, ld_dst) zero /
  * dst[c][r] = src[r][c], columns [rows, dst_cols) zero (dst_cols <= ld_dst) */
 int fm_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, void* stream);

@@ -91,6 +91,66 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
     }
 }
 
+// Multi-tensor refresh of the bf16 weight shadows: one launch walks a device table of (fp32 master -> bf16
+// shadow) jobs in 64x64 tiles; a job either casts in place or casts + transposes through LDS.  Pad rows /
+// columns of the destinations are never written (they are zero from allocation).
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const fm_shadow_desc* __restrict__ descs, int n) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n - 1;                                   // last job with tile_start <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const fm_shadow_desc d = descs[lo];
+    const int t = blockIdx.x - d.tile_start;
+    const int tiles_c = (d.cols + 63) / 64;
+    const int tr0 = (t / tiles_c) * 64, tc0 = (t % tiles_c) * 64;
+    const float* src = (const float*)d.src;
+    bf16_t* dst = (bf16_t*)d.dst;
+    const bool vec_src = ((((uintptr_t)src) & 15) == 0) && (d.ld_src % 4 == 0);
+    const bool vec_dst = ((((uintptr_t)dst) & 7) == 0) && (d.ld_dst % 4 == 0);
+    const int q = (threadIdx.x & 15) * 4, p = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = p + 16 * i, gr = tr0 + r, gc = tc0 + q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gr < d.rows) {
+            const float* sp = src + (size_t)gr * d.ld_src + gc;
+            if (vec_src && gc + 3 < d.cols) {
+                const float4 f = *(const float4*)sp;
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (gc + e < d.cols) v[e] = sp[e];
+            }
+        }
+        if (!d.transpose) {
+            if (gr < d.rows) {
+                bf16_t* dp = dst + (size_t)gr * d.ld_dst + gc;
+                if (vec_dst && gc + 3 < d.cols) *(uint2*)dp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gc + e < d.cols) dp[e] = f2bf(v[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][q + e] = v[e];
+        }
+    }
+    if (!d.transpose) return;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = p + 16 * i, gc = tc0 + c, gr = tr0 + q;          // dst row = src column
+        if (gc >= d.cols) continue;
+        bf16_t* dp = dst + (size_t)gc * d.ld_dst + gr;
+        if (vec_dst && gr + 3 < d.rows) *(uint2*)dp = make_uint2(pack2bf(tile[q][c], tile[q + 1][c]), pack2bf(tile[q + 2][c], tile[q + 3][c]));
+        else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (gr + e < d.rows) dp[e] = f2bf(tile[q + e][c]);
+    }
+}
+
 // db[n] += sum_r dY[r][n]
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dy, int ldy, float* __restrict__ db, int R, int N, int rows_per_block) {
     const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
@@ -213,6 +273,13 @@ extern "C" int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int
     dim3 grid((cols + 63) / 64, (dst_cols + 63) / 64);
     hipLaunchKernelGGL(transpose_cast_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, (bf16_t*)dst, ld_dst, dst_cols, rows, cols);
     FM_CHECK_LAUNCH("fm_transpose_cast_pad");
+    return 0;
+}
+
+extern "C" int fm_shadow_refresh(const fm_shadow_desc* descs, int n_descs, int total_tiles, void* stream) {
+    FM_CHECK_ARG(descs && n_descs > 0 && total_tiles > 0, "fm_shadow_refresh: bad argument");
+    hipLaunchKernelGGL(shadow_refresh_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs, n_descs);
+    FM_CHECK_LAUNCH("fm_shadow_refresh");
     return 0;
 }
 

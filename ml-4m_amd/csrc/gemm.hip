@@ -22,7 +22,7 @@ namespace {
 constexpr int BK = 64;           // reduction elements per LDS stage
 
 enum { EPI_BF16 = FM_EPI_BF16, EPI_GELU = FM_EPI_GELU, EPI_RES = FM_EPI_RESIDUAL, EPI_SWIGLU = FM_EPI_SWIGLU,
-       EPI_F32 = FM_EPI_F32, EPI_TANH = FM_EPI_TANH };
+       EPI_F32 = FM_EPI_F32, EPI_TANH = FM_EPI_TANH, EPI_SWIGLU_BWD = FM_EPI_SWIGLU_BWD, EPI_GELU_BWD = FM_EPI_GELU_BWD };
 
 struct NTArgs {
     const bf16_t* W; const bf16_t* W2; const bf16_t* X;
@@ -229,6 +229,38 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = tanhf(bfround(v[e]));
                         *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    } else if constexpr (EPI == EPI_SWIGLU_BWD) {
+                        // acc = d(silu(g)*u); res = saved (g | u) bf16; out = (dg | du) bf16     (GatedMlp, fm_utils.py:142-144)
+                        const bf16_t* gu = (const bf16_t*)a.res + (size_t)m * a.ldr + n;
+                        const uint2 gp = *(const uint2*)gu, up = *(const uint2*)(gu + a.Hp);
+                        const float gv[4] = {bf2f((bf16_t)(gp.x & 0xffff)), bf2f((bf16_t)(gp.x >> 16)), bf2f((bf16_t)(gp.y & 0xffff)), bf2f((bf16_t)(gp.y >> 16))};
+                        const float uv[4] = {bf2f((bf16_t)(up.x & 0xffff)), bf2f((bf16_t)(up.x >> 16)), bf2f((bf16_t)(up.y & 0xffff)), bf2f((bf16_t)(up.y >> 16))};
+                        float dg[4], du[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = bfround(v[e]);
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gv[e]));
+                            const float sl = bfround(gv[e] * sg);
+                            const float ds = bfround(d * uv[e]);
+                            const bool live = n + e < N;
+                            du[e] = live ? d * sl : 0.f;
+                            dg[e] = live ? ds * (sg * (1.0f + gv[e] * (1.0f - sg))) : 0.f;
+                        }
+                        bf16_t* o = (bf16_t*)a.out + (size_t)m * a.ldo + n;
+                        *(uint2*)o = make_uint2(pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3]));
+                        *(uint2*)(o + a.Hp) = make_uint2(pack2bf(du[0], du[1]), pack2bf(du[2], du[3]));
+                    } else if constexpr (EPI == EPI_GELU_BWD) {
+                        // acc = d(gelu(pre)); res = saved pre-activation bf16; out = d(pre) bf16    (Mlp, fm_utils.py:121-126)
+                        const uint2 pp = *(const uint2*)((const bf16_t*)a.res + (size_t)m * a.ldr + n);
+                        const float xv[4] = {bf2f((bf16_t)(pp.x & 0xffff)), bf2f((bf16_t)(pp.x >> 16)), bf2f((bf16_t)(pp.y & 0xffff)), bf2f((bf16_t)(pp.y >> 16))};
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float cdf = 0.5f * (1.0f + erff(xv[e] * 0.70710678118654752f));
+                            const float pdf = 0.3989422804014327f * __expf(-0.5f * xv[e] * xv[e]);
+                            o[e] = (n + e < N) ? bfround(v[e]) * (cdf + xv[e] * pdf) : 0.f;
+                        }
+                        *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
                     } else if constexpr (EPI == EPI_RES) {
                         const float4 r = *(const float4*)(a.res + (size_t)m * a.ldr + n);
                         float4 o = make_float4(r.x + bfround(v[0]), r.y + bfround(v[1]), r.z + bfround(v[2]), r.w + bfround(v[3]));
@@ -440,7 +472,8 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
 template <int EPI, bool GROUPED>
 int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     // grouped rows are segmented in 128-row tiles, so that path keeps the 128-row X tile
-    if (GROUPED || g_nt_config == 0 || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, GROUPED>(a, max_n, s);
+    if (GROUPED || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
+    if (g_nt_config == 0) return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, GROUPED>(a, max_n, s);
     if (g_nt_config == 9) {
         if (a.K >= 1536) return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, GROUPED>(a, max_n, s);
         return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, GROUPED>(a, max_n, s);
@@ -495,6 +528,13 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
             return launch_nt<EPI_SWIGLU, false>(a, max_n, s);
         case FM_EPI_F32: return launch_nt<EPI_F32, false>(a, max_n, s);
         case FM_EPI_TANH: return launch_nt<EPI_TANH, false>(a, max_n, s);
+        case FM_EPI_SWIGLU_BWD:
+            FM_CHECK_ARG(p->res && p->ldr % 4 == 0 && p->Hp % 4 == 0 && p->Hp >= p->N && p->ldo >= 2 * p->Hp && p->ldr >= 2 * p->Hp,
+                         "fm_gemm_nt: SwiGLU-backward epilogue needs res=(g|u) and out=(dg|du) of width 2*Hp");
+            return launch_nt<EPI_SWIGLU_BWD, false>(a, max_n, s);
+        case FM_EPI_GELU_BWD:
+            FM_CHECK_ARG(p->res && p->ldr % 4 == 0, "fm_gemm_nt: GELU-backward epilogue needs res = pre-activation");
+            return launch_nt<EPI_GELU_BWD, false>(a, max_n, s);
     }
     fm_set_error("fm_gemm_nt: unknown epilogue %d", p->epilogue);
     return -1;

@@ -64,16 +64,77 @@ __global__ void fill_i32_kernel(int32_t* p, int v, int n) {
     if (i < n) p[i] = v;
 }
 
-// one workgroup per padded row: loss_row = logsumexp(logits) - logits[target];
-// logits (bf16) are overwritten by d(loss)/d(logits) = (softmax - onehot) * w_head  (zero in pad rows / columns)
-__global__ __launch_bounds__(256) void ce_kernel(bf16_t* __restrict__ logits, int ldl, const int32_t* __restrict__ perm,
-                                                 const int32_t* __restrict__ tile_group, const long long* __restrict__ target_ids,
-                                                 const int32_t* __restrict__ vocab, const int32_t* __restrict__ seg_count,
-                                                 const float* __restrict__ gscale, int loss_type, int n_heads,
-                                                 float* __restrict__ row_loss, int write_grad) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* vals = (float*)smem;          // the row, fp32
-    __shared__ float red[4];
+// Forward: one workgroup per padded row, ONE streaming pass over the bf16 logits (online max / sum of
+// exponentials per thread, merged across the workgroup): row_loss = lse - logits[target], row_lse kept
+// for the backward.  Nothing is staged in LDS, so many rows are in flight per CU.
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16_t* __restrict__ logits, int ldl, const int32_t* __restrict__ perm,
+                                                     const int32_t* __restrict__ tile_group, const long long* __restrict__ target_ids,
+                                                     const int32_t* __restrict__ vocab, float* __restrict__ row_loss, float* __restrict__ row_lse) {
+    __shared__ float red_m[4], red_s[4];
+    const int pr = blockIdx.x;
+    const int g = tile_group[pr / SEG_ALIGN];
+    if (g < 0) return;
+    const int src = perm[pr];
+    if (src < 0) {
+        if (threadIdx.x == 0) { row_loss[pr] = 0.f; row_lse[pr] = 0.f; }
+        return;
+    }
+    const int V = vocab[g];
+    const bf16_t* row = logits + (size_t)pr * ldl;
+    float m = -INFINITY, ssum = 0.f;
+    for (int c = threadIdx.x * 8; c < V; c += 256 * 8) {
+        float v[8];
+        if (c + 8 <= V) {
+            const uint4 p = *(const uint4*)(row + c);
+            const uint32_t w[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] = bf2f((bf16_t)(w[e] & 0xffff)); v[2 * e + 1] = bf2f((bf16_t)(w[e] >> 16)); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = c + e < V ? bf2f(row[c + e]) : -INFINITY;
+        }
+        float cm = v[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) cm = fmaxf(cm, v[e]);
+        const float mn = fmaxf(m, cm);
+        float add = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) add += __expf(v[e] - mn);
+        ssum = ssum * __expf(m - mn) + add;
+        m = mn;
+    }
+    // merge across the wave, then across the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(ssum, o, 64);
+        if (m2 > -INFINITY || m > -INFINITY) online_merge(m, ssum, m2, s2);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red_m[wave] = m; red_s[wave] = ssum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float M = red_m[0], S = red_s[0];
+        for (int w = 1; w < 4; ++w)
+            if (red_m[w] > -INFINITY) online_merge(M, S, red_m[w], red_s[w]);
+        const float lse = M + __logf(S);
+        row_lse[pr] = lse;
+        row_loss[pr] = lse - bf2f(row[target_ids[src]]);
+    }
+}
+
+// Backward: logits (bf16) are overwritten in place by d(total)/d(logits) = (exp(x - lse) - onehot) * w_head
+// (zero in pad rows and in the pad columns up to roundup64(vocab)): one read + one write per element.
+__global__ __launch_bounds__(256) void ce_bwd_kernel(bf16_t* __restrict__ logits, int ldl, const int32_t* __restrict__ perm,
+                                                     const int32_t* __restrict__ tile_group, const long long* __restrict__ target_ids,
+                                                     const int32_t* __restrict__ vocab, const int32_t* __restrict__ seg_count,
+                                                     const float* __restrict__ gscale, int loss_type, int n_heads,
+                                                     const float* __restrict__ row_lse) {
     const int pr = blockIdx.x;
     const int g = tile_group[pr / SEG_ALIGN];
     if (g < 0) return;
@@ -82,50 +143,30 @@ __global__ __launch_bounds__(256) void ce_kernel(bf16_t* __restrict__ logits, in
     bf16_t* row = logits + (size_t)pr * ldl;
     const int src = perm[pr];
     if (src < 0) {   // pad row of a live segment: gradient must read as zero in the dW / dX GEMMs
-        if (write_grad)
-            for (int c = threadIdx.x; c < Vp / 4; c += 256) *(uint2*)(row + c * 4) = make_uint2(0u, 0u);
-        if (threadIdx.x == 0) row_loss[pr] = 0.f;
+        for (int c = threadIdx.x; c < Vp / 8; c += 256) *(uint4*)(row + c * 8) = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float mx = -INFINITY;
-    for (int c = threadIdx.x; c < V / 4; c += 256) {
-        const uint2 p = *(const uint2*)(row + c * 4);
-        const float4 v = make_float4(bf2f((bf16_t)(p.x & 0xffff)), bf2f((bf16_t)(p.x >> 16)), bf2f((bf16_t)(p.y & 0xffff)), bf2f((bf16_t)(p.y >> 16)));
-        *(float4*)(vals + c * 4) = v;
-        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-    }
-    for (int c = (V / 4) * 4 + threadIdx.x; c < V; c += 256) { vals[c] = bf2f(row[c]); mx = fmaxf(mx, vals[c]); }
-    mx = wave_max(mx);
-    if (lane == 0) red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float sum = 0.f;
-    for (int c = threadIdx.x; c < V; c += 256) sum += __expf(vals[c] - mx);
-    sum = wave_sum(sum);
-    if (lane == 0) red[wave] = sum;
-    __syncthreads();
-    sum = (red[0] + red[1]) + (red[2] + red[3]);
-    const long long tgt = target_ids[src];
-    if (threadIdx.x == 0) row_loss[pr] = (mx + __logf(sum)) - vals[tgt];
-    if (!write_grad) return;
-    // weight of this row in the total loss
     float w;
-    const float cnt = (float)seg_count[g];
     if (loss_type == FM_LOSS_MOD) {
-        w = 1.0f / (cnt * (float)n_heads);
+        w = 1.0f / ((float)seg_count[g] * (float)n_heads);
     } else {   // FM_LOSS_TOKEN: heads weighted by logits.numel() = rows * vocab (fm.py:633-635)
         float tot = 0.f;
-        for (int m = 0; m < n_heads; ++m) tot += (float)seg_count[m] * (float)vocab[m];
+        for (int mm = 0; mm < n_heads; ++mm) tot += (float)seg_count[mm] * (float)vocab[mm];
         w = (float)V / tot;
     }
     w *= gscale ? gscale[0] : 1.0f;
-    const float inv = 1.0f / sum;
-    for (int c = threadIdx.x; c < Vp; c += 256) {
-        float gval = 0.f;
-        if (c < V) gval = (__expf(vals[c] - mx) * inv - (c == tgt ? 1.f : 0.f)) * w;
-        row[c] = f2bf(gval);
+    const float lse = row_lse[pr];
+    const int tgt = (int)target_ids[src];
+    for (int c = threadIdx.x * 8; c < Vp; c += 256 * 8) {
+        const uint4 p = *(const uint4*)(row + c);
+        const uint32_t wd[4] = {p.x, p.y, p.z, p.w};
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = bf2f((bf16_t)((e & 1) ? (wd[e >> 1] >> 16) : (wd[e >> 1] & 0xffff)));
+            o[e] = (c + e < V) ? (__expf(x - lse) - ((c + e) == tgt ? 1.f : 0.f)) * w : 0.f;
+        }
+        *(uint4*)(row + c) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
     }
 }
 
@@ -197,20 +238,22 @@ extern "C" int fm_gather_rows(const void* src, int ld_src, const int32_t* perm, 
 
 extern "C" int fm_cross_entropy(void* logits, int ldl, const int32_t* perm, const int32_t* tile_group, const int64_t* target_ids,
                                 const int32_t* vocab, const int32_t* seg_start, const int32_t* seg_count, const void* grad_scale,
-                                int loss_type, int n_heads, int Rp, int max_vocab, void* row_loss, void* head_loss, void* total_loss,
-                                int write_grad, void* stream) {
-    FM_CHECK_ARG(logits && perm && tile_group && target_ids && vocab && seg_start && seg_count && row_loss && head_loss && total_loss,
+                                int loss_type, int n_heads, int Rp, int max_vocab, void* row_loss, void* row_lse, void* head_loss,
+                                void* total_loss, int write_grad, void* stream) {
+    FM_CHECK_ARG(logits && perm && tile_group && target_ids && vocab && seg_start && seg_count && row_loss && row_lse && head_loss && total_loss,
                  "fm_cross_entropy: null pointer");
     FM_CHECK_ARG(loss_type == FM_LOSS_MOD || loss_type == FM_LOSS_TOKEN, "fm_cross_entropy: invalid loss type %d", loss_type);
-    FM_CHECK_ARG(ldl % 4 == 0 && ldl >= (max_vocab + 63) / 64 * 64, "fm_cross_entropy: ldl=%d too small for vocab %d", ldl, max_vocab);
-    const size_t lds = (size_t)max_vocab * sizeof(float);
-    FM_CHECK_ARG(lds <= 150 * 1024, "fm_cross_entropy: vocab %d does not fit the LDS row buffer", max_vocab);
-    static bool once = (hipFuncSetAttribute((const void*)ce_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess);
-    (void)once;
-    hipLaunchKernelGGL(ce_kernel, dim3(Rp), dim3(256), lds, (hipStream_t)stream, (bf16_t*)logits, ldl, perm, tile_group,
-                       (const long long*)target_ids, vocab, seg_count, (const float*)grad_scale, loss_type, n_heads, (float*)row_loss, write_grad);
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)row_loss, seg_start, seg_count,
-                       vocab, n_heads, loss_type, (float*)head_loss, (float*)total_loss);
+    FM_CHECK_ARG(ldl % 8 == 0 && ldl >= (max_vocab + 63) / 64 * 64, "fm_cross_entropy: ldl=%d too small for vocab %d", ldl, max_vocab);
+    FM_CHECK_ARG((((uintptr_t)logits) & 15) == 0, "fm_cross_entropy: logits must be 16-byte aligned");
+    if (!write_grad) {
+        hipLaunchKernelGGL(ce_fwd_kernel, dim3(Rp), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ldl, perm, tile_group,
+                           (const long long*)target_ids, vocab, (float*)row_loss, (float*)row_lse);
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)row_loss, seg_start, seg_count,
+                           vocab, n_heads, loss_type, (float*)head_loss, (float*)total_loss);
+    } else {
+        hipLaunchKernelGGL(ce_bwd_kernel, dim3(Rp), dim3(256), 0, (hipStream_t)stream, (bf16_t*)logits, ldl, perm, tile_group,
+                           (const long long*)target_ids, vocab, seg_count, (const float*)grad_scale, loss_type, n_heads, (const float*)row_lse);
+    }
     FM_CHECK_LAUNCH("fm_cross_entropy");
     return 0;
 }

@@ -33,7 +33,7 @@ if lib.fm_abi_version() != ABI_VERSION:
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # enums (keep in sync with the header; tests/test_abi.py cross-checks them against the header text)
-EPI_BF16, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32, EPI_TANH = 0, 1, 2, 3, 4, 5
+EPI_BF16, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32, EPI_TANH, EPI_SWIGLU_BWD, EPI_GELU_BWD = 0, 1, 2, 3, 4, 5, 6, 7
 MASK_NONE, MASK_KEYPAD, MASK_DECODER, MASK_DENSE = 0, 1, 2, 3
 KIND_TOK, KIND_PATCH, KIND_SEQ, KIND_SEQ_EMB = 0, 1, 2, 3
 LOSS_MOD, LOSS_TOKEN = 0, 1
@@ -70,6 +70,11 @@ class ModDesc(C.Structure):
                 ("L", i32), ("kind", i32), ("ids_are_i64", i32), ("mod_id", i32), ("max_len", i32), ("shifted", i32),
                 ("mask_stride", i32), ("id_stride", i32), ("patch", i32), ("channels", i32), ("grid_w", i32),
                 ("orig_dim", i32), ("head_index", i32), ("pad_", i32)]
+
+
+class ShadowDesc(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("ld_src", i32), ("ld_dst", i32), ("rows", i32), ("cols", i32),
+                ("transpose", i32), ("tile_start", i32)]
 
 
 class SelectDesc(C.Structure):
@@ -112,12 +117,13 @@ embed_bwd = _sig("fm_embed_bwd", P(EmbedBwdDesc), vp)
 dense_decoder_mask = _sig("fm_dense_decoder_mask", vp, vp, vp, i32, i32, i32, i32, i32, vp)
 segment_rows = _sig("fm_segment_rows", vp, i32, i32, vp, vp, vp, vp, vp, i32, vp)
 gather_rows = _sig("fm_gather_rows", vp, i32, vp, vp, i32, i32, i32, vp)
-cross_entropy = _sig("fm_cross_entropy", vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp)
+cross_entropy = _sig("fm_cross_entropy", vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp)
 swiglu_bwd = _sig("fm_swiglu_bwd", vp, i32, vp, i32, vp, i32, i32, i32, i32, vp)
 gelu_bwd = _sig("fm_gelu_bwd", vp, i32, vp, i32, vp, i32, i32, i32, i32, vp)
 cast_pad = _sig("fm_cast_pad", vp, i32, vp, i32, i32, i32, vp)
 transpose_cast_pad = _sig("fm_transpose_cast_pad", vp, i32, vp, i32, i32, i32, i32, vp)
 colsum = _sig("fm_colsum", vp, i32, vp, i32, i32, vp)
+shadow_refresh = _sig("fm_shadow_refresh", vp, i32, i32, vp)
 f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
 adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp)
 sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
@@ -133,7 +139,7 @@ EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_conf
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
-           "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_colsum", "fm_f32_to_bf16", "fm_adamw",
+           "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_colsum", "fm_f32_to_bf16", "fm_adamw",
            "fm_sumsq", "fm_clip_coef", "fm_vq_patchify", "fm_l2norm_rows", "fm_vq_assign"]
 
 

@@ -38,12 +38,12 @@ def ru(x, m):
 
 
 class Shadow:
-    """bf16 copies of one Linear weight (out, in): ``w`` (out, in_p) and ``wt`` (in, out_p), each rebuilt
-    lazily when the fp32 master changed."""
-    __slots__ = ("param", "w", "wt", "stamp_w", "stamp_wt")
+    """One bf16 weight shadow: ``buf`` plus the jobs (fp32 master view -> bf16 view, transpose) that fill it and
+    the stamp of the masters it was last built from."""
+    __slots__ = ("buf", "params", "jobs", "stamp")
 
-    def __init__(self, param):
-        self.param, self.w, self.wt, self.stamp_w, self.stamp_wt = param, None, None, None, None
+    def __init__(self, buf, params, jobs):
+        self.buf, self.params, self.jobs, self.stamp = buf, params, jobs, None
 
 
 class Workspace:
@@ -88,7 +88,8 @@ class FourMEngine:
         self.scale = 64 ** -0.5
         self.eps = blk.norm1.eps
         self.ws: Optional[Workspace] = None
-        self.shadows: Dict[int, Shadow] = {}
+        self.shadows: Dict[tuple, Shadow] = {}
+        self._shadow_table = None
         self.flat_params = self.flat_grads = None
         self._slices = {}
         self._ctx = None           # saved state of the last training forward
@@ -193,50 +194,56 @@ class FourMEngine:
     # ------------------------------------------------------------------------------------------
     # weight shadows
     # ------------------------------------------------------------------------------------------
-    def _shadow(self, p) -> Shadow:
-        s = self.shadows.get(id(p))
-        if s is None:
-            s = self.shadows[id(p)] = Shadow(p)
-        return s
+    def _stamp(self, params):
+        return tuple((p._version, _WEIGHT_EPOCH, p.data_ptr()) for p in params)
 
-    def _stamp(self, p):
-        return (p._version, _WEIGHT_EPOCH, p.data_ptr())
+    def _get_shadow(self, key, make) -> torch.Tensor:
+        s = self.shadows.get(key)
+        if s is None:
+            s = self.shadows[key] = make()
+        if s.stamp != self._stamp(s.params):
+            self._refresh_shadows()
+        return s.buf
+
+    def _refresh_shadows(self):
+        """Rebuild EVERY stale shadow in one launch (after an optimizer step that is all of them: one table
+        walk instead of ~250 small cast / transpose launches)."""
+        stale = [s for s in self.shadows.values() if s.stamp != self._stamp(s.params)]
+        jobs = []
+        for s in stale:
+            jobs += [(p.detach().reshape(p.shape[0], -1), dst, tr) for (p, dst, tr) in s.jobs]
+        sig = tuple((a.data_ptr(), b.data_ptr(), tr) for (a, b, tr) in jobs)
+        if self._shadow_table is None or self._shadow_table[0] != sig:
+            table, tiles = ops.shadow_jobs_table(jobs, self.device)
+            self._shadow_table = (sig, table, len(jobs), tiles)
+        _, table, n, tiles = self._shadow_table
+        ops.shadow_refresh(table, n, tiles)
+        for s in stale:
+            s.stamp = self._stamp(s.params)
 
     def w(self, p):
         """(out, in_p) bf16, pad columns zero: the W operand of y = x W^T."""
-        s = self._shadow(p)
-        stamp = self._stamp(p)
-        if s.stamp_w != stamp:
+        def make():
             out_f, in_f = p.shape[0], p[0].numel()
-            if s.w is None or s.w.device != p.device:
-                s.w = torch.zeros(out_f, ru(in_f, 64), dtype=torch.bfloat16, device=p.device)
-            ops.cast_pad(p.detach(), s.w)
-            s.stamp_w = stamp
-        return s.w
+            buf = torch.zeros(out_f, ru(in_f, 64), dtype=torch.bfloat16, device=p.device)
+            return Shadow(buf, (p,), [(p, buf, False)])
+        return self._get_shadow(("w", id(p)), make)
 
     def wt(self, p):
         """(in, out_p) bf16, pad columns zero: the W operand of dX = dY W."""
-        s = self._shadow(p)
-        stamp = self._stamp(p)
-        if s.stamp_wt != stamp:
+        def make():
             out_f, in_f = p.shape[0], p[0].numel()
-            if s.wt is None or s.wt.device != p.device:
-                s.wt = torch.zeros(in_f, ru(out_f, 64), dtype=torch.bfloat16, device=p.device)
-            ops.transpose_cast_pad(p.detach(), s.wt)
-            s.stamp_wt = stamp
-        return s.wt
+            buf = torch.zeros(in_f, ru(out_f, 64), dtype=torch.bfloat16, device=p.device)
+            return Shadow(buf, (p,), [(p, buf, True)])
+        return self._get_shadow(("wt", id(p)), make)
 
     def w13t(self, mlp):
         """(D, 2*Hp) bf16 = [fc1^T | fc3^T]: the W operand of d(h2) = [dg | du] [fc1; fc3]."""
-        key = ("w13t", id(mlp))
-        ent = self.shadows.get(key)
-        stamp = (self._stamp(mlp.fc1.weight), self._stamp(mlp.fc3.weight))
-        if ent is None or ent[1] != stamp:
-            buf = ent[0] if ent is not None else torch.zeros(self.D, 2 * self.Hp, dtype=torch.bfloat16, device=self.device)
-            ops.transpose_cast_pad(mlp.fc1.weight.detach(), buf[:, :self.Hp])
-            ops.transpose_cast_pad(mlp.fc3.weight.detach(), buf[:, self.Hp:])
-            self.shadows[key] = ent = (buf, stamp)
-        return ent[0]
+        def make():
+            buf = torch.zeros(self.D, 2 * self.Hp, dtype=torch.bfloat16, device=self.device)
+            p1, p3 = mlp.fc1.weight, mlp.fc3.weight
+            return Shadow(buf, (p1, p3), [(p1, buf[:, :self.Hp], True), (p3, buf[:, self.Hp:], True)])
+        return self._get_shadow(("w13t", id(mlp)), make)
 
     # ------------------------------------------------------------------------------------------
     # selection + embedding
@@ -540,6 +547,7 @@ class FourMEngine:
         ops.gemm_nt_grouped(yp, hs["g_fwd"], hs["tile_group"], logits, hs["maxV"])
         hs.update(yp=yp, logits=logits, sv=sv)
         hs["row_loss"] = ws.get("heads.row_loss", (Rp,), torch.float32)
+        hs["row_lse"] = ws.get("heads.row_lse", (Rp,), torch.float32)
         hs["head_loss"] = ws.get("heads.head_loss", (nH,), torch.float32)
         hs["total"] = ws.get("heads.total", (1,), torch.float32)
         return hs
@@ -548,7 +556,7 @@ class FourMEngine:
         lt = L.LOSS_MOD if loss_type in ("mod", "modality") else L.LOSS_TOKEN
         hs["loss_type"] = lt
         ops.cross_entropy(hs["logits"], hs["perm"], hs["tile_group"], dec["target_ids"].view(-1), hs["vocab_t"], hs["seg_start"],
-                          hs["seg_count"], hs["n"], hs["maxV"], hs["row_loss"], hs["head_loss"], hs["total"], loss_type=lt)
+                          hs["seg_count"], hs["n"], hs["maxV"], hs["row_loss"], hs["row_lse"], hs["head_loss"], hs["total"], loss_type=lt)
         return hs["total"], hs["head_loss"]
 
     def dec_order(self, mod_dict):
@@ -601,18 +609,17 @@ class FourMEngine:
         R64 = ru(R, 64)
         ws = self.ws
         self._dW(g_bf, sv["act"], mlp.fc2, R64)
-        da = ws.get("bwd.da", (Rp, Hp), bf)
-        ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), da, M=R, N=Hd, K=D)
         dh = ws.get("bwd.dh", (Rp, D), bf)
+        # d(act) = g · W2 never reaches HBM: the activation backward runs in the GEMM epilogue on the saved (g | u) / pre
         if self.gated:
             dgu = ws.get("bwd.dgu", (Rp, 2 * Hp), bf)
-            ops.swiglu_bwd(da, sv["gu"], dgu, Hd, Hp, R=R)
+            ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), dgu, M=R, N=Hd, K=D, epilogue=L.EPI_SWIGLU_BWD, res=sv["gu"], Hp=Hp)
             self._dW(dgu[:, :Hp], sv["h2"], mlp.fc1, R64, n_cols=Hd)
             self._dW(dgu[:, Hp:], sv["h2"], mlp.fc3, R64, n_cols=Hd)
             ops.gemm_nt(dgu, self.w13t(mlp), dh, M=R, N=D, K=2 * Hp)
         else:
             dpre = ws.get("bwd.dpre", (Rp, Hp), bf)
-            ops.gelu_bwd(da, sv["pre"], dpre, Hd, Hp, R=R)
+            ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), dpre, M=R, N=Hd, K=D, epilogue=L.EPI_GELU_BWD, res=sv["pre"])
             self._dW(dpre, sv["h2"], mlp.fc1, R64, n_cols=Hd)
             ops.gemm_nt(dpre, self.wt(mlp.fc1.weight), dh, M=R, N=D, K=Hp)
         return dh
@@ -721,8 +728,8 @@ class FourMEngine:
         Rqp, Rcp = st["y_final"].shape[0], st["x_final"].shape[0]
         # ---- heads: d(logits) in place, then dY (grouped NT) and dW_head (grouped TN) -----------------
         ops.cross_entropy(hs["logits"], hs["perm"], hs["tile_group"], dec["target_ids"].view(-1), hs["vocab_t"], hs["seg_start"],
-                          hs["seg_count"], hs["n"], hs["maxV"], hs["row_loss"], hs["head_loss"], hs["total"], loss_type=hs["loss_type"],
-                          grad_scale=grad_scale, write_grad=True)
+                          hs["seg_count"], hs["n"], hs["maxV"], hs["row_loss"], hs["row_lse"], hs["head_loss"], hs["total"],
+                          loss_type=hs["loss_type"], grad_scale=grad_scale, write_grad=True)
         dyp = ws.get("bwd.dyp", (hs["Rp"], D), bf)
         ops.gemm_nt_grouped(hs["logits"], hs["g_bwd"], hs["tile_group"], dyp, D)
         heads = [m.decoder_embeddings[h] for h in hs["heads"]]

@@ -203,10 +203,11 @@ def gather_rows(src, perm, dst, D):
     L.check(L.gather_rows(_p(src), _ld(src), _p(perm), _p(dst), _ld(dst), perm.numel(), D, _stream()))
 
 
-def cross_entropy(logits, perm, tile_group, target_ids, vocab, seg_start, seg_count, n_heads, max_vocab, row_loss, head_loss,
+def cross_entropy(logits, perm, tile_group, target_ids, vocab, seg_start, seg_count, n_heads, max_vocab, row_loss, row_lse, head_loss,
                   total_loss, *, loss_type=L.LOSS_MOD, grad_scale=None, write_grad=False):
+    """write_grad=False: forward (losses + row_lse); write_grad=True: in-place d(logits) from the saved row_lse."""
     L.check(L.cross_entropy(_p(logits), _ld(logits), _p(perm), _p(tile_group), _p(target_ids), _p(vocab), _p(seg_start),
-                            _p(seg_count), _p(grad_scale), loss_type, n_heads, perm.numel(), max_vocab, _p(row_loss),
+                            _p(seg_count), _p(grad_scale), loss_type, n_heads, perm.numel(), max_vocab, _p(row_loss), _p(row_lse),
                             _p(head_loss), _p(total_loss), 1 if write_grad else 0, _stream()))
 
 
@@ -234,6 +235,27 @@ def transpose_cast_pad(src, dst):
     s2 = src.reshape(src.shape[0], -1)
     L.check(L.transpose_cast_pad(_p(s2), s2.stride(0), _p(dst), _ld(dst), dst.shape[1], s2.shape[0], s2.shape[1], _stream()))
     return dst
+
+
+def shadow_jobs_table(jobs, device):
+    """jobs: list of (src f32 2-D view, dst bf16 2-D view, transpose) -> (device byte tensor of fm_shadow_desc, total tiles)."""
+    arr = (L.ShadowDesc * len(jobs))()
+    tiles = 0
+    for i, (src, dst, tr) in enumerate(jobs):
+        rows, cols = src.shape
+        need = (cols, rows) if tr else (rows, cols)
+        assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.stride(1) == 1 and dst.stride(1) == 1
+        assert dst.shape[0] >= need[0] and dst.shape[1] >= need[1], (tuple(dst.shape), need)
+        d = arr[i]
+        d.src, d.dst, d.ld_src, d.ld_dst = src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0)
+        d.rows, d.cols, d.transpose, d.tile_start = rows, cols, 1 if tr else 0, tiles
+        tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return raw, tiles
+
+
+def shadow_refresh(table, n_jobs, tiles):
+    L.check(L.shadow_refresh(_p(table), n_jobs, tiles, _stream()))
 
 
 def colsum(dy, db, N, R=None):

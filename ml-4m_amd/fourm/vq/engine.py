@@ -26,7 +26,7 @@ class _VitEngine(FourMEngine):
         self.Hd = blk.mlp.hidden_features
         self.Hp = ru(self.Hd, 64)
         self.scale, self.eps = 64 ** -0.5, blk.norm1.eps
-        self.ws, self.shadows, self._ctx, self.reducer = None, {}, None, None
+        self.ws, self.shadows, self._shadow_table, self._ctx, self.reducer = None, {}, None, None, None
         self.flat_params = self.flat_grads = None
         self._cache = {}
 

@@ -208,11 +208,14 @@ def test_gemm_grouped():
     tgt = torch.stack([torch.randint(0, 64, (R,), generator=torch.Generator().manual_seed(3))]).flatten().to(DEV)
     vocab_t = torch.tensor(vocabs, dtype=torch.int32, device=DEV)
     row_loss = torch.zeros(Rp, device=DEV); head_loss = torch.zeros(n_heads, device=DEV); total = torch.zeros(1, device=DEV)
+    row_lse = torch.zeros(Rp, device=DEV)
     saved = logits.clone()
     for loss_type, name in ((L.LOSS_MOD, "mod"), (L.LOSS_TOKEN, "token")):
         logits.copy_(saved)
         gs = torch.tensor([0.5], device=DEV)
-        ops.cross_entropy(logits, perm, tile_group, tgt, vocab_t, seg_start, seg_count, n_heads, max(vocabs), row_loss, head_loss,
+        ops.cross_entropy(logits, perm, tile_group, tgt, vocab_t, seg_start, seg_count, n_heads, max(vocabs), row_loss, row_lse, head_loss,
+                          total, loss_type=loss_type)
+        ops.cross_entropy(logits, perm, tile_group, tgt, vocab_t, seg_start, seg_count, n_heads, max(vocabs), row_loss, row_lse, head_loss,
                           total, loss_type=loss_type, grad_scale=gs, write_grad=True)
         leafs, losses, numel = [], [], []
         for h in range(n_heads):
@@ -391,6 +394,31 @@ def test_swiglu_gelu_bwd():
     assert rel_err(dpre[:, :H], pr.grad) < 6e-3 and float(dpre[:, H:].float().abs().max()) == 0
 
 
+@pytest.mark.parametrize("M,H,K", [(100, 170, 64), (300, 2730, 768)])
+def test_gemm_nt_activation_backward_epilogues(M, H, K):
+    """fc2 dX GEMM with the SwiGLU / GELU backward fused into its epilogue == plain GEMM followed by the
+    stand-alone element-wise kernels (bit-exact: same bf16 rounding points)."""
+    ops, L = _ops()
+    Hp = ops.ru(H, 64)
+    gy = bf(randn(M, K, scale=0.5, seed=60))
+    w2t = bf(randn(H, K, scale=0.1, seed=61))            # fc2.weight transposed: (hidden, D)
+    gu = torch.zeros(M, 2 * Hp, device=DEV, dtype=torch.bfloat16)
+    gu[:, :H], gu[:, Hp:Hp + H] = bf(randn(M, H, seed=62)), bf(randn(M, H, seed=63))
+    da = torch.zeros(M, Hp, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(gy, w2t, da, N=H, K=K)
+    want = torch.zeros(M, 2 * Hp, device=DEV, dtype=torch.bfloat16)
+    ops.swiglu_bwd(da, gu, want, H, Hp)
+    got = torch.zeros(M, 2 * Hp, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(gy, w2t, got, N=H, K=K, epilogue=L.EPI_SWIGLU_BWD, res=gu, Hp=Hp)
+    assert torch.equal(got, want)
+    pre = gu[:, :Hp].contiguous()
+    want_p = torch.zeros(M, Hp, device=DEV, dtype=torch.bfloat16)
+    ops.gelu_bwd(da, pre, want_p, H, Hp)
+    got_p = torch.zeros(M, Hp, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(gy, w2t, got_p, N=H, K=K, epilogue=L.EPI_GELU_BWD, res=pre)
+    assert torch.equal(got_p, want_p)
+
+
 def test_weight_shadows_and_colsum():
     ops, L = _ops()
     w = randn(170, 128, seed=60)
@@ -404,6 +432,31 @@ def test_weight_shadows_and_colsum():
     db = torch.ones(200, device=DEV)
     ops.colsum(dy, db, 200)
     assert rel_err(db - 1, dy.float().sum(0)) < 1e-5
+
+
+def test_shadow_refresh_multi_tensor():
+    """One launch, many (fp32 master -> bf16 shadow) jobs: plain casts, transposes, a transposed pair written into
+    column slices of one buffer, ragged shapes; padding must stay untouched."""
+    ops, L = _ops()
+    flat = randn(170 * 128 + 3 * 77 + 256 * 192 + 2 * 64 * 130 + 8, seed=80)
+    off = 0
+    def take(r, c):
+        nonlocal off
+        v = flat[off:off + r * c].view(r, c); off += r * c
+        return v
+    a, b, c_, d1, d3 = take(170, 128), take(3, 77), take(256, 192), take(64, 130), take(64, 130)
+    wa = torch.zeros(170, 128, device=DEV, dtype=torch.bfloat16)
+    wb = torch.full((3, 128), 7.0, device=DEV, dtype=torch.bfloat16)
+    wat = torch.full((128, 192), 7.0, device=DEV, dtype=torch.bfloat16)
+    wct = torch.zeros(192, 256, device=DEV, dtype=torch.bfloat16)
+    pair = torch.full((130, 2 * 64), 7.0, device=DEV, dtype=torch.bfloat16)
+    jobs = [(a, wa, False), (b, wb, False), (a, wat, True), (c_, wct, True), (d1, pair[:, :64], True), (d3, pair[:, 64:], True)]
+    table, tiles = ops.shadow_jobs_table(jobs, DEV)
+    ops.shadow_refresh(table, len(jobs), tiles)
+    assert torch.equal(wa, bf(a)) and torch.equal(wb[:, :77], bf(b)) and float((wb[:, 77:].float() - 7).abs().max()) == 0
+    assert torch.equal(wat[:, :170], bf(a.t())) and float((wat[:, 170:].float() - 7).abs().max()) == 0
+    assert torch.equal(wct, bf(c_.t()))
+    assert torch.equal(pair[:, :64], bf(d1.t())) and torch.equal(pair[:, 64:], bf(d3.t()))
 
 
 def test_adamw_matches_torch():
