@@ -61,8 +61,9 @@ typedef struct fm_gemm_nt_args {
     const fm_gemm_group* groups; const int32_t* tile_group; int32_t max_N, pad_;
 } fm_gemm_nt_args;
 int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
-/* tile configuration of fm_gemm_nt, for A/B measurements (table in csrc/gemm.hip): low byte 0-6 = fixed
- * configuration, 9 = automatic (default); +256 = raise the wave priority around the MFMA clusters. */
+/* tile configuration of fm_gemm_nt, for A/B measurements (table in csrc/gemm.hip): low byte 0-8 = fixed
+ * configuration, 9 = automatic (default); +256 = raise the wave priority around the MFMA clusters;
+ * bits 16-19 / 20-23 (when non-zero) = the configurations "automatic" picks for K < 1536 / K >= 1536. */
 void fm_set_gemm_nt_config(int cfg);
 int fm_get_gemm_nt_config(void);
 

@@ -51,7 +51,17 @@ __device__ __forceinline__ void block_barrier() {
 // counted (never a full drain inside the loop) and there is one workgroup barrier per K-tile.
 // KB = reduction elements per stage (64 or 32): LDS rows are KB*2 bytes, 16-byte chunks XOR-swizzled so that
 // the 16 rows a ds_read_b128 lane group touches fall on 16 different 16-byte bank slots.
-template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED>
+//
+// PP ("ping-pong", 8 waves, 3 stages): the two wave rows (waves 0-3 / 4-7; wave i and i+4 share a SIMD) run
+// the same loop one barrier apart, so that on every SIMD one wave is in its MFMA half while the other is in
+// its LDS-read half.  Every K-tile iteration is  [MEM: all fragment reads of the tile] barrier [MFMA: 16 or 8
+// MFMAs] barrier.  Wall-clock slots (between consecutive workgroup barriers) alternate
+//     even: row 0 MEM_k   | row 1 MFMA_{k-1}        odd: row 0 MFMA_k | row 1 MEM_k
+// All LDS-DMA for tile k+2 is issued, and each wave's counted wait for its pieces of tile k+1 is done, in the
+// ODD slot k by both rows, so the barrier closing that slot orders tile k+1 for row 0 (read in the next slot)
+// and for row 1 (one slot later).  Tile k+2 overwrites the buffer of tile k-1, whose last reads (row 1, odd
+// slot k-1) were retired by lgkmcnt(0) before that slot's closing barrier.
+template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false>
 __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     constexpr int NWAVES = WW * WX;
     constexpr int RB = KB * 2;                                 // bytes per LDS row
@@ -84,36 +94,45 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     const int n0 = tw * NPT, m0 = tx * TX;
     if (n0 >= N) return;
 
-    // ---- staging: each wave-instruction moves RPP rows x RB bytes ------------------------------
+    // ---- staging: each wave-instruction moves RPP rows x RB bytes; the per-lane source addresses only
+    // advance by KB elements per K-tile, so they are computed once -------------------------------
+    constexpr int PW = TW / (RPP * NWAVES), PX = TX / (RPP * NWAVES);
+    const bf16_t* wsrc[PW];
+    const bf16_t* xsrc[PX];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) {
+        const int t = (p * NWAVES + wave) * RPP + lane / CPR;
+        const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
+        if constexpr (EPI == EPI_SWIGLU) {
+            // rows [0,32) of every 64-row group come from W (g), rows [32,64) from W2 (u), same hidden units
+            int n = n0 + (t >> 6) * 32 + (t & 31);
+            n = n < N ? n : N - 1;
+            wsrc[p] = (((t >> 5) & 1) ? a.W2 : Wp) + (size_t)n * ldw + lc * 8;
+        } else {
+            int n = n0 + t;
+            n = n < N ? n : N - 1;
+            wsrc[p] = Wp + (size_t)n * ldw + lc * 8;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        const int t = (p * NWAVES + wave) * RPP + lane / CPR;
+        const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
+        int m = m0 + t;
+        m = m < a.M ? m : a.M - 1;
+        xsrc[p] = a.X + (size_t)m * a.ldx + lc * 8;
+    }
+    auto stage_w = [&](int kt, int buf, int p) {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[p] + kt * KB), LDS_PTR(smem + buf * STAGE + (p * NWAVES + wave) * 1024), 16, 0, 0);
+    };
+    auto stage_x = [&](int kt, int buf, int p) {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(xsrc[p] + kt * KB), LDS_PTR(smem + buf * STAGE + TW * RB + (p * NWAVES + wave) * 1024), 16, 0, 0);
+    };
     auto stage = [&](int kt, int buf) {
-        char* base = smem + buf * STAGE;
-        const int k0 = kt * KB;
 #pragma unroll
-        for (int p = 0; p < TW / (RPP * NWAVES); ++p) {
-            const int t = (p * NWAVES + wave) * RPP + lane / CPR;
-            const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
-            const bf16_t* src;
-            if constexpr (EPI == EPI_SWIGLU) {
-                // rows [0,32) of every 64-row group come from W (g), rows [32,64) from W2 (u), same hidden units
-                int n = n0 + (t >> 6) * 32 + (t & 31);
-                n = n < N ? n : N - 1;
-                src = (((t >> 5) & 1) ? a.W2 : Wp) + (size_t)n * ldw + k0 + lc * 8;
-            } else {
-                int n = n0 + t;
-                n = n < N ? n : N - 1;
-                src = Wp + (size_t)n * ldw + k0 + lc * 8;
-            }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + (p * NWAVES + wave) * 1024), 16, 0, 0);
-        }
+        for (int p = 0; p < PW; ++p) stage_w(kt, buf, p);
 #pragma unroll
-        for (int p = 0; p < TX / (RPP * NWAVES); ++p) {
-            const int t = (p * NWAVES + wave) * RPP + lane / CPR;
-            const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
-            int m = m0 + t;
-            m = m < a.M ? m : a.M - 1;
-            const bf16_t* src = a.X + (size_t)m * a.ldx + k0 + lc * 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + TW * RB + (p * NWAVES + wave) * 1024), 16, 0, 0);
-        }
+        for (int p = 0; p < PX; ++p) stage_x(kt, buf, p);
     };
 
     f32x16_t acc[FW][FX];
@@ -134,39 +153,93 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     const int fswz = (frow >> SWSH) & (CPR - 1);         // swizzle key (fragment bases are multiples of 32)
     const int fhi = lane >> 5;
 
-    int buf = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        // tile kt has landed once at most min(STAGES-2, KT-1-kt) younger stages are still in flight
-        const int younger = KT - 1 - kt;
-        if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LOADS>();
-        else if (STAGES >= 3 && younger >= 1) wait_vmcnt<LOADS>();
-        else wait_vmcnt<0>();
-        block_barrier();      // everyone's pieces of tile kt are in LDS; everyone is done reading tile kt-1
-        if (kt + STAGES - 1 < KT) stage(kt + STAGES - 1, (buf + STAGES - 1) % STAGES);
-        const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * RB;
-        const char* xt = smem + buf * STAGE + TW * RB + (wx * (TX / WX) + frow) * RB;
-        // fragments of step kk+1 are read from LDS while the MFMAs of step kk execute
-        bf16x8_t wf[2][FW], xf[2][FX];
-        auto load_frags = [&](int kk, int par) {
-            const int off = ((kk * 2 + fhi) ^ fswz) * 16;
+    if constexpr (PP) {
+        static_assert(WW == 2 && NWAVES == 8 && STAGES == 3, "ping-pong schedule: 2 wave rows of 4 waves, 3-deep ring");
+        constexpr int KS = KB / 16;                          // MFMA k-steps per K-tile
+        constexpr int PIECES = PW + PX;
+        const bool lead = ww == 0;
+        if (KT > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        block_barrier();                                     // tile 0 is in LDS for everyone
+        if (!lead) block_barrier();                          // the trailing row runs one barrier behind
+        int buf = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool more = kt + 2 < KT;
+            const int nbuf = buf >= 1 ? buf - 1 : 2;         // (buf + 2) % 3: the buffer tile kt-1 lived in
+            // ---- MEM half: every fragment of tile kt ------------------------------------------------
+            const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * RB;
+            const char* xt = smem + buf * STAGE + TW * RB + (wx * (TX / WX) + frow) * RB;
+            bf16x8_t wf[KS][FW], xf[KS][FX];
 #pragma unroll
-            for (int i = 0; i < FW; ++i) wf[par][i] = *(const bf16x8_t*)(wt + i * 32 * RB + off);
+            for (int kk = 0; kk < KS; ++kk) {
+                const int off = ((kk * 2 + fhi) ^ fswz) * 16;
 #pragma unroll
-            for (int j = 0; j < FX; ++j) xf[par][j] = *(const bf16x8_t*)(xt + j * 32 * RB + off);
-        };
-        load_frags(0, 0);
+                for (int i = 0; i < FW; ++i) wf[kk][i] = *(const bf16x8_t*)(wt + i * 32 * RB + off);
 #pragma unroll
-        for (int kk = 0; kk < KB / 16; ++kk) {
-            if (kk + 1 < KB / 16) load_frags(kk + 1, (kk + 1) & 1);
+                for (int j = 0; j < FX; ++j) xf[kk][j] = *(const bf16x8_t*)(xt + j * 32 * RB + off);
+            }
+            if (!lead) {                                     // odd slot: the trailing row stages from its MEM half
+                if (more) { stage(kt + 2, nbuf); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
+            }
+            wait_lgkmcnt<0>();
+            block_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- MFMA half (the leading row also stages here: same odd slot) -------------------------
             if (a.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < FW; ++i)
+            for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
-                for (int j = 0; j < FX; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], xf[kk & 1][j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < FW; ++i)
+#pragma unroll
+                    for (int j = 0; j < FX; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
+                if (lead && more) {                          // DMA pieces spread between the MFMA groups
+#pragma unroll
+                    for (int q = kk * PIECES / KS; q < (kk + 1) * PIECES / KS; ++q) {
+                        if (q < PW) stage_w(kt + 2, nbuf, q); else stage_x(kt + 2, nbuf, q - PW);
+                    }
+                }
+            }
             if (a.prio) __builtin_amdgcn_s_setprio(0);
+            if (lead) { if (more) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (lead || kt + 1 < KT) block_barrier();        // barrier counts: lead 1+2*KT, trailing 2+2*KT-1
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
         }
-        buf = buf + 1 == STAGES ? 0 : buf + 1;
+    } else {
+        int buf = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            // tile kt has landed once at most min(STAGES-2, KT-1-kt) younger stages are still in flight
+            const int younger = KT - 1 - kt;
+            if (STAGES >= 4 && younger >= 2) wait_vmcnt<2 * LOADS>();
+            else if (STAGES >= 3 && younger >= 1) wait_vmcnt<LOADS>();
+            else wait_vmcnt<0>();
+            block_barrier();      // everyone's pieces of tile kt are in LDS; everyone is done reading tile kt-1
+            if (kt + STAGES - 1 < KT) stage(kt + STAGES - 1, (buf + STAGES - 1) % STAGES);
+            const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * RB;
+            const char* xt = smem + buf * STAGE + TW * RB + (wx * (TX / WX) + frow) * RB;
+            // fragments of step kk+1 are read from LDS while the MFMAs of step kk execute
+            bf16x8_t wf[2][FW], xf[2][FX];
+            auto load_frags = [&](int kk, int par) {
+                const int off = ((kk * 2 + fhi) ^ fswz) * 16;
+#pragma unroll
+                for (int i = 0; i < FW; ++i) wf[par][i] = *(const bf16x8_t*)(wt + i * 32 * RB + off);
+#pragma unroll
+                for (int j = 0; j < FX; ++j) xf[par][j] = *(const bf16x8_t*)(xt + j * 32 * RB + off);
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < KB / 16; ++kk) {
+                if (kk + 1 < KB / 16) load_frags(kk + 1, (kk + 1) & 1);
+                if (a.prio) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < FW; ++i)
+#pragma unroll
+                    for (int j = 0; j < FX; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][i], xf[kk & 1][j], acc[i][j], 0, 0, 0);
+                if (a.prio) __builtin_amdgcn_s_setprio(0);
+            }
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
+        }
     }
 
     // ---- epilogue: lane holds, per fragment, 4 groups of 4 consecutive features of one row ---
@@ -239,7 +312,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float d = bfround(v[e]);
-                            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-gv[e]));
+                            const float sg = 1.0f / (1.0f + __expf(-gv[e]));
                             const float sl = bfround(gv[e] * sg);
                             const float ds = bfround(d * uv[e]);
                             const bool live = n + e < N;
@@ -443,15 +516,16 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
 }
 
 int g_nt_config = 9, g_nt_prio = 1;
+int g_nt_auto[2] = {2, 1};          // automatic choice for short / long (K >= 1536) reductions
 
-template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED>
+template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false>
 int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (max_n + NPT - 1) / NPT;
     a.n_tiles_x = (a.M + TX - 1) / TX;
     const int grid = a.n_tiles_w * a.n_tiles_x;
     const size_t lds = (size_t)STAGES * (TW + TX) * KB * 2;
-    auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED>;
+    auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED, PP>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WW * WX * 64), lds, s, a);
@@ -460,35 +534,31 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
 }
 
 // Tile configurations (fm_set_gemm_nt_config):
-//   0  128(feat) x 128(rows), 4 waves, K-step 64, 3 stages                 (grouped path; small problems)
+//   0  128(feat) x 128(rows), 4 waves, K-step 64, 3 stages
 //   1  128 x 256, 8 waves (64x64 wave tiles), K-step 64, 3 stages, 144 KB  (1 workgroup / CU)
 //   2  128 x 256, 8 waves, K-step 32, 3 stages, 72 KB                      (2 workgroups / CU: epilogue overlap)
-//   3  128 x 256, 4 waves (64x128 wave tiles), K-step 64, 3 stages
-//   4  256 x 256, 8 waves (128x64 wave tiles), K-step 64, 2 stages, 128 KB
-//   5  128 x 256, 4 waves (64x128 wave tiles), K-step 32, 3 stages, 72 KB  (2 workgroups / CU)
-//   6  128 x 128, 4 waves, K-step 32, 3 stages, 48 KB                      (3 workgroups / CU)
+//   6  128 x 128, 4 waves, K-step 32, 3 stages, 48 KB                      (3 workgroups / CU; grouped path)
+//   7  as 1 with the ping-pong schedule (wave rows one barrier apart: LDS reads of one row under the MFMAs of the other)
+//   8  as 2 with the ping-pong schedule
 //   +256: s_setprio(1) around the MFMA clusters
 //   9  automatic (default): configuration 1 for long reductions (K >= 1536), else 2
 template <int EPI, bool GROUPED>
 int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     // grouped rows are segmented in 128-row tiles, so that path keeps the 128-row X tile
     if (GROUPED || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
-    if (g_nt_config == 0) return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, GROUPED>(a, max_n, s);
-    if (g_nt_config == 9) {
-        if (a.K >= 1536) return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, GROUPED>(a, max_n, s);
-        return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, GROUPED>(a, max_n, s);
-    }
     if constexpr (!GROUPED) {
-        switch (g_nt_config) {
-            case 3: return launch_nt_cfg<128, 256, 2, 2, 64, 3, EPI, false>(a, max_n, s);
-            case 4: return launch_nt_cfg<256, 256, 2, 4, 64, 2, EPI, false>(a, max_n, s);
-            case 5: return launch_nt_cfg<128, 256, 2, 2, 32, 3, EPI, false>(a, max_n, s);
+        int cfg = g_nt_config;
+        if (cfg == 9) cfg = g_nt_auto[a.K >= 1536 ? 1 : 0];
+        switch (cfg) {
+            case 0: return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, false>(a, max_n, s);
+            case 1: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false>(a, max_n, s);
             case 6: return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, false>(a, max_n, s);
-            default: break;
+            case 7: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false, true>(a, max_n, s);
+            case 8: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false, true>(a, max_n, s);
+            default: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false>(a, max_n, s);
         }
     }
-    if (g_nt_config == 1) return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, GROUPED>(a, max_n, s);
-    return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, GROUPED>(a, max_n, s);
+    return -1;
 }
 
 }  // namespace
@@ -540,7 +610,10 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     return -1;
 }
 
-extern "C" void fm_set_gemm_nt_config(int cfg) { g_nt_config = cfg & 0xff; g_nt_prio = (cfg >> 8) & 1; }
+extern "C" void fm_set_gemm_nt_config(int cfg) {
+    g_nt_config = cfg & 0xff; g_nt_prio = (cfg >> 8) & 1;
+    if (cfg >> 16) { g_nt_auto[0] = (cfg >> 16) & 0xf; g_nt_auto[1] = (cfg >> 20) & 0xf; }   // bits 16-19 / 20-23: automatic pair
+}
 extern "C" int fm_get_gemm_nt_config(void) { return g_nt_config; }
 static int g_tn_use_tr = 1;   // ds_read_b64_tr_b16 semantics verified on hardware (tools/probe_gfx950.hip)
 extern "C" void fm_set_tn_transpose_read(int on) { g_tn_use_tr = on; }

@@ -25,6 +25,7 @@ from . import _lib as L
 from . import ops
 
 _WEIGHT_EPOCH = 0
+FUSE_ACT_BWD = False
 
 
 def bump_weight_epoch():
@@ -534,12 +535,13 @@ class FourMEngine:
         vocabs = [m.decoder_embeddings[h].vocab_size for h in heads]
         hs["vocabs"], hs["maxV"] = vocabs, max(vocabs)
         ldl = ru(hs["maxV"], 64)
-        key = tuple((self._stamp(m.decoder_embeddings[h].to_logits.weight)) for h in heads)
+        w_fwd = [self.w(m.decoder_embeddings[h].to_logits.weight) for h in heads]       # refreshed if stale
+        w_bwd = [self.wt(m.decoder_embeddings[h].to_logits.weight) for h in heads] if save else None
+        key = tuple(t.data_ptr() for t in w_fwd) + (tuple(t.data_ptr() for t in w_bwd) if save else ())
         cache = getattr(self, "_head_groups", None)
-        if cache is None or cache[0] != key:
-            fwd = ops.make_groups([dict(W=self.w(m.decoder_embeddings[h].to_logits.weight), N=v, K=D, ldw=D) for h, v in zip(heads, vocabs)], dev)
-            bwd = ops.make_groups([dict(W=self.wt(m.decoder_embeddings[h].to_logits.weight), N=D, K=ru(v, 64), ldw=ru(v, 64))
-                                   for h, v in zip(heads, vocabs)], dev)
+        if cache is None or cache[0] != key:       # device tables of raw pointers: rebuilt only when a buffer moved
+            fwd = ops.make_groups([dict(W=t, N=v, K=D, ldw=D) for t, v in zip(w_fwd, vocabs)], dev)
+            bwd = ops.make_groups([dict(W=t, N=D, K=ru(v, 64), ldw=ru(v, 64)) for t, v in zip(w_bwd, vocabs)], dev) if save else None
             vt = torch.tensor(vocabs, dtype=i32, device=dev)
             self._head_groups = cache = (key, fwd, bwd, vt)
         hs["g_fwd"], hs["g_bwd"], hs["vocab_t"] = cache[1], cache[2], cache[3]
@@ -610,16 +612,28 @@ class FourMEngine:
         ws = self.ws
         self._dW(g_bf, sv["act"], mlp.fc2, R64)
         dh = ws.get("bwd.dh", (Rp, D), bf)
-        # d(act) = g · W2 never reaches HBM: the activation backward runs in the GEMM epilogue on the saved (g | u) / pre
+        # FUSE_ACT_BWD: the activation backward runs in the fc2 dX GEMM epilogue on the saved (g | u) / pre, so
+        # d(act) never reaches HBM.  Off by default: the epilogue's 8-byte row-strided reads of (g | u) cost more
+        # (10.4 vs 5.5 ms per 4M-B step, profiles/r01) than the coalesced stand-alone kernel they replace.
+        fuse = FUSE_ACT_BWD
+        if not fuse:
+            da = ws.get("bwd.da", (Rp, Hp), bf)
+            ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), da, M=R, N=Hd, K=D)
         if self.gated:
             dgu = ws.get("bwd.dgu", (Rp, 2 * Hp), bf)
-            ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), dgu, M=R, N=Hd, K=D, epilogue=L.EPI_SWIGLU_BWD, res=sv["gu"], Hp=Hp)
+            if fuse:
+                ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), dgu, M=R, N=Hd, K=D, epilogue=L.EPI_SWIGLU_BWD, res=sv["gu"], Hp=Hp)
+            else:
+                ops.swiglu_bwd(da, sv["gu"], dgu, Hd, Hp, R=R)
             self._dW(dgu[:, :Hp], sv["h2"], mlp.fc1, R64, n_cols=Hd)
             self._dW(dgu[:, Hp:], sv["h2"], mlp.fc3, R64, n_cols=Hd)
             ops.gemm_nt(dgu, self.w13t(mlp), dh, M=R, N=D, K=2 * Hp)
         else:
             dpre = ws.get("bwd.dpre", (Rp, Hp), bf)
-            ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), dpre, M=R, N=Hd, K=D, epilogue=L.EPI_GELU_BWD, res=sv["pre"])
+            if fuse:
+                ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), dpre, M=R, N=Hd, K=D, epilogue=L.EPI_GELU_BWD, res=sv["pre"])
+            else:
+                ops.gelu_bwd(da, sv["pre"], dpre, Hd, Hp, R=R)
             self._dW(dpre, sv["h2"], mlp.fc1, R64, n_cols=Hd)
             ops.gemm_nt(dpre, self.wt(mlp.fc1.weight), dh, M=R, N=D, K=Hp)
         return dh
@@ -734,8 +748,13 @@ class FourMEngine:
         ops.gemm_nt_grouped(hs["logits"], hs["g_bwd"], hs["tile_group"], dyp, D)
         heads = [m.decoder_embeddings[h] for h in hs["heads"]]
         if any(h.to_logits.weight.requires_grad for h in heads):
-            tn = ops.make_groups([dict(out=self.grad_view(h.to_logits.weight) if h.to_logits.weight.requires_grad else None,
-                                       N=(v if h.to_logits.weight.requires_grad else 0)) for h, v in zip(heads, hs["vocabs"])], self.device)
+            outs = [self.grad_view(h.to_logits.weight) if h.to_logits.weight.requires_grad else None for h in heads]
+            key = tuple(o.data_ptr() if o is not None else 0 for o in outs)
+            cache = getattr(self, "_head_tn_groups", None)
+            if cache is None or cache[0] != key:       # no per-step host-to-device table upload (it would fence the stream)
+                cache = self._head_tn_groups = (key, ops.make_groups(
+                    [dict(out=o, N=(v if o is not None else 0)) for o, v in zip(outs, hs["vocabs"])], self.device))
+            tn = cache[1]
             ops.gemm_tn_grouped(hs["logits"], hs["yp"], tn, hs["seg_start"], hs["seg_count"], hs["n"], hs["maxV"], hs["Rp"], D)
         g = ws.get("bwd.g_dec", (Rqp, D), f32)
         g_bf = ws.get("bwd.g_dec_bf", (Rqp, D), bf)
