@@ -71,8 +71,8 @@ class LaunchProfiler:
         self.recs = []
 
     class _Ctx:
-        def __init__(self, prof, name, flops, nbytes):
-            self.p, self.name, self.flops, self.nbytes = prof, name, flops, nbytes
+        def __init__(self, prof, name, flops, nbytes, tag):
+            self.p, self.name, self.flops, self.nbytes, self.tag = prof, name, flops, nbytes, tag
 
         def __enter__(self):
             self.a = torch.cuda.Event(enable_timing=True)
@@ -82,19 +82,67 @@ class LaunchProfiler:
 
         def __exit__(self, *exc):
             self.b.record(torch.cuda.current_stream())
-            self.p.recs.append((self.name, self.flops, self.nbytes, self.a, self.b))
+            self.p.recs.append((self.name, self.flops, self.nbytes, self.a, self.b, self.tag))
             return False
 
-    def launch(self, name, flops, nbytes):
-        return self._Ctx(self, name, flops, nbytes)
+    def launch(self, name, flops, nbytes, tag=""):
+        return self._Ctx(self, name, flops, nbytes, tag)
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, nb, a, b in self.recs:
-            d = agg.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
-            d["ms"] += a.elapsed_time(b); d["flops"] += fl; d["bytes"] += nb; d["n"] += 1
+        self.by_shape = {}
+        for name, fl, nb, a, b, tag in self.recs:
+            ms = a.elapsed_time(b)
+            for key, table in ((name, agg), (f"{name} {tag}".strip(), self.by_shape)):
+                d = table.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+                d["ms"] += ms; d["flops"] += fl; d["bytes"] += nb; d["n"] += 1
         return agg
+
+    def shape_table(self, steps):
+        rows = sorted(self.by_shape.items(), key=lambda kv: -kv[1]["ms"])
+        return [f"{k:46s} {d['n'] // steps:4d} launches/step {d['ms'] / steps:8.3f} ms/step {d['ms'] / d['n'] * 1e3:8.1f} us/launch"
+                + (f" {d['flops'] / d['ms'] / 1e9:7.1f} TF/s" if d["flops"] else "") for k, d in rows]
+
+
+KERNEL_REGEX = {   # profiler family -> regex on the demangled kernel name (7th template argument of gemm_nt = epilogue)
+    "gemm_nt": r"gemm_nt_kernel<\d+, \d+, \d+, \d+, \d+, \d+, {epi}, false",
+    "gemm_tn": r"gemm_tn_kernel<\w+, false", "attn_fwd": r"attn_fwd_kernel", "attn_bwd": r"attn_bwd_kernel",
+    "layernorm_fwd": r"ln_fwd_kernel", "layernorm_bwd": r"ln_bwd_kernel",
+}
+
+
+def pmc_traffic(kernel_regex, timeout_s=240):
+    """HBM-side bytes per launch of one kernel from rocprofv3 PMC counters (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
+    and WRITE_SIZE are collected in SEPARATE passes (TCC slot limit) over two train steps in a child process, per
+    dispatch; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 reports half of a wide coalesced read; WRITE_SIZE is
+    uncalibrated).  Returns (bytes_per_launch | None, detail dict)."""
+    import csv, glob, re, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    rx, kb, n_launch = re.compile(kernel_regex), {}, {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fm_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-worker"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=timeout_s, capture_output=True)
+            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+            tot, n = 0.0, 0
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] == counter and rx.search(row["Kernel_Name"]):
+                        tot += float(row["Counter_Value"]); n += 1
+            kb[counter], n_launch[counter] = tot / max(n, 1), n
+        except Exception as e:
+            return None, {"error": f"{counter} pass failed: {type(e).__name__}: {e}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if min(n_launch.values()) == 0:
+        return None, {"error": f"no dispatch matched {kernel_regex}"}
+    nbytes = (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+    return nbytes, {"fetch_size_kb_per_launch": kb["FETCH_SIZE"], "write_size_kb_per_launch": kb["WRITE_SIZE"],
+                    "launches_counted": n_launch["FETCH_SIZE"], "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 B, separate --pmc passes"}
 
 
 def cpu_baseline(timeout_s=240):
@@ -159,7 +207,9 @@ def main():
     ap.add_argument("--n-out", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.cpu_baseline_worker:
         print(json.dumps(cpu_baseline_worker()))
@@ -208,6 +258,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.pmc_worker:            # child of pmc_traffic(): two plain steps under rocprofv3 --pmc, nothing printed
+        for i in range(2):
+            step(i)
+        fence()
+        return
     for i in range(a.warmup):
         loss, norm = step(i)
     fence()
@@ -254,7 +309,10 @@ def main():
         name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
         fam, _, epi = name.partition("/epi")
         common = {"kernel": symbol.get(fam, fam).format(epi=epi or "0"), "traffic": None, "launches_per_step": d["n"] // 2,
-                  "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms}
+                  "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms,
+                  "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
+        if world == 1 and not a.no_traffic and fam in KERNEL_REGEX:
+            common["traffic"], common["traffic_detail"] = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0"))
         if d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS, **common}
@@ -263,6 +321,9 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, **common}
         out["kernel_breakdown_ms_per_step"] = {k: round(v["ms"] / 2, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         out["kernel_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in agg.items() if v["flops"] > 0 and v["ms"] > 0}
+        if os.environ.get("BENCH_SHAPE_TABLE"):      # per-shape table of the timed launches (tuning aid), off the JSON line
+            with open(os.environ["BENCH_SHAPE_TABLE"], "w") as f:
+                f.write("\n".join(prof.shape_table(2)) + "\n")
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -382,18 +382,15 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     const int wa = wave / WB, wb = wave % WB;
 
     // Workgroups that reduce the same rows (same split) read the same A / B row panels, each a different
-    // column slice pair: they are placed on ONE XCD (dispatch puts workgroup b on XCD b % 8) and run
-    // concurrently, so a panel is fetched from HBM once and shared through that XCD's L2.
+    // column slice pair.  Work items are ordered split-major and cut into 8 contiguous runs, one per XCD
+    // (dispatch puts workgroup b on XCD b % 8): an XCD sees one or two splits, so a panel is fetched from HBM
+    // once (at most twice) and shared through that XCD's L2, for any split count.
     const int nwg = a.n_tiles_a * a.n_tiles_b;
-    int tile, split;
-    if (a.splits % 8 == 0) {
-        const int xcd = blockIdx.x % 8, i = blockIdx.x / 8;
-        split = xcd + 8 * (i / nwg);
-        tile = i % nwg;
-    } else {
-        split = blockIdx.x / nwg;
-        tile = blockIdx.x % nwg;
-    }
+    const int total = nwg * a.splits;
+    const int per_xcd = (total + 7) / 8;
+    const int item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (blockIdx.x / 8 >= per_xcd || item >= total) return;
+    const int split = item / nwg, tile = item % nwg;
     const int ta = tile / a.n_tiles_b, tb = tile % a.n_tiles_b;
     int N = a.N, r_begin = 0, r_end = a.R;
     float* out = a.out;
@@ -537,6 +534,9 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
 //   0  128(feat) x 128(rows), 4 waves, K-step 64, 3 stages
 //   1  128 x 256, 8 waves (64x64 wave tiles), K-step 64, 3 stages, 144 KB  (1 workgroup / CU)
 //   2  128 x 256, 8 waves, K-step 32, 3 stages, 72 KB                      (2 workgroups / CU: epilogue overlap)
+//   3  256 x 256, 8 waves (128x64 wave tiles), K-step 32, 3 stages, 96 KB, ping-pong schedule
+//   4  256 x 256, 8 waves, K-step 32, 3 stages, 96 KB
+//   5  256 x 256, 8 waves, K-step 64, 2 stages, 128 KB
 //   6  128 x 128, 4 waves, K-step 32, 3 stages, 48 KB                      (3 workgroups / CU; grouped path)
 //   7  as 1 with the ping-pong schedule (wave rows one barrier apart: LDS reads of one row under the MFMAs of the other)
 //   8  as 2 with the ping-pong schedule
@@ -552,6 +552,9 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
         switch (cfg) {
             case 0: return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, false>(a, max_n, s);
             case 1: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false>(a, max_n, s);
+            case 3: return launch_nt_cfg<256, 256, 2, 4, 32, 3, EPI, false, true>(a, max_n, s);
+            case 4: return launch_nt_cfg<256, 256, 2, 4, 32, 3, EPI, false>(a, max_n, s);
+            case 5: return launch_nt_cfg<256, 256, 2, 4, 64, 2, EPI, false>(a, max_n, s);
             case 6: return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, false>(a, max_n, s);
             case 7: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false, true>(a, max_n, s);
             case 8: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false, true>(a, max_n, s);
@@ -637,17 +640,19 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
     if (splits <= 0) {
-        // One split (or several) per XCD: 32 CUs x 2 resident workgroups = 64 slots per XCD
+        // Fill the chip in ONE round: 256 CUs x 2 resident workgroups = 512 slots (e.g. the 66 tiles of an MLP
+        // weight gradient take 7 splits = 462 workgroups; 8 splits would leave 16 workgroups for a second round).
         const int tiles = a.n_tiles_a * a.n_tiles_b;
         const int nt = grouped ? (p->max_R + TN_KB - 1) / TN_KB : p->R / TN_KB;
-        int per_xcd = tiles >= 64 ? 1 : 64 / tiles;
-        while (per_xcd > 1 && nt / (8 * per_xcd) < 8) --per_xcd;      // keep >= 8 reduction tiles per workgroup
-        splits = 8 * per_xcd;
+        splits = tiles >= 512 ? 1 : 512 / tiles;
+        while (splits > 1 && nt / splits < 8) --splits;                // keep >= 8 reduction tiles per workgroup
+        if (splits > 64) splits = 64;
         if (nt < 16) splits = 1;                                       // tiny problems
     }
     a.splits = splits;
     const size_t lds = (size_t)TN_STAGES * TN_KB * (TN_TA + TN_TB) * 2;
-    dim3 grid(a.n_tiles_a * a.n_tiles_b * splits, 1, grouped ? p->n_groups : 1);
+    const int total_items = a.n_tiles_a * a.n_tiles_b * splits;
+    dim3 grid((total_items + 7) / 8 * 8, 1, grouped ? p->n_groups : 1);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TN(TR, G)                                                                            \
     {                                                                                               \

@@ -28,8 +28,8 @@ class _Null:
 _NULL = _Null()
 
 
-def _prof(name, flops=0.0, nbytes=0.0):
-    return _NULL if _PROFILER is None else _PROFILER.launch(name, flops, nbytes)
+def _prof(name, flops=0.0, nbytes=0.0, tag=""):
+    return _NULL if _PROFILER is None else _PROFILER.launch(name, flops, nbytes, tag)
 
 
 BK = 64          # reduction granularity of the GEMMs (zero padded)
@@ -72,7 +72,10 @@ def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bia
     a.ldo2 = _ld(out2) if out2 is not None else 0
     a.ldr = _ld(res) if res is not None else 0
     a.Hp, a.epilogue = Hp, epilogue
-    with _prof(f"gemm_nt/epi{epilogue}", 2.0 * a.M * a.N * a.K * (2 if epilogue == L.EPI_SWIGLU else 1)):
+    two = 2 if epilogue == L.EPI_SWIGLU else 1
+    nbytes = 2.0 * a.K * (a.M + two * a.N) + a.M * a.N * two * out.element_size()        # operands once + output once
+    nbytes += (a.M * a.N * 4.0 if res is not None and epilogue in (L.EPI_RESIDUAL, L.EPI_F32) else 0.0) + (a.M * a.N * 4.0 if out2 is not None else 0.0)
+    with _prof(f"gemm_nt/epi{epilogue}", 2.0 * a.M * a.N * a.K * two, nbytes, tag=f"M{a.M} N{a.N} K{a.K}"):
         L.check(L.gemm_nt(C.byref(a), _stream()))
     return out
 
@@ -99,7 +102,7 @@ def gemm_tn(a_mat, b_mat, out, *, N=None, K=None, R=None, splits=0, force_tr=-1,
     a.a_cols = a_cols or a_mat.shape[1]
     a.b_cols = b_cols or b_mat.shape[1]
     a.splits, a.force_tr = splits, force_tr
-    with _prof("gemm_tn", 2.0 * a.R * a.N * a.K):
+    with _prof("gemm_tn", 2.0 * a.R * a.N * a.K, 2.0 * a.R * (a.N + a.K) + 4.0 * a.N * a.K, tag=f"R{a.R} N{a.N} K{a.K}"):
         L.check(L.gemm_tn(C.byref(a), _stream()))
     return out
 
