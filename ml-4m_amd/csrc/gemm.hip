@@ -39,6 +39,24 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // ------------------------------------------------------------------------------------------------
 // NT kernel
 // ------------------------------------------------------------------------------------------------
+// bf16 epilogue store of two adjacent 8-feature groups of one row.  After the 32x32 MFMA chain lane l holds
+// features [8g+4h, 8g+4h+4) of its row (h = l >> 5; lanes l and l+32 share the row), packed in `pg` for group g
+// and `pg1` for group g+1.  Wide form: two v_permlane32_swap per pair hand each half-wave 16 contiguous bytes
+// (lower half: group g, upper half: group g+1) -> ONE 16-byte store instead of two 8-byte ones (the store tail is
+// issue bound, not byte bound).  `col` = first feature of group g; features >= N are not written.
+__device__ __forceinline__ void store_bf16_groups(bf16_t* row, int col, uint2 pg, uint2 pg1, int fhi, int N, bool wide) {
+    if (wide) {
+        const auto x = __builtin_amdgcn_permlane32_swap(pg.x, pg1.x, false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(pg.y, pg1.y, false, false);
+        const int c = col + 8 * fhi;
+        if (c < N) *(uint4*)(row + c) = make_uint4(x[0], y[0], x[1], y[1]);
+    } else {
+        const int c = col + 4 * fhi;
+        if (c < N) *(uint2*)(row + c) = pg;
+        if (c + 8 < N) *(uint2*)(row + c + 8) = pg1;
+    }
+}
+
 // wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void block_barrier() {
@@ -248,33 +266,79 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         const int m = m0 + wx * (TX / WX) + j * 32 + frow;
         if (m >= a.M) continue;
         if constexpr (EPI == EPI_SWIGLU) {
+            bf16_t* gu = (bf16_t*)a.out2 + (size_t)m * a.ldo2;
+            bf16_t* ao = (bf16_t*)a.out + (size_t)m * a.ldo;
+            const bool wide = ((N | a.Hp | a.ldo | a.ldo2) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.out2) & 15) == 0;
 #pragma unroll
-            for (int ip = 0; ip < FW / 2; ++ip)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int ip = 0; ip < FW / 2; ++ip) {
                 // fragment pair (2ip, 2ip+1) = (g, u) of hidden units n0 + (tile row / 64) * 32 + ...
-                const int h = n0 + (ww * (TW / WW) / 64 + ip) * 32 + 8 * g + 4 * fhi;
-                if (h >= N) continue;
-                float gv[4], uv[4], av[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias) {
+                const int hb = n0 + (ww * (TW / WW) / 64 + ip) * 32;
+                uint2 pg_[4], pu_[4], pa_[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b1[e] = bfround(a.bias[min(h + e, N - 1)]);
-                }
-                if (a.bias2) {
+                for (int g = 0; g < 4; ++g) {
+                    const int h = hb + 8 * g + 4 * fhi;
+                    float gv[4], uv[4], av[4], b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) b2[e] = bfround(a.bias2[min(h + e, N - 1)]);
+                        for (int e = 0; e < 4; ++e) b1[e] = bfround(a.bias[min(h + e, N - 1)]);
+                    }
+                    if (a.bias2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) b2[e] = bfround(a.bias2[min(h + e, N - 1)]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool live = h + e < N;          // hidden sizes need not be multiples of 4 (2730)
+                        gv[e] = live ? bfround(acc[2 * ip][j][4 * g + e] + b1[e]) : 0.f;
+                        uv[e] = live ? bfround(acc[2 * ip + 1][j][4 * g + e] + b2[e]) : 0.f;
+                        av[e] = bfround(silu_f(gv[e])) * uv[e];
+                    }
+                    pg_[g] = make_uint2(pack2bf(gv[0], gv[1]), pack2bf(gv[2], gv[3]));
+                    pu_[g] = make_uint2(pack2bf(uv[0], uv[1]), pack2bf(uv[2], uv[3]));
+                    pa_[g] = make_uint2(pack2bf(av[0], av[1]), pack2bf(av[2], av[3]));
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const bool live = h + e < N;          // hidden sizes need not be multiples of 4 (2730)
-                    gv[e] = live ? bfround(acc[2 * ip][j][4 * g + e] + b1[e]) : 0.f;
-                    uv[e] = live ? bfround(acc[2 * ip + 1][j][4 * g + e] + b2[e]) : 0.f;
-                    av[e] = bfround(silu_f(gv[e])) * uv[e];
+                for (int g = 0; g < 4; g += 2) {
+                    store_bf16_groups(gu, hb + 8 * g, pg_[g], pg_[g + 1], fhi, N, wide);
+                    store_bf16_groups(gu + a.Hp, hb + 8 * g, pu_[g], pu_[g + 1], fhi, N, wide);
+                    store_bf16_groups(ao, hb + 8 * g, pa_[g], pa_[g + 1], fhi, N, wide);
                 }
-                bf16_t* gu = (bf16_t*)a.out2 + (size_t)m * a.ldo2;
-                *(uint2*)(gu + h) = make_uint2(pack2bf(gv[0], gv[1]), pack2bf(gv[2], gv[3]));
-                *(uint2*)(gu + a.Hp + h) = make_uint2(pack2bf(uv[0], uv[1]), pack2bf(uv[2], uv[3]));
-                *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + h) = make_uint2(pack2bf(av[0], av[1]), pack2bf(av[2], av[3]));
+            }
+        } else if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_TANH) {
+            bf16_t* orow = (bf16_t*)a.out + (size_t)m * a.ldo;
+            bf16_t* prow = (EPI == EPI_GELU && a.out2) ? (bf16_t*)a.out2 + (size_t)m * a.ldo2 : nullptr;
+            const bool wide = ((N | a.ldo | (prow ? a.ldo2 : 0)) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)(prow ? a.out2 : nullptr)) & 15) == 0;
+#pragma unroll
+            for (int i = 0; i < FW; ++i) {
+                const int nb = n0 + ww * (TW / WW) + i * 32;
+                uint2 po[4], pp[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nb + 8 * g + 4 * fhi;
+                    float v[4], b[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias && n < N) {
+                        const float4 t = *(const float4*)(a.bias + n);     // n % 4 == 0, bias 16-B aligned
+                        b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bfround(b[e]);
+                    if constexpr (EPI == EPI_GELU) {
+                        pp[g] = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_f(bfround(v[e]));
+                    } else if constexpr (EPI == EPI_TANH) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = tanhf(bfround(v[e]));
+                    }
+                    po[g] = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    store_bf16_groups(orow, nb + 8 * g, po[g], po[g + 1], fhi, N, wide);
+                    if constexpr (EPI == EPI_GELU) {
+                        if (prow) store_bf16_groups(prow, nb + 8 * g, pp[g], pp[g + 1], fhi, N, wide);
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -290,18 +354,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + ((EPI == EPI_F32) ? b[e] : bfround(b[e]));
-                    if constexpr (EPI == EPI_BF16) {
-                        *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                    } else if constexpr (EPI == EPI_GELU) {
-                        if (a.out2)
-                            *(uint2*)((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_f(bfround(v[e]));
-                        *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-                    } else if constexpr (EPI == EPI_TANH) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = tanhf(bfround(v[e]));
-                        *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    if constexpr (false) {
                     } else if constexpr (EPI == EPI_SWIGLU_BWD) {
                         // acc = d(silu(g)*u); res = saved (g | u) bf16; out = (dg | du) bf16     (GatedMlp, fm_utils.py:142-144)
                         const bf16_t* gu = (const bf16_t*)a.res + (size_t)m * a.ldr + n;
@@ -513,7 +566,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
 }
 
 int g_nt_config = 9, g_nt_prio = 1;
-int g_nt_auto[2] = {2, 1};          // automatic choice for short / long (K >= 1536) reductions
+int g_nt_auto[2] = {2, 7};          // automatic choice: short reductions / long ones (K >= 1536) and the fp32 residual epilogue
 
 template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false>
 int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
@@ -541,14 +594,15 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
 //   7  as 1 with the ping-pong schedule (wave rows one barrier apart: LDS reads of one row under the MFMAs of the other)
 //   8  as 2 with the ping-pong schedule
 //   +256: s_setprio(1) around the MFMA clusters
-//   9  automatic (default): configuration 1 for long reductions (K >= 1536), else 2
+//   9  automatic (default): configuration 7 for long reductions (K >= 1536) and the residual epilogue, else 2
+//      (measured: profiles/r01_v5_nt_config_sweep.txt)
 template <int EPI, bool GROUPED>
 int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     // grouped rows are segmented in 128-row tiles, so that path keeps the 128-row X tile
     if (GROUPED || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
     if constexpr (!GROUPED) {
         int cfg = g_nt_config;
-        if (cfg == 9) cfg = g_nt_auto[a.K >= 1536 ? 1 : 0];
+        if (cfg == 9) cfg = g_nt_auto[(a.K >= 1536 || EPI == EPI_RES) ? 1 : 0];
         switch (cfg) {
             case 0: return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, false>(a, max_n, s);
             case 1: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false>(a, max_n, s);
