@@ -52,8 +52,9 @@ typedef struct fm_gemm_group {  /* one entry per row segment (modality) in group
  * K % 64 == 0 (zero padded), ldw/ldx % 8 == 0, ldo % 4 == 0 and ldo >= roundup4(N): a lane stores 4
  * consecutive features, so for N % 4 != 0 the columns [N, roundup4(N)) of out receive don't-care values
  * (FM_EPI_SWIGLU writes zeros there instead).
- * Grouped mode (groups != NULL): rows of X are segmented in 128-row tiles, tile_group[tile] selects
- * the group (or -1 = skip); W/N/K/ldw come from the group record, max_N bounds the launch. */
+ * Grouped mode (groups != NULL): rows of X are segmented in FM_SEG_ROWS-row tiles, tile_group[tile] selects
+ * the group (or -1 = skip); W/N/K/ldw come from the group record, max_N bounds the launch and K (an upper bound
+ * of the groups' K, 0 = unknown) picks the tile configuration. */
 typedef struct fm_gemm_nt_args {
     const void* W; const void* W2; const void* X;
     void* out; void* out2; const void* res; const void* bias; const void* bias2;
@@ -207,9 +208,10 @@ int fm_dense_decoder_mask(const int32_t* cs, const int16_t* mod, void* out, int 
  * Heads: segment rows by modality, cross-entropy  (fm.py:573-637)
  * ---------------------------------------------------------------------------------------------- */
 enum fm_loss_type { FM_LOSS_MOD = 0, FM_LOSS_TOKEN = 1 };
-/* Buckets rows 0..R-1 by head_of_row (-1 = no head) into 128-row-aligned segments of a padded row
- * space of Rp rows (Rp % 128 == 0, Rp >= roundup128(R) + 128*(n_heads-1)).  perm[pr] = source row or
- * -1; row_to_padded[r] = padded row or -1; tile_group[pr/128] = head or -1. */
+#define FM_SEG_ROWS 256   /* row alignment of the per-modality segments = the row tile of the grouped GEMMs */
+/* Buckets rows 0..R-1 by head_of_row (-1 = no head) into FM_SEG_ROWS-aligned segments of a padded row
+ * space of Rp rows (Rp % FM_SEG_ROWS == 0, Rp >= roundup(R) + FM_SEG_ROWS*(n_heads-1)).  perm[pr] = source row or
+ * -1; row_to_padded[r] = padded row or -1; tile_group[pr/FM_SEG_ROWS] = head or -1. */
 int fm_segment_rows(const int32_t* head_of_row, int R, int n_heads, int32_t* seg_start, int32_t* seg_count,
                     int32_t* perm, int32_t* row_to_padded, int32_t* tile_group, int Rp, void* stream);
 int fm_gather_rows(const void* src, int ld_src, const int32_t* perm, void* dst, int ld_dst, int Rp, int D, void* stream);

@@ -30,6 +30,7 @@ struct NTArgs {
     int M, N, K, ldw, ldx, ldo, ldo2, ldr, Hp;
     const fm_gemm_group* groups; const int* tile_group;   // grouped mode (may be null)
     int n_tiles_w, n_tiles_x;
+    int group_w;                                          // grouped: W-tiles per column block
     int prio;                                             // raise the wave priority around the MFMA clusters
 };
 
@@ -44,6 +45,26 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // and `pg1` for group g+1.  Wide form: two v_permlane32_swap per pair hand each half-wave 16 contiguous bytes
 // (lower half: group g, upper half: group g+1) -> ONE 16-byte store instead of two 8-byte ones (the store tail is
 // issue bound, not byte bound).  `col` = first feature of group g; features >= N are not written.
+// The read-side mirror of store_bf16_groups: one 16-byte load per half-wave (lower half: group g, upper half:
+// group g+1), two swaps, and every lane has its 4 features of both groups.  Features >= N read as zero.
+__device__ __forceinline__ void load_bf16_groups(const bf16_t* row, int col, int fhi, int N, bool wide, uint2& pg, uint2& pg1) {
+    if (wide) {
+        const int c = col + 8 * fhi;
+        const uint4 t = c < N ? *(const uint4*)(row + c) : make_uint4(0u, 0u, 0u, 0u);
+        const auto x = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
+        pg = make_uint2(x[0], y[0]); pg1 = make_uint2(x[1], y[1]);
+    } else {
+        const int c = col + 4 * fhi;
+        pg = c < N ? *(const uint2*)(row + c) : make_uint2(0u, 0u);
+        pg1 = c + 8 < N ? *(const uint2*)(row + c + 8) : make_uint2(0u, 0u);
+    }
+}
+
+__device__ __forceinline__ void unpack_bf4(uint2 p, float (&v)[4]) {
+    v[0] = bf2f((bf16_t)(p.x & 0xffff)); v[1] = bf2f((bf16_t)(p.x >> 16)); v[2] = bf2f((bf16_t)(p.y & 0xffff)); v[3] = bf2f((bf16_t)(p.y >> 16));
+}
+
 __device__ __forceinline__ void store_bf16_groups(bf16_t* row, int col, uint2 pg, uint2 pg1, int fhi, int N, bool wide) {
     if (wide) {
         const auto x = __builtin_amdgcn_permlane32_swap(pg.x, pg1.x, false, false);
@@ -98,9 +119,26 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     const int ww = wave / WX, wx = wave % WX;
 
     // ---- which tile ------------------------------------------------------------------------
-    const int nwg = a.n_tiles_w * a.n_tiles_x;
-    const int tile = xcd_remap(blockIdx.x, nwg);
-    const int tx = tile / a.n_tiles_w, tw = tile % a.n_tiles_w;   // W tiles fastest: X tile shared in L2
+    int tx, tw;
+    if constexpr (GROUPED) {
+        // Head GEMMs: a vocabulary matrix (up to 46 MB) does not fit an L2 and the groups have very different
+        // widths (4096 ... 30000 of max_N columns), so (1) tiles are ordered in column blocks of `gw` W-tiles: all X
+        // tiles sweep one block, then the next (W is fetched about once, the much smaller X tiles once per block);
+        // (2) the order is cut into chunks of gw x 4 tiles (one L2 working set) dealt ROUND-ROBIN to the 8 XCDs
+        // (dispatch puts workgroup b on XCD b % 8), so the tiles a narrow group leaves empty thin out every XCD's
+        // share evenly instead of emptying some XCDs (contiguous shares: 465 TF on a 4096 | 30000 pair, dense: 730).
+        constexpr int GX = 4;
+        const int gw = a.group_w, chunk_sz = gw * GX;
+        const int nblk = (a.n_tiles_w + gw - 1) / gw, nxg = (a.n_tiles_x + GX - 1) / GX;
+        const int xcd = blockIdx.x % 8, j = blockIdx.x / 8;
+        const int chunk = (j / chunk_sz) * 8 + xcd, within = j % chunk_sz;
+        const int blk = chunk / nxg, txg = chunk % nxg;
+        tx = txg * GX + within / gw; tw = blk * gw + within % gw;
+        if (blk >= nblk || tx >= a.n_tiles_x || tw >= a.n_tiles_w) return;
+    } else {
+        const int tile = xcd_remap(blockIdx.x, a.n_tiles_w * a.n_tiles_x);
+        tx = tile / a.n_tiles_w; tw = tile % a.n_tiles_w;         // W tiles fastest: X tile shared in L2
+    }
     const bf16_t* Wp = a.W;
     int N = a.N, K = a.K, ldw = a.ldw;
     if constexpr (GROUPED) {
@@ -340,6 +378,56 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                     }
                 }
             }
+        } else if constexpr (EPI == EPI_SWIGLU_BWD || EPI == EPI_GELU_BWD) {
+            // acc = d(act); res = saved (g | u) or pre-activation (bf16); out = (dg | du) or d(pre) (bf16)
+            // (GatedMlp fm_utils.py:142-144 / Mlp :121-126).  16-byte loads and stores, see load/store_bf16_groups.
+            const bf16_t* srow = (const bf16_t*)a.res + (size_t)m * a.ldr;
+            bf16_t* orow = (bf16_t*)a.out + (size_t)m * a.ldo;
+            const bool wide = ((N | a.Hp | a.ldo | a.ldr) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.res) & 15) == 0;
+#pragma unroll
+            for (int i = 0; i < FW; ++i) {
+                const int nb = n0 + ww * (TW / WW) + i * 32;
+                uint2 sg_[4], su_[4], o1[4], o2[4];
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    load_bf16_groups(srow, nb + 8 * g, fhi, N, wide, sg_[g], sg_[g + 1]);
+                    if constexpr (EPI == EPI_SWIGLU_BWD) load_bf16_groups(srow + a.Hp, nb + 8 * g, fhi, N, wide, su_[g], su_[g + 1]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nb + 8 * g + 4 * fhi;
+                    float xv[4], r1[4], r2[4];
+                    unpack_bf4(sg_[g], xv);
+                    if constexpr (EPI == EPI_SWIGLU_BWD) {
+                        float uv[4];
+                        unpack_bf4(su_[g], uv);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = bfround(acc[i][j][4 * g + e]);
+                            const float sg = 1.0f / (1.0f + __expf(-xv[e]));
+                            const float sl = bfround(xv[e] * sg);
+                            const float ds = bfround(d * uv[e]);
+                            const bool live = n + e < N;
+                            r2[e] = live ? d * sl : 0.f;
+                            r1[e] = live ? ds * (sg * (1.0f + xv[e] * (1.0f - sg))) : 0.f;
+                        }
+                        o2[g] = make_uint2(pack2bf(r2[0], r2[1]), pack2bf(r2[2], r2[3]));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float cdf = 0.5f * (1.0f + erff(xv[e] * 0.70710678118654752f));
+                            const float pdf = 0.3989422804014327f * __expf(-0.5f * xv[e] * xv[e]);
+                            r1[e] = (n + e < N) ? bfround(acc[i][j][4 * g + e]) * (cdf + xv[e] * pdf) : 0.f;
+                        }
+                    }
+                    o1[g] = make_uint2(pack2bf(r1[0], r1[1]), pack2bf(r1[2], r1[3]));
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    store_bf16_groups(orow, nb + 8 * g, o1[g], o1[g + 1], fhi, N, wide);
+                    if constexpr (EPI == EPI_SWIGLU_BWD) store_bf16_groups(orow + a.Hp, nb + 8 * g, o2[g], o2[g + 1], fhi, N, wide);
+                }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < FW; ++i)
@@ -354,40 +442,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + ((EPI == EPI_F32) ? b[e] : bfround(b[e]));
-                    if constexpr (false) {
-                    } else if constexpr (EPI == EPI_SWIGLU_BWD) {
-                        // acc = d(silu(g)*u); res = saved (g | u) bf16; out = (dg | du) bf16     (GatedMlp, fm_utils.py:142-144)
-                        const bf16_t* gu = (const bf16_t*)a.res + (size_t)m * a.ldr + n;
-                        const uint2 gp = *(const uint2*)gu, up = *(const uint2*)(gu + a.Hp);
-                        const float gv[4] = {bf2f((bf16_t)(gp.x & 0xffff)), bf2f((bf16_t)(gp.x >> 16)), bf2f((bf16_t)(gp.y & 0xffff)), bf2f((bf16_t)(gp.y >> 16))};
-                        const float uv[4] = {bf2f((bf16_t)(up.x & 0xffff)), bf2f((bf16_t)(up.x >> 16)), bf2f((bf16_t)(up.y & 0xffff)), bf2f((bf16_t)(up.y >> 16))};
-                        float dg[4], du[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float d = bfround(v[e]);
-                            const float sg = 1.0f / (1.0f + __expf(-gv[e]));
-                            const float sl = bfround(gv[e] * sg);
-                            const float ds = bfround(d * uv[e]);
-                            const bool live = n + e < N;
-                            du[e] = live ? d * sl : 0.f;
-                            dg[e] = live ? ds * (sg * (1.0f + gv[e] * (1.0f - sg))) : 0.f;
-                        }
-                        bf16_t* o = (bf16_t*)a.out + (size_t)m * a.ldo + n;
-                        *(uint2*)o = make_uint2(pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3]));
-                        *(uint2*)(o + a.Hp) = make_uint2(pack2bf(du[0], du[1]), pack2bf(du[2], du[3]));
-                    } else if constexpr (EPI == EPI_GELU_BWD) {
-                        // acc = d(gelu(pre)); res = saved pre-activation bf16; out = d(pre) bf16    (Mlp, fm_utils.py:121-126)
-                        const uint2 pp = *(const uint2*)((const bf16_t*)a.res + (size_t)m * a.ldr + n);
-                        const float xv[4] = {bf2f((bf16_t)(pp.x & 0xffff)), bf2f((bf16_t)(pp.x >> 16)), bf2f((bf16_t)(pp.y & 0xffff)), bf2f((bf16_t)(pp.y >> 16))};
-                        float o[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float cdf = 0.5f * (1.0f + erff(xv[e] * 0.70710678118654752f));
-                            const float pdf = 0.3989422804014327f * __expf(-0.5f * xv[e] * xv[e]);
-                            o[e] = (n + e < N) ? bfround(v[e]) * (cdf + xv[e] * pdf) : 0.f;
-                        }
-                        *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                    } else if constexpr (EPI == EPI_RES) {
+                    if constexpr (EPI == EPI_RES) {
                         const float4 r = *(const float4*)(a.res + (size_t)m * a.ldr + n);
                         float4 o = make_float4(r.x + bfround(v[0]), r.y + bfround(v[1]), r.z + bfround(v[2]), r.w + bfround(v[3]));
                         *(float4*)((float*)a.out + (size_t)m * a.ldo + n) = o;
@@ -438,11 +493,22 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     // column slice pair.  Work items are ordered split-major and cut into 8 contiguous runs, one per XCD
     // (dispatch puts workgroup b on XCD b % 8): an XCD sees one or two splits, so a panel is fetched from HBM
     // once (at most twice) and shared through that XCD's L2, for any split count.
+    //
+    // Grouped (per-modality heads): groups have very different widths, so contiguous runs would leave most XCDs
+    // idle on the narrow ones; there the order is cut into chunks of 4 A-tiles x all B-tiles (they share their
+    // panels) dealt round-robin to the XCDs.
     const int nwg = a.n_tiles_a * a.n_tiles_b;
     const int total = nwg * a.splits;
-    const int per_xcd = (total + 7) / 8;
-    const int item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    if (blockIdx.x / 8 >= per_xcd || item >= total) return;
+    int item;
+    if constexpr (GROUPED) {
+        const int chunk_sz = 4 * a.n_tiles_b, j = blockIdx.x / 8;
+        item = ((j / chunk_sz) * 8 + blockIdx.x % 8) * chunk_sz + j % chunk_sz;
+        if (item >= total) return;
+    } else {
+        const int per_xcd = (total + 7) / 8;
+        item = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+        if (blockIdx.x / 8 >= per_xcd || item >= total) return;
+    }
     const int split = item / nwg, tile = item % nwg;
     const int ta = tile / a.n_tiles_b, tb = tile % a.n_tiles_b;
     int N = a.N, r_begin = 0, r_end = a.R;
@@ -573,7 +639,12 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (max_n + NPT - 1) / NPT;
     a.n_tiles_x = (a.M + TX - 1) / TX;
-    const int grid = a.n_tiles_w * a.n_tiles_x;
+    int grid = a.n_tiles_w * a.n_tiles_x;
+    if (GROUPED) {
+        a.group_w = a.n_tiles_w < 16 ? a.n_tiles_w : 16;
+        const int chunks = ((a.n_tiles_w + a.group_w - 1) / a.group_w) * ((a.n_tiles_x + 3) / 4);
+        grid = (chunks + 7) / 8 * 8 * a.group_w * 4;
+    }
     const size_t lds = (size_t)STAGES * (TW + TX) * KB * 2;
     auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED, PP>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
@@ -598,8 +669,13 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
 //      (measured: profiles/r01_v5_nt_config_sweep.txt)
 template <int EPI, bool GROUPED>
 int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
-    // grouped rows are segmented in 128-row tiles, so that path keeps the 128-row X tile
-    if (GROUPED || a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
+    if constexpr (GROUPED) {
+        // rows are segmented in FM_SEG_ROWS (= 256 = the X tile) per group; a.K = upper bound of the groups' K
+        static_assert(FM_SEG_ROWS == 256, "the grouped configurations use a 256-row X tile");
+        if (a.K >= 1536) return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, true, true>(a, max_n, s);
+        return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, true>(a, max_n, s);
+    }
+    if (a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
     if constexpr (!GROUPED) {
         int cfg = g_nt_config;
         if (cfg == 9) cfg = g_nt_auto[(a.K >= 1536 || EPI == EPI_RES) ? 1 : 0];
@@ -706,7 +782,8 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     a.splits = splits;
     const size_t lds = (size_t)TN_STAGES * TN_KB * (TN_TA + TN_TB) * 2;
     const int total_items = a.n_tiles_a * a.n_tiles_b * splits;
-    dim3 grid((total_items + 7) / 8 * 8, 1, grouped ? p->n_groups : 1);
+    const int deal = grouped ? 8 * 4 * a.n_tiles_b : 8;                // grouped: chunks of 4 A-tiles x all B-tiles per XCD
+    dim3 grid((total_items + deal - 1) / deal * deal, 1, grouped ? p->n_groups : 1);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TN(TR, G)                                                                            \
     {                                                                                               \

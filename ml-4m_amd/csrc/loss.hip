@@ -2,7 +2,7 @@
 //
 // Upstream (fourm/models/fm.py:573-637) boolean-indexes the decoder output per modality (a host
 // sync each), runs `to_logits` and F.cross_entropy (fp32, mean) and averages over modalities.
-// Here the decoder rows are bucketed on the device into 128-row-aligned segments (one per
+// Here the decoder rows are bucketed on the device into FM_SEG_ROWS-aligned segments (one per
 // modality), one grouped GEMM produces bf16 logits for every segment (gemm.hip), and the kernels
 // below turn them into per-row losses and in-place d(logits).  No host synchronisation anywhere.
 #include "common.h"
@@ -10,10 +10,10 @@
 
 namespace {
 
-constexpr int SEG_ALIGN = 128;
+constexpr int SEG_ALIGN = FM_SEG_ROWS;
 
 // grid = n_heads workgroups.  Workgroup g counts every head <= g (cheap: one int per row) to find
-// its 128-aligned start, then writes the stable list of its rows.
+// its SEG_ALIGN-aligned start, then writes the stable list of its rows.
 __global__ __launch_bounds__(1024) void segment_rows_kernel(const int32_t* __restrict__ head_of_row, int R, int n_heads,
                                                             int32_t* __restrict__ seg_start, int32_t* __restrict__ seg_count,
                                                             int32_t* __restrict__ perm, int32_t* __restrict__ row_to_padded,

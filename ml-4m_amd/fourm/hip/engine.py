@@ -25,7 +25,8 @@ from . import _lib as L
 from . import ops
 
 _WEIGHT_EPOCH = 0
-FUSE_ACT_BWD = False
+import os as _os
+FUSE_ACT_BWD = _os.environ.get("FOURM_FUSE_ACT_BWD", "0") == "1"
 
 
 def bump_weight_epoch():
@@ -525,7 +526,7 @@ class FourMEngine:
         hs = dict(n=nH, Rp=Rp, heads=heads)
         hs["seg_start"], hs["seg_count"] = ws.get("heads.seg_start", (nH,), i32), ws.get("heads.seg_count", (nH,), i32)
         hs["perm"], hs["r2p"] = ws.get("heads.perm", (Rp,), i32), ws.get("heads.r2p", (R,), i32)
-        hs["tile_group"] = ws.get("heads.tile_group", (Rp // 128,), i32)
+        hs["tile_group"] = ws.get("heads.tile_group", (Rp // ops.SEG,), i32)
         ops.segment_rows(dec["head_of_row"].view(-1), nH, hs["seg_start"], hs["seg_count"], hs["perm"], hs["r2p"], hs["tile_group"])
         sv = {} if save else None
         yp = ws.get("heads.yp", (Rp, D), torch.bfloat16)
@@ -546,7 +547,7 @@ class FourMEngine:
             self._head_groups = cache = (key, fwd, bwd, vt)
         hs["g_fwd"], hs["g_bwd"], hs["vocab_t"] = cache[1], cache[2], cache[3]
         logits = ws.get("heads.logits", (Rp, ldl), torch.bfloat16)
-        ops.gemm_nt_grouped(yp, hs["g_fwd"], hs["tile_group"], logits, hs["maxV"])
+        ops.gemm_nt_grouped(yp, hs["g_fwd"], hs["tile_group"], logits, hs["maxV"], max_K=D)
         hs.update(yp=yp, logits=logits, sv=sv)
         hs["row_loss"] = ws.get("heads.row_loss", (Rp,), torch.float32)
         hs["row_lse"] = ws.get("heads.row_lse", (Rp,), torch.float32)
@@ -745,7 +746,7 @@ class FourMEngine:
                           hs["seg_count"], hs["n"], hs["maxV"], hs["row_loss"], hs["row_lse"], hs["head_loss"], hs["total"],
                           loss_type=hs["loss_type"], grad_scale=grad_scale, write_grad=True)
         dyp = ws.get("bwd.dyp", (hs["Rp"], D), bf)
-        ops.gemm_nt_grouped(hs["logits"], hs["g_bwd"], hs["tile_group"], dyp, D)
+        ops.gemm_nt_grouped(hs["logits"], hs["g_bwd"], hs["tile_group"], dyp, D, max_K=ru(hs["maxV"], 64))
         heads = [m.decoder_embeddings[h] for h in hs["heads"]]
         if any(h.to_logits.weight.requires_grad for h in heads):
             outs = [self.grad_view(h.to_logits.weight) if h.to_logits.weight.requires_grad else None for h in heads]

@@ -33,7 +33,7 @@ def _prof(name, flops=0.0, nbytes=0.0, tag=""):
 
 
 BK = 64          # reduction granularity of the GEMMs (zero padded)
-SEG = 128        # row-segment alignment of the grouped head GEMMs
+SEG = 256        # row-segment alignment of the grouped head GEMMs (FM_SEG_ROWS)
 
 
 def ru(x: int, m: int) -> int:
@@ -80,10 +80,11 @@ def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bia
     return out
 
 
-def gemm_nt_grouped(x, groups, tile_group, out, max_N, M=None):
+def gemm_nt_grouped(x, groups, tile_group, out, max_N, M=None, max_K=0):
     a = L.GemmNTArgs()
     a.X, a.out = _p(x), _p(out)
     a.M = x.shape[0] if M is None else M
+    a.K = max_K
     a.ldx, a.ldo = _ld(x), _ld(out)
     a.epilogue = L.EPI_BF16
     a.groups, a.tile_group, a.max_N = _p(groups), _p(tile_group), max_N

@@ -180,7 +180,7 @@ def test_gemm_grouped():
     seg_count = torch.zeros_like(seg_start)
     perm = torch.zeros(Rp, dtype=torch.int32, device=DEV)
     r2p = torch.zeros(R, dtype=torch.int32, device=DEV)
-    tile_group = torch.zeros(Rp // 128, dtype=torch.int32, device=DEV)
+    tile_group = torch.zeros(Rp // ops.SEG, dtype=torch.int32, device=DEV)
     ops.segment_rows(head, n_heads, seg_start, seg_count, perm, r2p, tile_group)
     assert seg_count.tolist() == counts
     assert seg_start.tolist() == [0, 256, 256]
