@@ -101,6 +101,16 @@ int fm_layernorm_bwd(const void* dy, int lddy, const int32_t* dy_row_map, const 
                      const void* mean, const void* rstd, const void* dres, void* dx, int lddx, void* dx_bf16,
                      int lddxbf, void* dw, void* db, int R, int D, void* stream);
 
+/* Per-head LayerNorm of q / k for qk_norm models (NormAttention / NormCrossAttention q_norm, k_norm:
+ * fourm/models/fm_utils.py:235-236,244-245,279-280,290-291).  x, y: bf16 rows of H heads x 64 contiguous features
+ * (row stride ldx / ldy, e.g. the q or k column block of the fused qkv buffer); w, b: f32 (64) (b may be NULL);
+ * stats: f32 (R*H, 2) = (mean, rstd) kept for the backward.  fp32 arithmetic, bf16 result (autocast). */
+int fm_headnorm_fwd(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, void* stats, int R, int H, float eps,
+                    void* stream);
+/* dx (bf16) = LayerNorm backward of dy w.r.t. the head vectors; dw / db (f32 (64), may be NULL) are accumulated. */
+int fm_headnorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* w, const void* stats, void* dx, int lddx, void* dw,
+                    void* db, int R, int H, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Masked multi-head attention, head_dim 64 — fourm/models/fm_utils.py:160-180 (Attention) and
  * :197-219 (CrossAttention).  Element (b, t, h, d) of Q lives at Q[(b*Nq + t)*ldq + h*64 + d]

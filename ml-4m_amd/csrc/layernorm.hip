@@ -3,6 +3,7 @@
 // casts to bf16 — here the cast is fused into the store).
 //
 // HBM-bound: one wavefront per row, the row lives in registers (<= 2048 columns), 16-byte accesses.
+#include <algorithm>
 #include "common.h"
 #include "fourm_hip.h"
 
@@ -149,6 +150,86 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Per-head LayerNorm of q / k (qk_norm models: NormAttention / NormCrossAttention, fm_utils.py:222-308).
+// A head vector has 64 elements: 16 lanes x 4 elements, so one wave normalises 4 heads; under autocast the
+// norm runs in fp32 on the bf16 q / k and its output is rounded to bf16 by the following matmul.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void headnorm_fwd_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                           const float* __restrict__ b, bf16_t* __restrict__ y, int ldy,
+                                                           float2* __restrict__ stats, int R, int H, float eps) {
+    const int sub = threadIdx.x & 15;
+    const float4 wv = *(const float4*)(w + sub * 4);
+    const float4 bv = b ? *(const float4*)(b + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t total = (size_t)R * H;
+    for (size_t v = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4); v < total; v += (size_t)gridDim.x * 16) {
+        const int r = v / H, h = v % H;
+        const uint2 p = *(const uint2*)(x + (size_t)r * ldx + h * 64 + sub * 4);
+        const float e[4] = {bf2f((bf16_t)(p.x & 0xffff)), bf2f((bf16_t)(p.x >> 16)), bf2f((bf16_t)(p.y & 0xffff)), bf2f((bf16_t)(p.y >> 16))};
+        const float mean = group16_sum(e[0] + e[1] + e[2] + e[3]) * (1.0f / 64.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q += (e[i] - mean) * (e[i] - mean);
+        const float rs = rsqrtf(group16_sum(q) * (1.0f / 64.0f) + eps);
+        const float o0 = (e[0] - mean) * rs * wv.x + bv.x, o1 = (e[1] - mean) * rs * wv.y + bv.y;
+        const float o2 = (e[2] - mean) * rs * wv.z + bv.z, o3 = (e[3] - mean) * rs * wv.w + bv.w;
+        *(uint2*)(y + (size_t)r * ldy + h * 64 + sub * 4) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));
+        if (sub == 0 && stats) stats[v] = make_float2(mean, rs);
+    }
+}
+
+// dx = rs * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw += sum dy*xhat;  db += sum dy
+__global__ __launch_bounds__(256) void headnorm_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                           const float* __restrict__ w, const float2* __restrict__ stats,
+                                                           bf16_t* __restrict__ dx, int lddx, float* __restrict__ dw, float* __restrict__ db,
+                                                           int R, int H) {
+    __shared__ float red[2][16][64];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const float4 wv = *(const float4*)(w + sub * 4);
+    const float wj[4] = {wv.x, wv.y, wv.z, wv.w};
+    float aw[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t total = (size_t)R * H;
+    for (size_t v = (size_t)blockIdx.x * 16 + grp; v < total; v += (size_t)gridDim.x * 16) {
+        const int r = v / H, h = v % H;
+        const uint2 px = *(const uint2*)(x + (size_t)r * ldx + h * 64 + sub * 4);
+        const uint2 pd = *(const uint2*)(dy + (size_t)r * lddy + h * 64 + sub * 4);
+        const float2 st = stats[v];
+        const float e[4] = {bf2f((bf16_t)(px.x & 0xffff)), bf2f((bf16_t)(px.x >> 16)), bf2f((bf16_t)(px.y & 0xffff)), bf2f((bf16_t)(px.y >> 16))};
+        const float d[4] = {bf2f((bf16_t)(pd.x & 0xffff)), bf2f((bf16_t)(pd.x >> 16)), bf2f((bf16_t)(pd.y & 0xffff)), bf2f((bf16_t)(pd.y >> 16))};
+        float xh[4], g[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            xh[i] = (e[i] - st.x) * st.y;
+            g[i] = d[i] * wj[i];
+            s1 += g[i]; s2 += g[i] * xh[i];
+            aw[i] += d[i] * xh[i]; ab[i] += d[i];
+        }
+        s1 = group16_sum(s1) * (1.0f / 64.0f); s2 = group16_sum(s2) * (1.0f / 64.0f);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = st.y * (g[i] - s1 - xh[i] * s2);
+        *(uint2*)(dx + (size_t)r * lddx + h * 64 + sub * 4) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+    }
+    // column sums over the workgroup's 16 vector slots, then one atomic per column
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[0][grp][sub * 4 + i] = aw[i]; red[1][grp][sub * 4 + i] = ab[i]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) s += red[which][gq][c];
+        float* dst = which ? db : dw;
+        if (dst) unsafeAtomicAdd(dst + c, s);
+    }
+}
+
 }  // namespace
 
 static int chunks_for(int D) { const int c = (D / 4 + 63) / 64; return c <= 2 ? 2 : c <= 3 ? 3 : c <= 4 ? 4 : 8; }
@@ -202,5 +283,31 @@ extern "C" int fm_layernorm_bwd(const void* dy, int lddy, const int32_t* dy_row_
     }
 #undef LN_BWD
     FM_CHECK_LAUNCH("fm_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int fm_headnorm_fwd(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, void* stats, int R, int H, float eps,
+                               void* stream) {
+    FM_CHECK_ARG(x && w && y && R > 0 && H > 0, "fm_headnorm_fwd: bad argument");
+    FM_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ((((uintptr_t)x | (uintptr_t)y) & 7) == 0) && ((((uintptr_t)w | (uintptr_t)b) & 15) == 0),
+                 "fm_headnorm_fwd: alignment (x/y 8 B, w/b 16 B, leading dims %% 4)");
+    const size_t total = (size_t)R * H;
+    const int grid = (int)std::min<size_t>((total + 15) / 16, 256 * 32);
+    hipLaunchKernelGGL(headnorm_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const float*)w, (const float*)b,
+                       (bf16_t*)y, ldy, (float2*)stats, R, H, eps);
+    FM_CHECK_LAUNCH("fm_headnorm_fwd");
+    return 0;
+}
+
+extern "C" int fm_headnorm_bwd(const void* dy, int lddy, const void* x, int ldx, const void* w, const void* stats, void* dx, int lddx, void* dw,
+                               void* db, int R, int H, void* stream) {
+    FM_CHECK_ARG(dy && x && w && stats && dx && R > 0 && H > 0, "fm_headnorm_bwd: bad argument");
+    FM_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 7) == 0) &&
+                     ((((uintptr_t)w) & 15) == 0), "fm_headnorm_bwd: alignment (x/dy/dx 8 B, w 16 B, leading dims %% 4)");
+    const size_t total = (size_t)R * H;
+    const int grid = (int)std::min<size_t>((total + 15) / 16, 256 * 8);
+    hipLaunchKernelGGL(headnorm_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx,
+                       (const float*)w, (const float2*)stats, (bf16_t*)dx, lddx, (float*)dw, (float*)db, R, H);
+    FM_CHECK_LAUNCH("fm_headnorm_bwd");
     return 0;
 }

@@ -77,8 +77,7 @@ class FourMEngine:
         self.H = attn0.num_heads
         if self.D // self.H != 64:
             raise NotImplementedError(f"head_dim {self.D // self.H}: the HIP attention kernels are built for head_dim 64")
-        if isinstance(attn0, NormAttention):
-            raise NotImplementedError("qk_norm=True (per-head LayerNorm on q/k) has no HIP kernel yet")
+        self.qk_norm = isinstance(attn0, NormAttention)       # per-head LayerNorm on q / k (fm_utils.py:222-308)
         self.gated = isinstance(blk.mlp, GatedMlp)
         self.act = act_name(blk.mlp.act)
         if self.gated and self.act != "silu":
@@ -410,16 +409,36 @@ class FourMEngine:
             ops.gemm_nt(h, self.w(mlp.fc1.weight), act, epilogue=L.EPI_GELU, out2=pre, bias=mlp.fc1.bias, M=R, N=self.Hd, K=self.D)
         ops.gemm_nt(act, self.w(mlp.fc2.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=mlp.fc2.bias, M=R, N=self.D, K=self.Hp)
 
+    def _qk_norm_fwd(self, attn, q, k, Rq, Rk, Rqp, Rkp, sv, tag, key):
+        """q_norm / k_norm of NormAttention / NormCrossAttention: bf16 q, k -> normalised bf16 copies + (mean, rstd)."""
+        bf, f32, D, H = torch.bfloat16, torch.float32, self.D, self.H
+        qn = self._buf(sv, tag, key + ".q", (Rqp, D), bf)
+        kn = self._buf(sv, tag, key + ".k", (Rkp, D), bf)
+        sq = self._buf(sv, tag, key + ".sq", (Rqp * H, 2), f32)
+        sk = self._buf(sv, tag, key + ".sk", (Rkp * H, 2), f32)
+        ops.headnorm_fwd(q, attn.q_norm.weight, attn.q_norm.bias, qn, sq, Rq, H, attn.q_norm.eps)
+        ops.headnorm_fwd(k, attn.k_norm.weight, attn.k_norm.bias, kn, sk, Rk, H, attn.k_norm.eps)
+        return qn, kn
+
+    def _qk_norm_bwd(self, attn, sv, key, dqn, dkn, q, k, dq, dk, Rq, Rk):
+        """dq / dk (bf16) from the gradients of the normalised copies; accumulates q_norm / k_norm weight (bias) grads."""
+        for norm, d_n, x, d_x, st, R in ((attn.q_norm, dqn, q, dq, sv[key + ".sq"], Rq), (attn.k_norm, dkn, k, dk, sv[key + ".sk"], Rk)):
+            db = self._g(norm.bias) if isinstance(norm.bias, nn.Parameter) else None
+            ops.headnorm_bwd(d_n, x, norm.weight, st, d_x, self._g(norm.weight), db, R, self.H)
+
     def _self_attn_fwd(self, attn, h, x_res, x_out, B, N, R, Rp, mask, sv, tag):
         bf, D = torch.bfloat16, self.D
         qkv = self._buf(sv, tag, "qkv", (Rp, 3 * D), bf)
         o = self._buf(sv, tag, "o", (Rp, D), bf)
         ops.gemm_nt(h, self.w(attn.qkv.weight), qkv, bias=attn.qkv.bias, M=R, N=3 * D, K=D)
+        q_in, k_in = qkv[:, :D], qkv[:, D:2 * D]
+        if self.qk_norm:
+            q_in, k_in = self._qk_norm_fwd(attn, q_in, k_in, R, R, Rp, Rp, sv, tag, "qkn")
         sm = sl = None
         if sv is not None:
             sm = self._buf(sv, tag, "sm", (B, self.H, N), torch.float32)
             sl = self._buf(sv, tag, "sl", (B, self.H, N), torch.float32)
-        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, self.H, N, N, self.scale, stat_m=sm, stat_l=sl, **mask)
+        ops.attn_fwd(q_in, k_in, qkv[:, 2 * D:], o, B, self.H, N, N, self.scale, stat_m=sm, stat_l=sl, **mask)
         ops.gemm_nt(o, self.w(attn.proj.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=attn.proj.bias, M=R, N=D, K=D)
 
     def _cross_attn_fwd(self, attn, hq, hc, x_res, x_out, B, M, N, Rq, Rqp, Rc, Rcp, mask, sv, tag):
@@ -433,7 +452,10 @@ class FourMEngine:
         if sv is not None:
             sm = self._buf(sv, tag, "sm2", (B, self.H, M), torch.float32)
             sl = self._buf(sv, tag, "sl2", (B, self.H, M), torch.float32)
-        ops.attn_fwd(q, kv[:, :D], kv[:, D:], o, B, self.H, M, N, self.scale, stat_m=sm, stat_l=sl, **mask)
+        q_in, k_in = q, kv[:, :D]
+        if self.qk_norm:
+            q_in, k_in = self._qk_norm_fwd(attn, q_in, k_in, Rq, Rc, Rqp, Rcp, sv, tag, "xqkn")
+        ops.attn_fwd(q_in, k_in, kv[:, D:], o, B, self.H, M, N, self.scale, stat_m=sm, stat_l=sl, **mask)
         ops.gemm_nt(o, self.w(attn.proj.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=attn.proj.bias, M=Rq, N=D, K=D)
 
     def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag):
@@ -647,8 +669,14 @@ class FourMEngine:
         ops.gemm_nt(g_bf, self.wt(attn.proj.weight), do, M=R, N=D, K=D)
         dqkv = ws.get("bwd.dqkv", (Rp, 3 * D), bf)
         qkv = sv["qkv"]
-        ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["o"], do, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
-                     B, self.H, N, N, self.scale, sv["sm"], sv["sl"], **mask)
+        if self.qk_norm:
+            dqkn = ws.get("bwd.dqkn", (Rp, 2 * D), bf)
+            ops.attn_bwd(sv["qkn.q"], sv["qkn.k"], qkv[:, 2 * D:], sv["o"], do, dqkn[:, :D], dqkn[:, D:], dqkv[:, 2 * D:],
+                         B, self.H, N, N, self.scale, sv["sm"], sv["sl"], **mask)
+            self._qk_norm_bwd(attn, sv, "qkn", dqkn[:, :D], dqkn[:, D:], qkv[:, :D], qkv[:, D:2 * D], dqkv[:, :D], dqkv[:, D:2 * D], R, R)
+        else:
+            ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["o"], do, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                         B, self.H, N, N, self.scale, sv["sm"], sv["sl"], **mask)
         self._dW(dqkv, sv["h1"], attn.qkv, R64)
         dh = ws.get("bwd.dh", (Rp, D), bf)
         ops.gemm_nt(dqkv, self.wt(attn.qkv.weight), dh, M=R, N=D, K=3 * D)
@@ -675,8 +703,15 @@ class FourMEngine:
         dq = ws.get("bwd.dq", (Rqp, D), bf)
         dkv = ws.get("bwd.dkv", (Rcp, 2 * D), bf)
         kv = sv["kv"]
-        ops.attn_bwd(sv["q"], kv[:, :D], kv[:, D:], sv["o2"], do, dq, dkv[:, :D], dkv[:, D:], B, self.H, M, N, self.scale,
-                     sv["sm2"], sv["sl2"], **xa_mask)
+        if self.qk_norm:
+            dqn = ws.get("bwd.dqn", (Rqp, D), bf)
+            dkn = ws.get("bwd.dkn", (Rcp, D), bf)
+            ops.attn_bwd(sv["xqkn.q"], sv["xqkn.k"], kv[:, D:], sv["o2"], do, dqn, dkn, dkv[:, D:], B, self.H, M, N, self.scale,
+                         sv["sm2"], sv["sl2"], **xa_mask)
+            self._qk_norm_bwd(xa, sv, "xqkn", dqn, dkn, sv["q"], kv[:, :D], dq, dkv[:, :D], Rq, Rc)
+        else:
+            ops.attn_bwd(sv["q"], kv[:, :D], kv[:, D:], sv["o2"], do, dq, dkv[:, :D], dkv[:, D:], B, self.H, M, N, self.scale,
+                         sv["sm2"], sv["sl2"], **xa_mask)
         self._dW(dq, sv["hq"], xa.q, ru(Rq, 64))
         dhq = ws.get("bwd.dh", (Rqp, D), bf)
         ops.gemm_nt(dq, self.wt(xa.q.weight), dhq, M=Rq, N=D, K=D)

@@ -158,6 +158,15 @@ def _ln_bwd(dy, x, w, mean, rstd, dx, dres, dx_bf16, dw, db, dy_row_map, R):
     return dx
 
 
+def headnorm_fwd(x, w, b, y, stats, R, H, eps):
+    """Per-head (64 features) LayerNorm of the q / k column block ``x`` -> ``y`` (both bf16 2-D views)."""
+    L.check(L.headnorm_fwd(_p(x), _ld(x), _p(w), _p(b), _p(y), _ld(y), _p(stats), R, H, eps, _stream()))
+
+
+def headnorm_bwd(dy, x, w, stats, dx, dw, db, R, H):
+    L.check(L.headnorm_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(stats), _p(dx), _ld(dx), _p(dw), _p(db), R, H, _stream()))
+
+
 # ---------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------

@@ -369,6 +369,33 @@ def test_attention(kind, Nq, Nk, tr):
         assert rel_err(got, want) < 2e-2, (kind, tr, name, rel_err(got, want))
 
 
+@pytest.mark.parametrize("R,H,bias", [(37, 2, True), (1000, 12, False)])
+def test_headnorm(R, H, bias):
+    """Per-head LayerNorm of q / k (qk_norm models) on a column block of a wider buffer, forward and backward."""
+    ops, L = _ops()
+    D = 64 * H
+    buf = bf(randn(R, 3 * D, seed=90))
+    x = buf[:, D:2 * D]                                   # the "k" block of a fused qkv buffer
+    w, b = randn(64, seed=91) * 0.2 + 1.0, (randn(64, seed=92) * 0.1 if bias else None)
+    y = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    st = torch.zeros(R * H, 2, device=DEV)
+    ops.headnorm_fwd(x, w, b, y, st, R, H, 1e-6)
+    xr = x.float().reshape(R, H, 64).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), (b.clone().requires_grad_(True) if bias else None)
+    ref = torch.nn.functional.layer_norm(xr, (64,), wr, br, 1e-6)
+    assert max_err(y.float().reshape(R, H, 64), ref) < 2e-2 and rel_err(y.float().reshape(R, H, 64), ref) < 4e-3
+    dy = bf(randn(R, D, seed=93))
+    dx = torch.zeros(R, 3 * D, device=DEV, dtype=torch.bfloat16)
+    dw, db = torch.ones(64, device=DEV), torch.ones(64, device=DEV)
+    ops.headnorm_bwd(dy, x, w, st, dx[:, :D], dw, db if bias else None, R, H)
+    ref.backward(dy.float().reshape(R, H, 64))
+    assert rel_err(dx[:, :D].float().reshape(R, H, 64), xr.grad) < 6e-3
+    assert rel_err(dw - 1, wr.grad) < 1e-4
+    if bias:
+        assert rel_err(db - 1, br.grad) < 1e-4
+    assert float(dx[:, D:].float().abs().max()) == 0
+
+
 # ------------------------------------------------------------------------------------------------
 # element-wise
 # ------------------------------------------------------------------------------------------------

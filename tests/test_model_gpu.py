@@ -16,7 +16,7 @@ from tests.util_model import build_hip_model, tie, to_device
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "ti_mod7"]
+HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "micro_qknorm", "ti_mod7"]
 
 
 def setup(name):
@@ -139,8 +139,11 @@ def test_eval_forward_and_accumulation():
 
 
 def test_unsupported_config_is_loud():
-    case = build_case("micro_qknorm")
-    model = build_hip_model(case["cfg"]).cuda()
+    """head_dim != 64 has no attention kernel: the model must refuse, not fall back."""
+    import dataclasses
+    case = build_case("micro_swiglu")
+    cfg = dataclasses.replace(case["cfg"], heads=4)          # dim 128 / 4 heads = head_dim 32
+    model = build_hip_model(cfg).cuda()
     with pytest.raises(NotImplementedError):
         model(to_device(case["mod_dict"]), case["N"], case["M"])
 
