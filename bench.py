@@ -294,12 +294,15 @@ def main():
     }
 
     # ---- dominant kernel vs its roofline, measured live with events on the launch stream (rank 0) ----------
-    if rank == 0 and not a.no_kernel_profile:
-        prof = LaunchProfiler()
+    if not a.no_kernel_profile:
+        # every rank runs the two extra steps (they contain the gradient collectives); only rank 0 records
+        prof = LaunchProfiler() if rank == 0 else None
         ops.set_profiler(prof)
         for i in range(2):
             step(i)
         ops.set_profiler(None)
+        fence()
+    if rank == 0 and not a.no_kernel_profile:
         agg = prof.summary()
         tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
         symbol = {"gemm_nt": "gemm_nt_kernel<128,256,2,4,{{32|64}},3,EPI={epi},false>  (csrc/gemm.hip)",

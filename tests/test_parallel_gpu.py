@@ -1,0 +1,99 @@
+"""Data parallelism end to end on ONE GPU: two processes share cuda:0 and exchange gradients through gloo (RCCL
+refuses two ranks on one device; the driver's 8-GPU run covers RCCL).  Checks the replica broadcast at construction,
+that every rank ends with the MEAN of the per-rank gradients of the HIP backward (stage-wise overlapped exchange),
+and ``no_sync()`` accumulation."""
+import os
+import random
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import fourm_oracle as O
+from tests.golden.cases import build_case
+from tests.util_model import build_hip_model, to_device
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASE = "micro_swiglu"
+
+
+def _model(case):
+    m = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    m.load_state_dict(case["sd"], strict=True)
+    return m.cuda().train()
+
+
+def _batch(case, rank, step):
+    c = case["cfg"]
+    return to_device(O.synthetic_mod_dict(c, 3, 20, 18, seed=100 + 10 * step + rank))
+
+
+def _local_grads(model, case, rank, steps):
+    """Plain single-process gradients of ``steps`` accumulated micro-batches (the reference the exchange must average)."""
+    model.zero_grad(set_to_none=True)
+    for s in steps:
+        random.seed(7 + s)
+        loss, _ = model(_batch(case, rank, s), case["N"], case["M"])
+        loss.backward()
+    model.engine._ensure_flat()
+    return model.engine.flat_grads.detach().clone()
+
+
+def worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fourm.parallel import DataParallel
+    case = build_case(CASE)
+    model = _model(case)
+    if rank == 1:                                   # replicas must start from rank 0's weights
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.37)
+    dp = DataParallel(model)
+    random.seed(7)
+    loss, _ = dp(_batch(case, rank, 0), case["N"], case["M"])
+    loss.backward()
+    torch.cuda.synchronize()
+    torch.save(model.engine.flat_grads.detach().cpu(), os.path.join(out_dir, f"sync_r{rank}.pt"))
+    torch.save(model.engine.flat_params.detach().cpu(), os.path.join(out_dir, f"params_r{rank}.pt"))
+    # gradient accumulation: first micro-batch inside no_sync(), exchange on the second
+    model.zero_grad(set_to_none=True)
+    with dp.no_sync():
+        random.seed(7 + 1)
+        dp(_batch(case, rank, 1), case["N"], case["M"])[0].backward()
+    random.seed(7 + 2)
+    dp(_batch(case, rank, 2), case["N"], case["M"])[0].backward()
+    torch.cuda.synchronize()
+    torch.save(model.engine.flat_grads.detach().cpu(), os.path.join(out_dir, f"accum_r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_processes_one_gpu(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {**os.environ, "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "ml-4m_amd"), os.environ.get("PYTHONPATH", "")])}
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), "2", str(port), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
+
+    case = build_case(CASE)
+    model = _model(case)
+    ref_params = None
+    for name, steps in (("sync", [0]), ("accum", [1, 2])):
+        want = (_local_grads(model, case, 0, steps) + _local_grads(model, case, 1, steps)).cpu() / 2
+        if ref_params is None:
+            ref_params = model.engine.flat_params.detach().cpu()
+        for r in range(2):
+            got = torch.load(tmp_path / f"{name}_r{r}.pt")
+            err = float((got - want).norm() / want.norm())
+            assert err < 2e-5, (name, r, err)            # fp32 sums in a different order (atomics + the two-rank mean)
+    for r in range(2):                                   # rank 1's perturbed weights were overwritten by the broadcast
+        assert torch.equal(torch.load(tmp_path / f"params_r{r}.pt"), ref_params)
+
+
+if __name__ == "__main__":
+    worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
