@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--n-out", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test hook: several ranks on one GPU)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
@@ -219,11 +220,16 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "no GPU visible: the 4M hot path has no CPU implementation"}))
         sys.exit(2)
+    if a.dist_backend != "nccl":
+        local = local % torch.cuda.device_count()          # test hook: ranks may share a device under gloo
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
     if a.gpus != world:
         if rank == 0:
             print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
