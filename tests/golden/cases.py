@@ -20,6 +20,20 @@ def micro_mods():
     ]
 
 
+def l_like_mods():
+    """4M-L / mod21 shaped modalities at 224 px: pixels, a T5-embedded caption (77 x 4096), grid tokens, a 16-token
+    global modality with a learned position table, and two text sequences (BASELINE.json configs[3], depth 1)."""
+    return [
+        O.ModSpec("caption", "seq", vocab=3000, n_pos=64),
+        O.ModSpec("det", "seq", vocab=1000, n_pos=40),
+        O.ModSpec("rgb@224", "patch", n_pos=196, patch=16, in_dec=False),
+        O.ModSpec("t5_caption", "seq_emb", n_pos=77, orig_dim=4096, in_dec=False),
+        O.ModSpec("tok_depth@224", "tok", vocab=8192, n_pos=196, patch=16),
+        O.ModSpec("tok_rgb@224", "tok", vocab=16384, n_pos=196, patch=16),
+        O.ModSpec("tok_g", "tok", vocab=512, n_pos=16, patch=56),
+    ]
+
+
 def _micro(**kw):
     base = dict(dim=128, enc_depth=2, dec_depth=2, heads=2, mods=micro_mods())
     base.update(kw)
@@ -35,6 +49,9 @@ CASES = {
                                           registers=2, causal=True),
                        B=3, N=20, M=18, bud=(20, 18), norm_bias=True, share_embedding=False, seed=5),
     "micro_qknorm": dict(cfg=lambda: _micro(qk_norm=True, sep=False), B=2, N=16, M=16, bud=(16, 16), seed=7),
+    # 4M-L geometry (D=1024, 16 heads, hidden 2730 -> padded 2752, 256+256 tokens), one block each side
+    "l_like": dict(cfg=lambda: O.TrunkCfg(dim=1024, enc_depth=1, dec_depth=1, heads=16, mods=l_like_mods()),
+                   B=2, N=256, M=256, bud=(256, 256), seed=11),
     # BASELINE.json configs[0]: 4M-Ti mod7, one masked-modeling step, seq_len 128+128, batch 2
     "ti_mod7": dict(cfg=lambda: O.named_cfg("tiny", O.mod7_specs()), B=2, N=128, M=128, bud=(128, 128), seed=0),
 }

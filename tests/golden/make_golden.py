@@ -146,7 +146,8 @@ def run_case(name: str, check_only: bool):
     same_int(taps["enc_mask"], e_mask, "encoder mask"); same_int(taps["enc_mod_mask"], e_mod, "encoder mod_mask")
     same_int(taps["dec_mask"], d_mask, "decoder mask"); same_int(taps["dec_mod_mask"], d_mod, "decoder mod_mask")
     same_int(taps["dec_target_ids"], d_tgt, "target ids"); same_int(taps["dec_attn_mask"], d_attn, "decoder attn mask")
-    assert torch.equal(taps["enc_tokens"], e_tok.float()), "encoder tokens"
+    # gathers are exact; the dense projections (pixels, T5 rows) only agree to fp32 summation order
+    close(taps["enc_tokens"], e_tok.float().detach(), "encoder tokens", 1e-5)
     assert torch.equal(taps["enc_emb"], e_emb), "encoder emb"
     assert torch.equal(taps["dec_tokens"], d_tok), "decoder tokens"
     assert torch.equal(taps["dec_emb"], d_emb), "decoder emb"

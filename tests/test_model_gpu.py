@@ -16,7 +16,7 @@ from tests.util_model import build_hip_model, tie, to_device
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "micro_qknorm", "ti_mod7"]
+HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "micro_qknorm", "ti_mod7", "l_like"]
 
 
 def setup(name):
