@@ -29,43 +29,57 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const int* __restrict__ row_map, int R, int D, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
-    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
-        const float* xr = x + (size_t)r * ldx;
-        float4 v[MAXC];
-        float s = 0.f;
+    // weights once per wave; two rows per iteration with both rows' loads issued first (HBM stream: more bytes in flight)
+    float4 ww[MAXC], bb[MAXC];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            v[c] = ch < nch ? *(const float4*)(xr + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
-        }
-        const float mu = wave_sum(s) / (float)D;
-        float q = 0.f;
+    for (int c = 0; c < MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        ww[c] = ch < nch ? *(const float4*)(w + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bb[c] = (b && ch < nch) ? *(const float4*)(b + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    constexpr int NR = 2;
+    for (int r0 = blockIdx.x * 4 + wave; r0 < R; r0 += gridDim.x * 4 * NR) {
+        float4 v[NR][MAXC];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nch) {
-                const float a0 = v[c].x - mu, a1 = v[c].y - mu, a2 = v[c].z - mu, a3 = v[c].w - mu;
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        for (int q = 0; q < NR; ++q) {
+            const int r = r0 + q * gridDim.x * 4;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                v[q][c] = (ch < nch && r < R) ? *(const float4*)(x + (size_t)r * ldx + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-        if (lane == 0) {
-            if (mean) mean[r] = mu;
-            if (rstd) rstd[r] = rs;
-        }
-        const int dst = row_map ? row_map[r] : r;
-        if (dst < 0) continue;
-        OutT* yr = y + (size_t)dst * ldy;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nch) {
-                const float4 ww = *(const float4*)(w + ch * 4);
-                float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b) bb = *(const float4*)(b + ch * 4);
-                store4<OutT>(yr + ch * 4, (v[c].x - mu) * rs * ww.x + bb.x, (v[c].y - mu) * rs * ww.y + bb.y,
-                             (v[c].z - mu) * rs * ww.z + bb.z, (v[c].w - mu) * rs * ww.w + bb.w);
+        for (int q = 0; q < NR; ++q) {
+            const int r = r0 + q * gridDim.x * 4;
+            if (r >= R) continue;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) s += (v[q][c].x + v[q][c].y) + (v[q][c].z + v[q][c].w);
+            const float mu = wave_sum(s) / (float)D;
+            float sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nch) {
+                    const float a0 = v[q][c].x - mu, a1 = v[q][c].y - mu, a2 = v[q][c].z - mu, a3 = v[q][c].w - mu;
+                    sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+            const float rs = rsqrtf(wave_sum(sq) / (float)D + eps);
+            if (lane == 0) {
+                if (mean) mean[r] = mu;
+                if (rstd) rstd[r] = rs;
+            }
+            const int dst = row_map ? row_map[r] : r;
+            if (dst < 0) continue;
+            OutT* yr = y + (size_t)dst * ldy;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nch)
+                    store4<OutT>(yr + ch * 4, (v[q][c].x - mu) * rs * ww[c].x + bb[c].x, (v[q][c].y - mu) * rs * ww[c].y + bb[c].y,
+                                 (v[q][c].z - mu) * rs * ww[c].z + bb[c].z, (v[q][c].w - mu) * rs * ww[c].w + bb[c].w);
             }
         }
     }
@@ -92,44 +106,66 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         wv[c] = ch < nch ? *(const float4*)(w + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int r_end = min(R, (int)(blockIdx.x + 1) * BWD_ROWS);
-    for (int r = blockIdx.x * BWD_ROWS + wave; r < r_end; r += 4) {
-        const int src = dy_row_map ? dy_row_map[r] : r;
-        const float mu = mean[r], rs = rstd[r];
-        const float* xr = x + (size_t)r * ldx;
-        float4 g[MAXC], xh[MAXC];
-        float s1 = 0.f, s2 = 0.f;
+    // Two rows per iteration, every load of both rows (dy, x, residual gradient) issued before any arithmetic:
+    // the kernel is a pure HBM stream and a wave otherwise waits out one memory round trip per row.
+    constexpr int NR = 2;
+    for (int r0 = blockIdx.x * BWD_ROWS + wave; r0 < r_end; r0 += 4 * NR) {
+        uint2 dyp[NR][MAXC];
+        float4 xv[NR][MAXC], rv[NR][MAXC];
+        float mu[NR], rs[NR];
+        bool live[NR];
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            g[c] = xh[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ch < nch) {
-                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (src >= 0) {
-                    const uint2 p = *(const uint2*)(dy + (size_t)src * lddy + ch * 4);
-                    d = make_float4(bf2f((bf16_t)(p.x & 0xffff)), bf2f((bf16_t)(p.x >> 16)), bf2f((bf16_t)(p.y & 0xffff)), bf2f((bf16_t)(p.y >> 16)));
+        for (int q = 0; q < NR; ++q) {
+            const int r = r0 + 4 * q;
+            live[q] = r < r_end;
+            const int rr = live[q] ? r : r0;
+            const int src = dy_row_map ? dy_row_map[rr] : rr;
+            mu[q] = mean[rr]; rs[q] = rstd[rr];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                dyp[q][c] = make_uint2(0u, 0u);
+                xv[q][c] = rv[q][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ch < nch && live[q]) {
+                    if (src >= 0) dyp[q][c] = *(const uint2*)(dy + (size_t)src * lddy + ch * 4);
+                    xv[q][c] = *(const float4*)(x + (size_t)rr * ldx + ch * 4);
+                    if (dres) rv[q][c] = *(const float4*)(dres + (size_t)rr * lddx + ch * 4);
                 }
-                const float4 xv = *(const float4*)(xr + ch * 4);
-                xh[c] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                aw[c].x += d.x * xh[c].x; aw[c].y += d.y * xh[c].y; aw[c].z += d.z * xh[c].z; aw[c].w += d.w * xh[c].w;
-                ab[c].x += d.x; ab[c].y += d.y; ab[c].z += d.z; ab[c].w += d.w;
-                g[c] = make_float4(d.x * wv[c].x, d.y * wv[c].y, d.z * wv[c].z, d.w * wv[c].w);
-                s1 += (g[c].x + g[c].y) + (g[c].z + g[c].w);
-                s2 += (g[c].x * xh[c].x + g[c].y * xh[c].y) + (g[c].z * xh[c].z + g[c].w * xh[c].w);
             }
         }
-        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nch) {
-                float4 o = make_float4(rs * (g[c].x - m1 - xh[c].x * m2), rs * (g[c].y - m1 - xh[c].y * m2),
-                                       rs * (g[c].z - m1 - xh[c].z * m2), rs * (g[c].w - m1 - xh[c].w * m2));
-                if (dres) {
-                    const float4 t = *(const float4*)(dres + (size_t)r * lddx + ch * 4);
-                    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+        for (int q = 0; q < NR; ++q) {
+            if (!live[q]) continue;
+            const int r = r0 + 4 * q;
+            float4 g[MAXC], xh[MAXC];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                g[c] = xh[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ch < nch) {
+                    const uint2 p = dyp[q][c];
+                    const float4 d = make_float4(bf2f((bf16_t)(p.x & 0xffff)), bf2f((bf16_t)(p.x >> 16)), bf2f((bf16_t)(p.y & 0xffff)), bf2f((bf16_t)(p.y >> 16)));
+                    const float4 v = xv[q][c];
+                    xh[c] = make_float4((v.x - mu[q]) * rs[q], (v.y - mu[q]) * rs[q], (v.z - mu[q]) * rs[q], (v.w - mu[q]) * rs[q]);
+                    aw[c].x += d.x * xh[c].x; aw[c].y += d.y * xh[c].y; aw[c].z += d.z * xh[c].z; aw[c].w += d.w * xh[c].w;
+                    ab[c].x += d.x; ab[c].y += d.y; ab[c].z += d.z; ab[c].w += d.w;
+                    g[c] = make_float4(d.x * wv[c].x, d.y * wv[c].y, d.z * wv[c].z, d.w * wv[c].w);
+                    s1 += (g[c].x + g[c].y) + (g[c].z + g[c].w);
+                    s2 += (g[c].x * xh[c].x + g[c].y * xh[c].y) + (g[c].z * xh[c].z + g[c].w * xh[c].w);
                 }
-                *(float4*)(dx + (size_t)r * lddx + ch * 4) = o;
-                if (dx_bf) *(uint2*)(dx_bf + (size_t)r * lddxbf + ch * 4) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+            }
+            const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nch) {
+                    const float4 t = rv[q][c];
+                    const float4 o = make_float4(rs[q] * (g[c].x - m1 - xh[c].x * m2) + t.x, rs[q] * (g[c].y - m1 - xh[c].y * m2) + t.y,
+                                                 rs[q] * (g[c].z - m1 - xh[c].z * m2) + t.z, rs[q] * (g[c].w - m1 - xh[c].w * m2) + t.w);
+                    *(float4*)(dx + (size_t)r * lddx + ch * 4) = o;
+                    if (dx_bf) *(uint2*)(dx_bf + (size_t)r * lddxbf + ch * 4) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
+                }
             }
         }
     }

@@ -22,7 +22,7 @@ class _VitEngine(FourMEngine):
         self.D, self.H = enc.dim_tokens, blk.attn.num_heads
         if self.D // self.H != 64:
             raise NotImplementedError("the HIP attention kernels are built for head_dim 64")
-        self.gated, self.act = False, "gelu"
+        self.gated, self.act, self.qk_norm = False, "gelu", False
         self.Hd = blk.mlp.hidden_features
         self.Hp = ru(self.Hd, 64)
         self.scale, self.eps = 64 ** -0.5, blk.norm1.eps
