@@ -82,6 +82,10 @@ typedef struct fm_gemm_tn_args {
     int32_t n_groups, max_N, max_R, pad_;
 } fm_gemm_tn_args;
 int fm_gemm_tn(const fm_gemm_tn_args* args, void* stream);
+/* tile schedule of fm_gemm_tn (table in csrc/gemm.hip): 0 = K-step 32, two workgroups per CU; 1 = K-step 64,
+ * one workgroup per CU, ping-pong schedule (half the workgroups -> half the atomic epilogue traffic). */
+void fm_set_gemm_tn_config(int cfg);
+int fm_get_gemm_tn_config(void);
 void fm_set_tn_transpose_read(int on);
 int fm_get_tn_transpose_read(void);
 

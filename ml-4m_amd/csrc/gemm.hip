@@ -14,6 +14,7 @@
 // Contracts (the Python layer allocates every bf16 buffer and guarantees them):
 //   * the reduction dimension is a multiple of 64 and zero padded;
 //   * leading dimensions are multiples of 8 elements (16-byte aligned rows).
+#include <type_traits>
 #include "common.h"
 #include "fourm_hip.h"
 
@@ -467,16 +468,28 @@ struct TNArgs {
     int a_cols, b_cols;                       // readable columns of A / B (clamp for the tile loads)
     const fm_gemm_group* groups; const int* seg_start; const int* seg_count;   // grouped (per-modality rows)
     int n_tiles_a, n_tiles_b;
+    int dbg_store;
 };
 
 // element (row, col) of a row-major [64][cols] bf16 LDS tile with RB bytes per row; 16-byte chunks are
 // XOR-swizzled by (row & 3) << 2 so that the 4 rows a transpose read touches fall on different banks
 template <int RB>
-__device__ __forceinline__ const char* tn_addr(const char* tile, int row, int col) {
-    return tile + row * RB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2;
+__device__ __forceinline__ int tn_off(int row, int col) { return row * RB + ((((col >> 3) ^ ((row & 3) << 2))) << 4) + (col & 7) * 2; }
+template <int RB>
+__device__ __forceinline__ const char* tn_addr(const char* tile, int row, int col) { return tile + tn_off<RB>(row, col); }
+
+// one half (4 rows x 16 columns per 16-lane group) of a transpose-read fragment at a compile-time byte offset
+template <int OFF>
+__device__ __forceinline__ s16x4_t tr_read(uint32_t lds_addr) {
+    s16x4_t h;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h) : "v"(lds_addr), "n"(OFF));
+    return h;
 }
 
-template <bool TR, bool GROUPED, int TA, int TB, int WA, int WB, int KB, int STAGES>
+// PP = the ping-pong schedule of gemm_nt_kernel (wave rows one barrier apart; see there) on the TN operands: the
+// fragment addresses of one lane differ between k-steps only by constants (the swizzle key (row & 3) does not
+// change), so a K-tile's 8 * KB/16 transpose reads use immediate offsets on four per-lane base addresses.
+template <bool TR, bool GROUPED, int TA, int TB, int WA, int WB, int KB, int STAGES, bool PP = false>
 __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     constexpr int NWAVES = WA * WB;
     constexpr int RBA = TA * 2, RBB = TB * 2;                         // bytes per LDS tile row
@@ -548,6 +561,31 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
         }
     };
+    // the same pieces, a share of them per call (ping-pong: spread between the MFMA groups of the leading wave row)
+    auto stage_part = [&](int t, int buf, int part, int nparts) {
+        char* base = smem + buf * STAGE;
+        const int r0 = r_begin + t * KB;
+        constexpr int NP = PA / NWAVES + PB / NWAVES;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            if (q < part * NP / nparts || q >= (part + 1) * NP / nparts) continue;
+            if (q < PA / NWAVES) {
+                constexpr int LPR = RBA / 16, RPP = 1024 / RBA;
+                const int piece = q * NWAVES + wave;
+                const int row = piece * RPP + lane / LPR;
+                const int lc = (lane % LPR) ^ ((row & 3) << 2);
+                int ca = n0 + lc * 8; ca = ca <= a.a_cols - 8 ? ca : a.a_cols - 8;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(a.A + (size_t)(r0 + row) * a.lda + ca), LDS_PTR(base + piece * 1024), 16, 0, 0);
+            } else {
+                constexpr int LPR = RBB / 16, RPP = 1024 / RBB;
+                const int piece = (q - PA / NWAVES) * NWAVES + wave;
+                const int row = piece * RPP + lane / LPR;
+                const int lc = (lane % LPR) ^ ((row & 3) << 2);
+                int cb = k0 + lc * 8; cb = cb <= a.b_cols - 8 ? cb : a.b_cols - 8;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
+            }
+        }
+    };
 
     f32x16_t acc[2][2];
 #pragma unroll
@@ -562,6 +600,70 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     for (int p = 0; p < STAGES - 1; ++p)
         if (p < NT_) stage(t_begin + p, p);
     const int fhi = lane >> 5;
+    if constexpr (PP) {
+        static_assert(TR && WA == 2 && NWAVES == 8 && STAGES == 3, "ping-pong schedule: transpose reads, 2 wave rows of 4 waves, 3-deep ring");
+        constexpr int KS = KB / 16;
+        const bool lead = wa == 0;
+        // per-lane base addresses (LDS byte offsets inside a stage) of the 2 + 2 fragments at k-step 0
+        const int li = lane & 15;
+        const int frow0 = fhi * 8 + (li >> 2), fcol = ((lane >> 4) & 1) * 16 + (li & 3) * 4;
+        const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+        uint32_t baseA[2], baseB[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            baseA[i] = (uint32_t)tn_off<RBA>(frow0, wa * 64 + i * 32 + fcol);
+            baseB[i] = (uint32_t)tn_off<RBB>(frow0, wb * 64 + i * 32 + fcol) + KB * RBA;
+        }
+        if (NT_ > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (!lead) block_barrier();
+        int buf = 0;
+        for (int it = 0; it < NT_; ++it) {
+            const bool more = it + 2 < NT_;
+            const int nbuf = buf >= 1 ? buf - 1 : 2;
+            const uint32_t st = smem_lds + buf * STAGE;
+            union Frag { bf16x8_t v; s16x4_t h[2]; };
+            Frag af[KS][2], bfr[KS][2];
+            auto read_k = [&](auto kk_c) {
+                constexpr int kk = decltype(kk_c)::value;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[kk][i].h[0] = tr_read<kk * 16 * RBA>(st + baseA[i]);
+                    af[kk][i].h[1] = tr_read<kk * 16 * RBA + 4 * RBA>(st + baseA[i]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bfr[kk][j].h[0] = tr_read<kk * 16 * RBB>(st + baseB[j]);
+                    bfr[kk][j].h[1] = tr_read<kk * 16 * RBB + 4 * RBB>(st + baseB[j]);
+                }
+            };
+            read_k(std::integral_constant<int, 0>{});
+            if constexpr (KS > 1) read_k(std::integral_constant<int, 1>{});
+            if constexpr (KS > 2) read_k(std::integral_constant<int, 2>{});
+            if constexpr (KS > 3) read_k(std::integral_constant<int, 3>{});
+            if (!lead) {
+                if (more) { stage(t_begin + it + 2, nbuf); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
+            }
+            wait_lgkmcnt<0>();
+            block_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i].v, bfr[kk][j].v, acc[i][j], 0, 0, 0);
+                if (lead && more) stage_part(t_begin + it + 2, nbuf, kk, KS);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (lead) { if (more) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (lead || it + 1 < NT_) block_barrier();
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
+        }
+    } else {
     int buf = 0;
     for (int it = 0; it < NT_; ++it) {
         const int younger = NT_ - 1 - it;
@@ -616,6 +718,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
         }
         buf = buf + 1 == STAGES ? 0 : buf + 1;
     }
+    }
     // accumulator: rows <-> n (A columns), cols <-> k (B columns); lane = k, regs = n
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -626,7 +729,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wa * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-                if (n < N) unsafeAtomicAdd(out + (size_t)n * a.ldo + k, acc[i][j][r]);
+                if (n < N) { if (a.dbg_store) out[(size_t)n * a.ldo + k] = acc[i][j][r]; else unsafeAtomicAdd(out + (size_t)n * a.ldo + k, acc[i][j][r]); }
             }
     }
 }
@@ -748,6 +851,9 @@ extern "C" void fm_set_gemm_nt_config(int cfg) {
     if (cfg >> 16) { g_nt_auto[0] = (cfg >> 16) & 0xf; g_nt_auto[1] = (cfg >> 20) & 0xf; }   // bits 16-19 / 20-23: automatic pair
 }
 extern "C" int fm_get_gemm_nt_config(void) { return g_nt_config; }
+static int g_tn_config = 1;
+extern "C" void fm_set_gemm_tn_config(int cfg) { g_tn_config = cfg; }
+extern "C" int fm_get_gemm_tn_config(void) { return g_tn_config; }
 static int g_tn_use_tr = 1;   // ds_read_b64_tr_b16 semantics verified on hardware (tools/probe_gfx950.hip)
 extern "C" void fm_set_tn_transpose_read(int on) { g_tn_use_tr = on; }
 extern "C" int fm_get_tn_transpose_read(void) { return g_tn_use_tr; }
@@ -766,35 +872,43 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     FM_CHECK_ARG(a.a_cols >= 8 && a.b_cols >= 8, "fm_gemm_tn: operands need at least 8 readable columns");
     a.groups = p->groups; a.seg_start = p->seg_start; a.seg_count = p->seg_count;
     const int max_n = grouped ? p->max_N : p->N;
-    constexpr int TN_TA = 128, TN_TB = 256, TN_KB = 32, TN_STAGES = 3;   // 72 KB of LDS: two workgroups per CU
+    // configuration 0: K-step 32, 72 KB of LDS, two workgroups per CU, lock-step waves
+    // configuration 1: K-step 64, 144 KB, ONE workgroup per CU, ping-pong schedule: half the workgroups, so half the
+    //                  fp32 atomic traffic of the epilogue (workgroups x 128 KB per launch, ~25 us at 512 workgroups)
+    constexpr int TN_TA = 128, TN_TB = 256, TN_STAGES = 3;
+    // (the grouped head GEMM keeps configuration 0: short, uneven reductions - 940 vs 1110 us at the 4M-B shapes)
+    const bool pp = g_tn_config == 1 && !grouped && (p->force_tr < 0 || (p->force_tr & 1));
+    const int kb = pp ? 64 : 32, slots = pp ? 256 : 512;
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
     if (splits <= 0) {
-        // Fill the chip in ONE round: 256 CUs x 2 resident workgroups = 512 slots (e.g. the 66 tiles of an MLP
-        // weight gradient take 7 splits = 462 workgroups; 8 splits would leave 16 workgroups for a second round).
+        // Fill the chip in ONE round (e.g. 66 tiles on 512 slots take 7 splits = 462 workgroups; 8 would leave 16
+        // workgroups for a second round).
         const int tiles = a.n_tiles_a * a.n_tiles_b;
-        const int nt = grouped ? (p->max_R + TN_KB - 1) / TN_KB : p->R / TN_KB;
-        splits = tiles >= 512 ? 1 : 512 / tiles;
+        const int nt = grouped ? (p->max_R + kb - 1) / kb : p->R / kb;
+        splits = tiles >= slots ? 1 : slots / tiles;
         while (splits > 1 && nt / splits < 8) --splits;                // keep >= 8 reduction tiles per workgroup
         if (splits > 64) splits = 64;
         if (nt < 16) splits = 1;                                       // tiny problems
     }
     a.splits = splits;
-    const size_t lds = (size_t)TN_STAGES * TN_KB * (TN_TA + TN_TB) * 2;
+    const size_t lds = (size_t)TN_STAGES * kb * (TN_TA + TN_TB) * 2;
     const int total_items = a.n_tiles_a * a.n_tiles_b * splits;
     const int deal = grouped ? 8 * 4 * a.n_tiles_b : 8;                // grouped: chunks of 4 A-tiles x all B-tiles per XCD
     dim3 grid((total_items + deal - 1) / deal * deal, 1, grouped ? p->n_groups : 1);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_TN(TR, G)                                                                            \
+#define LAUNCH_TN(TR, G, KBV, PPV)                                                                  \
     {                                                                                               \
-        auto k = gemm_tn_kernel<TR, G, TN_TA, TN_TB, 2, 4, TN_KB, TN_STAGES>;                              \
+        auto k = gemm_tn_kernel<TR, G, TN_TA, TN_TB, 2, 4, KBV, TN_STAGES, PPV>;                    \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true); \
         (void)once;                                                                                 \
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a);                                          \
     }
-    const int tr = p->force_tr >= 0 ? p->force_tr : g_tn_use_tr;
-    if (tr) { if (grouped) LAUNCH_TN(true, true) else LAUNCH_TN(true, false) }
-    else { if (grouped) LAUNCH_TN(false, true) else LAUNCH_TN(false, false) }
+    a.dbg_store = p->force_tr >= 2;
+    const int tr = p->force_tr >= 0 ? (p->force_tr & 1) : g_tn_use_tr;
+    if (pp) { if (grouped) LAUNCH_TN(true, true, 64, true) else LAUNCH_TN(true, false, 64, true) }
+    else if (tr) { if (grouped) LAUNCH_TN(true, true, 32, false) else LAUNCH_TN(true, false, 32, false) }
+    else { if (grouped) LAUNCH_TN(false, true, 32, false) else LAUNCH_TN(false, false, 32, false) }
 #undef LAUNCH_TN
     FM_CHECK_LAUNCH("fm_gemm_tn");
     return 0;

@@ -150,6 +150,25 @@ def test_gemm_tn(tr, R, N, K):
     assert rel_err(out, ref) < 1e-4, (tr, rel_err(out, ref))
 
 
+@pytest.mark.parametrize("R,N,K,splits", [(64, 128, 128, 0), (320, 200, 136, 1), (4096, 768, 384, 0), (32768, 304, 520, 0)])
+def test_gemm_tn_pingpong_schedule(R, N, K, splits):
+    """Both schedules of fm_gemm_tn: 1 (default) = K-step 64, one workgroup per CU, wave rows one barrier apart; 0 =
+    K-step 32, lock-step.  Repeated to screen for races in the staggered LDS ring."""
+    ops, L = _ops()
+    a = bf(randn(R, N, seed=14) + torch.arange(N, device=DEV)[None] * 0.01)
+    b = bf(randn(R, K, seed=15))
+    ref = a.float().t() @ b.float()
+    for cfg in (1, 0):
+        L.lib.fm_set_gemm_tn_config(cfg)
+        try:
+            for _ in range(5):
+                out = torch.zeros(N, K, device=DEV, dtype=torch.float32)
+                ops.gemm_tn(a, b, out, splits=splits)
+                assert rel_err(out, ref) < 1e-4, (cfg, rel_err(out, ref))
+        finally:
+            L.lib.fm_set_gemm_tn_config(1)
+
+
 def test_gemm_tn_identity_layout():
     ops, L = _ops()
     R = 128

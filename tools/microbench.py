@@ -53,8 +53,10 @@ L.lib.fm_set_gemm_nt_config(9 + 256)
 for name, N, K in (("dW qkv", 3 * D, D), ("dW proj", D, D), ("dW fc2", D, Hd), ("dW fc1", Hd, D)):
     a_, b_ = rnd(R, N), rnd(R, K)
     out = torch.zeros(N, K, device=dev)
-    for sp in (0, 8, 16):
-        report(f"tn splits={sp or 'auto'} {name} N={N} K={K}", timeit(lambda: ops.gemm_tn(a_, b_, out, splits=sp)), 2.0 * R * N * K)
+    for cfg in (0, 1):
+        L.lib.fm_set_gemm_tn_config(cfg)
+        report(f"tn cfg{cfg} {name} N={N} K={K}", timeit(lambda: ops.gemm_tn(a_, b_, out)), 2.0 * R * N * K)
+    L.lib.fm_set_gemm_tn_config(1)
 
 B, H, N = 256, 12, 128
 qkv = rnd(B * N, 3 * D)
