@@ -94,60 +94,78 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 // Multi-tensor refresh of the bf16 weight shadows: one launch walks a device table of (fp32 master -> bf16
 // shadow) jobs in 64x64 tiles; a job either casts in place or casts + transposes through LDS.  Pad rows /
 // columns of the destinations are never written (they are zero from allocation).
-__global__ __launch_bounds__(256) void shadow_refresh_kernel(const fm_shadow_desc* __restrict__ descs, int n) {
+constexpr int SHADOW_TILES_PER_BLOCK = 8;   // consecutive tiles per workgroup: one table search amortised over 128 KB of work
+
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const fm_shadow_desc* __restrict__ descs, int n, int total_tiles) {
     __shared__ float tile[64][65];
-    int lo = 0, hi = n - 1;                                   // last job with tile_start <= blockIdx.x
+    const int t_first = blockIdx.x * SHADOW_TILES_PER_BLOCK;
+    int lo = 0, hi = n - 1;                                   // last job with tile_start <= t_first
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        if (descs[mid].tile_start <= t_first) lo = mid; else hi = mid - 1;
     }
-    const fm_shadow_desc d = descs[lo];
-    const int t = blockIdx.x - d.tile_start;
-    const int tiles_c = (d.cols + 63) / 64;
-    const int tr0 = (t / tiles_c) * 64, tc0 = (t % tiles_c) * 64;
-    const float* src = (const float*)d.src;
-    bf16_t* dst = (bf16_t*)d.dst;
-    const bool vec_src = ((((uintptr_t)src) & 15) == 0) && (d.ld_src % 4 == 0);
-    const bool vec_dst = ((((uintptr_t)dst) & 7) == 0) && (d.ld_dst % 4 == 0);
+    fm_shadow_desc d = descs[lo];
+    int next_start = lo + 1 < n ? descs[lo + 1].tile_start : 0x7fffffff;
     const int q = (threadIdx.x & 15) * 4, p = threadIdx.x >> 4;
+    for (int tt = t_first; tt < min(total_tiles, t_first + SHADOW_TILES_PER_BLOCK); ++tt) {
+        if (tt >= next_start) {                               // walked into the next job
+            ++lo;
+            d = descs[lo];
+            next_start = lo + 1 < n ? descs[lo + 1].tile_start : 0x7fffffff;
+        }
+        const int t = tt - d.tile_start;
+        const int tiles_c = (d.cols + 63) / 64;
+        const int tr0 = (t / tiles_c) * 64, tc0 = (t % tiles_c) * 64;
+        const float* src = (const float*)d.src;
+        bf16_t* dst = (bf16_t*)d.dst;
+        const bool vec_src = ((((uintptr_t)src) & 15) == 0) && (d.ld_src % 4 == 0);
+        const bool vec_dst = ((((uintptr_t)dst) & 7) == 0) && (d.ld_dst % 4 == 0);
+        float v[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = p + 16 * i, gr = tr0 + r, gc = tc0 + q;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gr < d.rows) {
-            const float* sp = src + (size_t)gr * d.ld_src + gc;
-            if (vec_src && gc + 3 < d.cols) {
-                const float4 f = *(const float4*)sp;
-                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
-            } else {
+        for (int i = 0; i < 4; ++i) {                         // all 4 loads of this tile in flight together
+            const int gr = tr0 + p + 16 * i, gc = tc0 + q;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (gc + e < d.cols) v[e] = sp[e];
+            for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+            if (gr < d.rows) {
+                const float* sp = src + (size_t)gr * d.ld_src + gc;
+                if (vec_src && gc + 3 < d.cols) {
+                    const float4 f = *(const float4*)sp;
+                    v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gc + e < d.cols) v[i][e] = sp[e];
+                }
             }
         }
         if (!d.transpose) {
-            if (gr < d.rows) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gr = tr0 + p + 16 * i, gc = tc0 + q;
+                if (gr >= d.rows) continue;
                 bf16_t* dp = dst + (size_t)gr * d.ld_dst + gc;
-                if (vec_dst && gc + 3 < d.cols) *(uint2*)dp = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                if (vec_dst && gc + 3 < d.cols) *(uint2*)dp = make_uint2(pack2bf(v[i][0], v[i][1]), pack2bf(v[i][2], v[i][3]));
                 else
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (gc + e < d.cols) dp[e] = f2bf(v[e]);
+                    for (int e = 0; e < 4; ++e) if (gc + e < d.cols) dp[e] = f2bf(v[i][e]);
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tile[r][q + e] = v[e];
+            continue;
         }
-    }
-    if (!d.transpose) return;
-    __syncthreads();
+        __syncthreads();                                       // previous tile's readers are done with `tile`
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = p + 16 * i, gc = tc0 + c, gr = tr0 + q;          // dst row = src column
-        if (gc >= d.cols) continue;
-        bf16_t* dp = dst + (size_t)gc * d.ld_dst + gr;
-        if (vec_dst && gr + 3 < d.rows) *(uint2*)dp = make_uint2(pack2bf(tile[q][c], tile[q + 1][c]), pack2bf(tile[q + 2][c], tile[q + 3][c]));
-        else
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (gr + e < d.rows) dp[e] = f2bf(tile[q + e][c]);
+            for (int e = 0; e < 4; ++e) tile[p + 16 * i][q + e] = v[i][e];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = p + 16 * i, gc = tc0 + c, gr = tr0 + q;          // dst row = src column
+            if (gc >= d.cols) continue;
+            bf16_t* dp = dst + (size_t)gc * d.ld_dst + gr;
+            if (vec_dst && gr + 3 < d.rows) *(uint2*)dp = make_uint2(pack2bf(tile[q][c], tile[q + 1][c]), pack2bf(tile[q + 2][c], tile[q + 3][c]));
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (gr + e < d.rows) dp[e] = f2bf(tile[q + e][c]);
+        }
     }
 }
 
@@ -278,7 +296,8 @@ extern "C" int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int
 
 extern "C" int fm_shadow_refresh(const fm_shadow_desc* descs, int n_descs, int total_tiles, void* stream) {
     FM_CHECK_ARG(descs && n_descs > 0 && total_tiles > 0, "fm_shadow_refresh: bad argument");
-    hipLaunchKernelGGL(shadow_refresh_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs, n_descs);
+    hipLaunchKernelGGL(shadow_refresh_kernel, dim3((total_tiles + SHADOW_TILES_PER_BLOCK - 1) / SHADOW_TILES_PER_BLOCK), dim3(256), 0,
+                       (hipStream_t)stream, descs, n_descs, total_tiles);
     FM_CHECK_LAUNCH("fm_shadow_refresh");
     return 0;
 }

@@ -781,7 +781,7 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     if (a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
     if constexpr (!GROUPED) {
         int cfg = g_nt_config;
-        if (cfg == 9) cfg = g_nt_auto[(a.K >= 1536 || EPI == EPI_RES) ? 1 : 0];
+        if (cfg == 9) cfg = g_nt_auto[(a.K >= 1536 || EPI == EPI_RES || EPI == EPI_SWIGLU_BWD || EPI == EPI_GELU_BWD) ? 1 : 0];   // epilogues that READ prefer one workgroup per CU
         switch (cfg) {
             case 0: return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, false>(a, max_n, s);
             case 1: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false>(a, max_n, s);
