@@ -248,14 +248,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // S and dP are recomputed in both passes, so no atomics and no register-tile transposes.
 // ------------------------------------------------------------------------------------------------
 template <bool TR, int MASK>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
-    char* Ql = smem;
-    char* dOl = Ql + NqP * ROWB;
-    char* Kl = dOl + NqP * ROWB;
-    char* Vl = Kl + NkP * ROWB;
-    float4* qs_l = (float4*)(Vl + NkP * ROWB);          // per query: {row max (base 2), 1/row sum, delta, cs | mod}
+    const int NP = NqP > NkP ? NqP : NkP;
+    // Two LDS tiles, used twice: (Q, dO) during pass A, then (K, V) during pass B.  The operand a wave keeps in
+    // registers for a whole pass (its K/V block in A, its Q/dO block in B) comes straight from global memory.
+    // Half the LDS of holding all four tiles -> twice the resident workgroups: this kernel streams 400 MB per
+    // launch and needs the memory-level parallelism more than anything else.
+    char* T0 = smem;
+    char* T1 = T0 + NP * ROWB;
+    char* Ql = T0; char* dOl = T1; char* Kl = T0; char* Vl = T1;
+    float4* qs_l = (float4*)(T1 + NP * ROWB);           // per query: {row max (base 2), 1/row sum, delta, cs | mod}
     int16_t* modk_l = (int16_t*)(qs_l + NqP);
     uint8_t* kpad_l = (uint8_t*)(modk_l + NkP);
 
@@ -272,8 +276,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 
     stage_rows<4>(Qb, a.ldq, 0, a.Nq, NqP, Ql, wave, lane);
     stage_rows<4>(dOb, a.lddo, 0, a.Nq, NqP, dOl, wave, lane);
-    stage_rows<4>(Kb, a.ldk, 0, a.Nk, NkP, Kl, wave, lane);
-    stage_rows<4>(Vb, a.ldv, 0, a.Nk, NkP, Vl, wave, lane);
     // delta[q] = sum_d dO[q][d] * O[q][d]: two threads per query row, 4 x 16-byte loads each from O and dO,
     // all independent (one memory round trip for the whole prologue)
     for (int q0 = 0; q0 < NqP; q0 += 128) {
@@ -319,6 +321,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
 
     const int nQB = NqP / 32, nKB = NkP / 32;
     const float c2 = a.scale * LOG2E;
+    const bool wide_q = (a.lddq & 7) == 0 && (((uintptr_t)a.dQ) & 15) == 0;
+    const bool wide_k = (a.lddk & 7) == 0 && (((uintptr_t)a.dK) & 15) == 0;
+    const bool wide_v = (a.lddv & 7) == 0 && (((uintptr_t)a.dV) & 15) == 0;
 
     // ---- pass A: dK, dV -------------------------------------------------------------------------
     for (int kb = wave; kb < nKB; kb += 4) {
@@ -328,9 +333,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         const bool kp = kpad_l[kc] != 0;
         bf16x8_t kf[4], vf[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            kf[kk] = row_frag(Kl, kb * 32 + (lane & 31), kk, fhi);
-            vf[kk] = row_frag(Vl, kb * 32 + (lane & 31), kk, fhi);
+        for (int kk = 0; kk < 4; ++kk) {                 // rows past Nk repeat the last key (their p is forced to 0 below)
+            kf[kk] = *(const bf16x8_t*)(Kb + (size_t)kc * a.ldk + (kk * 2 + fhi) * 8);
+            vf[kk] = *(const bf16x8_t*)(Vb + (size_t)kc * a.ldv + (kk * 2 + fhi) * 8);
         }
         f32x16_t dKt[2], dVt[2];
 #pragma unroll
@@ -380,19 +385,32 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
                 }
             }
         }
-        if (k < a.Nk) {
-            bf16_t* dkrow = a.dK + ((size_t)b * a.Nk + k) * a.lddk + h * HD;
-            bf16_t* dvrow = a.dV + ((size_t)b * a.Nk + k) * a.lddv + h * HD;
+        {   // lanes l and l+32 own the same key row: 16-byte stores through v_permlane32_swap (store_bf16_groups)
+            bf16_t* dkrow = a.dK + ((size_t)b * a.Nk + kc) * a.lddk + h * HD;
+            bf16_t* dvrow = a.dV + ((size_t)b * a.Nk + kc) * a.lddv + h * HD;
+            const int lim = k < a.Nk ? HD : 0;           // rows past Nk write nothing
 #pragma unroll
             for (int df = 0; df < 2; ++df)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = df * 32 + 8 * g + 4 * fhi;
-                    *(uint2*)(dkrow + d) = make_uint2(pack2bf(dKt[df][4 * g], dKt[df][4 * g + 1]), pack2bf(dKt[df][4 * g + 2], dKt[df][4 * g + 3]));
-                    *(uint2*)(dvrow + d) = make_uint2(pack2bf(dVt[df][4 * g], dVt[df][4 * g + 1]), pack2bf(dVt[df][4 * g + 2], dVt[df][4 * g + 3]));
+                for (int g = 0; g < 4; g += 2) {
+                    uint2 pk[2], pv2[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        pk[u] = make_uint2(pack2bf(dKt[df][4 * (g + u)], dKt[df][4 * (g + u) + 1]), pack2bf(dKt[df][4 * (g + u) + 2], dKt[df][4 * (g + u) + 3]));
+                        pv2[u] = make_uint2(pack2bf(dVt[df][4 * (g + u)], dVt[df][4 * (g + u) + 1]), pack2bf(dVt[df][4 * (g + u) + 2], dVt[df][4 * (g + u) + 3]));
+                    }
+                    store_bf16_groups(dkrow, df * 32 + 8 * g, pk[0], pk[1], fhi, lim, wide_k);
+                    store_bf16_groups(dvrow, df * 32 + 8 * g, pv2[0], pv2[1], fhi, lim, wide_v);
                 }
         }
     }
+
+    // ---- (K, V) take the place of (Q, dO) in LDS -------------------------------------------------
+    __syncthreads();
+    stage_rows<4>(Kb, a.ldk, 0, a.Nk, NkP, Kl, wave, lane);
+    stage_rows<4>(Vb, a.ldv, 0, a.Nk, NkP, Vl, wave, lane);
+
+    __syncthreads();
 
     // ---- pass B: dQ -----------------------------------------------------------------------------
     for (int qb = wave; qb < nQB; qb += 4) {
@@ -404,8 +422,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
         bf16x8_t qf[4], dof[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            qf[kk] = row_frag(Ql, qb * 32 + (lane & 31), kk, fhi);
-            dof[kk] = row_frag(dOl, qb * 32 + (lane & 31), kk, fhi);
+            qf[kk] = *(const bf16x8_t*)(Qb + (size_t)qc * a.ldq + (kk * 2 + fhi) * 8);
+            dof[kk] = *(const bf16x8_t*)(dOb + (size_t)qc * a.lddo + (kk * 2 + fhi) * 8);
         }
         f32x16_t dQt[2];
 #pragma unroll
@@ -453,14 +471,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a) {
                 }
             }
         }
-        if (q < a.Nq) {
-            bf16_t* dqrow = a.dQ + ((size_t)b * a.Nq + q) * a.lddq + h * HD;
+        {
+            bf16_t* dqrow = a.dQ + ((size_t)b * a.Nq + qc) * a.lddq + h * HD;
+            const int lim = q < a.Nq ? HD : 0;
 #pragma unroll
             for (int df = 0; df < 2; ++df)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = df * 32 + 8 * g + 4 * fhi;
-                    *(uint2*)(dqrow + d) = make_uint2(pack2bf(dQt[df][4 * g], dQt[df][4 * g + 1]), pack2bf(dQt[df][4 * g + 2], dQt[df][4 * g + 3]));
+                for (int g = 0; g < 4; g += 2) {
+                    uint2 pq[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        pq[u] = make_uint2(pack2bf(dQt[df][4 * (g + u)], dQt[df][4 * (g + u) + 1]), pack2bf(dQt[df][4 * (g + u) + 2], dQt[df][4 * (g + u) + 3]));
+                    store_bf16_groups(dqrow, df * 32 + 8 * g, pq[0], pq[1], fhi, lim, wide_q);
                 }
         }
     }
@@ -524,7 +546,7 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     FM_CHECK_ARG(a.Nq <= 256 && a.Nk <= 256, "fm_attn_bwd: Nq=%d Nk=%d exceed the 256-token training budget of this kernel", a.Nq, a.Nk);
     FM_CHECK_ARG(p->lddo % 8 == 0 && p->lddq % 4 == 0 && p->lddk % 4 == 0 && p->lddv % 4 == 0, "fm_attn_bwd: leading dims");
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
-    const size_t lds = (size_t)(2 * NqP + 2 * NkP) * ROWB + NqP * 16 + NkP * (2 + 1) + 64;
+    const size_t lds = (size_t)2 * (NqP > NkP ? NqP : NkP) * ROWB + NqP * 16 + NkP * (2 + 1) + 64;
     dim3 grid(a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
 #define BWD(TR, MK)                                                                                                   \

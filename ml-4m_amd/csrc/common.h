@@ -128,3 +128,52 @@ __device__ __forceinline__ bf16x8_t lds_col_frag_tr_async(AddrFn addr_of, int rA
     return u.v;
 }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- 16-byte accesses for MFMA 32x32 accumulator rows (used by the GEMM epilogues and attention) ----------------
+// bf16 epilogue store of two adjacent 8-feature groups of one row.  After the 32x32 MFMA chain lane l holds
+// features [8g+4h, 8g+4h+4) of its row (h = l >> 5; lanes l and l+32 share the row), packed in `pg` for group g
+// and `pg1` for group g+1.  Wide form: two v_permlane32_swap per pair hand each half-wave 16 contiguous bytes
+// (lower half: group g, upper half: group g+1) -> ONE 16-byte store instead of two 8-byte ones (the store tail is
+// issue bound, not byte bound).  `col` = first feature of group g; features >= N are not written.
+// The read-side mirror of store_bf16_groups: one 16-byte load per half-wave (lower half: group g, upper half:
+// group g+1), two swaps, and every lane has its 4 features of both groups.  Features >= N read as zero.
+__device__ __forceinline__ void load_bf16_groups(const bf16_t* row, int col, int fhi, int N, bool wide, uint2& pg, uint2& pg1) {
+    if (wide) {
+        const int c = col + 8 * fhi;
+        const uint4 t = c < N ? *(const uint4*)(row + c) : make_uint4(0u, 0u, 0u, 0u);
+        const auto x = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
+        pg = make_uint2(x[0], y[0]); pg1 = make_uint2(x[1], y[1]);
+    } else {
+        const int c = col + 4 * fhi;
+        pg = c < N ? *(const uint2*)(row + c) : make_uint2(0u, 0u);
+        pg1 = c + 8 < N ? *(const uint2*)(row + c + 8) : make_uint2(0u, 0u);
+    }
+}
+
+__device__ __forceinline__ void unpack_bf4(uint2 p, float (&v)[4]) {
+    v[0] = bf2f((bf16_t)(p.x & 0xffff)); v[1] = bf2f((bf16_t)(p.x >> 16)); v[2] = bf2f((bf16_t)(p.y & 0xffff)); v[3] = bf2f((bf16_t)(p.y >> 16));
+}
+
+__device__ __forceinline__ void store_bf16_groups(bf16_t* row, int col, uint2 pg, uint2 pg1, int fhi, int N, bool wide) {
+    if (wide) {
+        const auto x = __builtin_amdgcn_permlane32_swap(pg.x, pg1.x, false, false);
+        const auto y = __builtin_amdgcn_permlane32_swap(pg.y, pg1.y, false, false);
+        const int c = col + 8 * fhi;
+        if (c < N) *(uint4*)(row + c) = make_uint4(x[0], y[0], x[1], y[1]);
+    } else {
+        const int c = col + 4 * fhi;
+        if (c < N) *(uint2*)(row + c) = pg;
+        if (c + 8 < N) *(uint2*)(row + c + 8) = pg1;
+    }
+}
+
+// wait until at most N of this wave's vector-memory operations (here: LDS-DMA pieces) are outstanding
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+
