@@ -422,7 +422,6 @@ struct TNArgs {
     int a_cols, b_cols;                       // readable columns of A / B (clamp for the tile loads)
     const fm_gemm_group* groups; const int* seg_start; const int* seg_count;   // grouped (per-modality rows)
     int n_tiles_a, n_tiles_b;
-    int dbg_store;
 };
 
 // element (row, col) of a row-major [64][cols] bf16 LDS tile with RB bytes per row; 16-byte chunks are
@@ -683,7 +682,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wa * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
-                if (n < N) { if (a.dbg_store) out[(size_t)n * a.ldo + k] = acc[i][j][r]; else unsafeAtomicAdd(out + (size_t)n * a.ldo + k, acc[i][j][r]); }
+                if (n < N) unsafeAtomicAdd(out + (size_t)n * a.ldo + k, acc[i][j][r]);
             }
     }
 }
@@ -831,7 +830,7 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     //                  fp32 atomic traffic of the epilogue (workgroups x 128 KB per launch, ~25 us at 512 workgroups)
     constexpr int TN_TA = 128, TN_TB = 256, TN_STAGES = 3;
     // (the grouped head GEMM keeps configuration 0: short, uneven reductions - 940 vs 1110 us at the 4M-B shapes)
-    const bool pp = g_tn_config == 1 && !grouped && (p->force_tr < 0 || (p->force_tr & 1));
+    const bool pp = g_tn_config == 1 && !grouped && p->force_tr != 0;
     const int kb = pp ? 64 : 32, slots = pp ? 256 : 512;
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
@@ -858,8 +857,7 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
         (void)once;                                                                                 \
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a);                                          \
     }
-    a.dbg_store = p->force_tr >= 2;
-    const int tr = p->force_tr >= 0 ? (p->force_tr & 1) : g_tn_use_tr;
+    const int tr = p->force_tr >= 0 ? p->force_tr : g_tn_use_tr;
     if (pp) { if (grouped) LAUNCH_TN(true, true, 64, true) else LAUNCH_TN(true, false, 64, true) }
     else if (tr) { if (grouped) LAUNCH_TN(true, true, 32, false) else LAUNCH_TN(true, false, 32, false) }
     else { if (grouped) LAUNCH_TN(false, true, 32, false) else LAUNCH_TN(false, false, 32, false) }
