@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
     // ---- pass 3: one wave per kept slot -------------------------------------------------------------
     const int D = d.dim, nch = D >> 2;
     const int Nt = d.n_reg + d.n_keep;
-    for (int s = wave; s < Nt; s += 4) {
+    // the row movement is split over gridDim.y workgroups per sample (each repeats the cheap index passes above):
+    // one workgroup per sample leaves 3/4 of the chip's memory parallelism unused
+    for (int s = wave + 4 * blockIdx.y; s < Nt; s += 4 * gridDim.y) {
         const size_t orow = (size_t)b * Nt + s;
         float* tok_o = (float*)d.tokens + orow * D;
         float* emb_o = (float*)d.emb + orow * D;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(fm_embed_bwd_desc d) {
     __shared__ int used[FM_MAX_MODS + 1];
     if (threadIdx.x <= FM_MAX_MODS) used[threadIdx.x] = 0;
     __syncthreads();
-    for (int s = wave; s < d.Nt; s += 4) {
+    for (int s = wave + 4 * blockIdx.y; s < d.Nt; s += 4 * gridDim.y) {       // gridDim.y workgroups share a sample's slots
         const size_t row = (size_t)b * d.Nt + s;
         const int m = ((const int32_t*)d.slot_mod)[row];
         if (m == -1) continue;                                   // masked slot: both inputs were zeroed
@@ -334,7 +336,8 @@ extern "C" int fm_select_embed(const fm_select_desc* d, void* stream) {
     static bool once = (hipFuncSetAttribute((const void*)select_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAXPOS * 9 + MAXKEEP * 4 + 16) == hipSuccess);
     (void)once;
     SelArgs A; A.d = *d;
-    hipLaunchKernelGGL(select_embed_kernel, dim3(d->batch), dim3(256), lds, (hipStream_t)stream, A);
+    const int slices = d->batch >= 2048 ? 1 : d->batch >= 1024 ? 2 : 4;
+    hipLaunchKernelGGL(select_embed_kernel, dim3(d->batch, slices), dim3(256), lds, (hipStream_t)stream, A);
     FM_CHECK_LAUNCH("fm_select_embed");
     return 0;
 }
@@ -346,7 +349,8 @@ extern "C" int fm_embed_bwd(const fm_embed_bwd_desc* d, void* stream) {
     FM_CHECK_ARG(lds <= 150 * 1024, "fm_embed_bwd: %zu bytes of LDS needed", lds);
     static bool once = (hipFuncSetAttribute((const void*)embed_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess);
     (void)once;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(d->batch), dim3(256), lds, (hipStream_t)stream, *d);
+    const int slices = d->batch >= 2048 ? 1 : d->batch >= 1024 ? 2 : 4;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(d->batch, slices), dim3(256), lds, (hipStream_t)stream, *d);
     FM_CHECK_LAUNCH("fm_embed_bwd");
     return 0;
 }
