@@ -28,19 +28,25 @@ class NativeScalerWithGradNormCount:
                 norm = optimizer.fused_grad_norm()
             optimizer.step()
             return norm
-        self._scaler.unscale_(optimizer)
+        return self._generic_step(optimizer, parameters, clip_grad, skip_grad, compute_grad_norm)
+
+    def _generic_step(self, optimizer, parameters, clip_grad, skip_grad, want_norm):
+        """Any other optimizer (or an enabled loss scaler): torch's own unscale / clip / step sequence."""
+        sc = self._scaler
+        sc.unscale_(optimizer)
+        norm, do_step = None, True
         if clip_grad is not None:
-            assert parameters is not None
+            if parameters is None:
+                raise ValueError("clip_grad needs the parameter list")
             norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
         elif skip_grad is not None:
             norm = get_grad_norm_(parameters)
-            if norm >= skip_grad:
-                self._scaler.update()
-                return norm
-        else:
-            norm = get_grad_norm_(parameters) if compute_grad_norm else None
-        self._scaler.step(optimizer)
-        self._scaler.update()
+            do_step = bool(norm < skip_grad)                 # an exploding step is dropped, the scaler still advances
+        elif want_norm:
+            norm = get_grad_norm_(parameters)
+        if do_step:
+            sc.step(optimizer)
+        sc.update()
         return norm
 
     def state_dict(self):
@@ -51,9 +57,7 @@ class NativeScalerWithGradNormCount:
 
 
 def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
-    if isinstance(parameters, torch.Tensor):
-        parameters = [parameters]
-    grads = [p.grad.detach() for p in parameters if p.grad is not None]
-    if not grads:
-        return torch.tensor(0.)
-    return torch.norm(torch.stack([torch.norm(g, float(norm_type)) for g in grads]), float(norm_type))
+    """Global p-norm of the gradients present on ``parameters`` (a tensor or an iterable of tensors)."""
+    params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
+    per_tensor = [p.grad.detach().norm(float(norm_type)) for p in params if p.grad is not None]
+    return torch.stack(per_tensor).norm(float(norm_type)) if per_tensor else torch.tensor(0.)
