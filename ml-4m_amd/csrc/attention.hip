@@ -223,16 +223,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q < a.Nq) {
-        bf16_t* orow = a.O + ((size_t)b * a.Nq + q) * a.ldo + h * HD;
+    {   // lanes l and l+32 own the same query row: 16-byte stores (store_bf16_groups)
+        bf16_t* orow = a.O + ((size_t)b * a.Nq + qc) * a.ldo + h * HD;
+        const bool wide_o = (a.ldo & 7) == 0 && (((uintptr_t)a.O) & 15) == 0;
+        const int lim = q < a.Nq ? HD : 0;
 #pragma unroll
         for (int df = 0; df < 2; ++df)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = df * 32 + 8 * g + 4 * fhi;
-                *(uint2*)(orow + d) = make_uint2(pack2bf(o[df][4 * g] * inv, o[df][4 * g + 1] * inv),
-                                                 pack2bf(o[df][4 * g + 2] * inv, o[df][4 * g + 3] * inv));
+            for (int g = 0; g < 4; g += 2) {
+                uint2 po[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    po[u] = make_uint2(pack2bf(o[df][4 * (g + u)] * inv, o[df][4 * (g + u) + 1] * inv),
+                                       pack2bf(o[df][4 * (g + u) + 2] * inv, o[df][4 * (g + u) + 3] * inv));
+                store_bf16_groups(orow, df * 32 + 8 * g, po[0], po[1], fhi, lim, wide_o);
             }
+    }
+    if (q < a.Nq) {
         if (fhi == 0 && a.stat_m) {
             const size_t si = ((size_t)b * a.H + h) * a.Nq + q;
             a.stat_m[si] = m_run;

@@ -346,7 +346,9 @@ def make_masks(kind, B, Nq, Nk, seed):
 
 @pytest.mark.parametrize("tr", [0, 1])
 @pytest.mark.parametrize("kind,Nq,Nk", [("none", 128, 128), ("keypad", 128, 128), ("decoder", 128, 128), ("dense", 96, 160),
-                                        ("keypad", 40, 200), ("none", 196, 196), ("decoder", 256, 256)])
+                                        ("keypad", 40, 200), ("none", 196, 196), ("decoder", 256, 256),
+                                        # ragged query / key counts
+                                        ("dense", 200, 100), ("keypad", 70, 50), ("decoder", 96, 96), ("none", 33, 128)])
 def test_attention(kind, Nq, Nk, tr):
     ops, L = _ops()
     B, H = 3, 2
