@@ -55,7 +55,13 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // ODD slot k by both rows, so the barrier closing that slot orders tile k+1 for row 0 (read in the next slot)
 // and for row 1 (one slot later).  Tile k+2 overwrites the buffer of tile k-1, whose last reads (row 1, odd
 // slot k-1) were retired by lgkmcnt(0) before that slot's closing barrier.
-template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false>
+//
+// PERSIST (with PP, dense only): the workgroup walks tiles blockIdx.x, + gridDim.x, ... of the same XCD-aware order.
+// The LDS-DMA of the next tile's first stages is issued BEFORE the store epilogue of the current one (every LDS read
+// of a tile is retired before the last barrier both wave rows pass), so that latency and the workgroup relaunch
+// disappear under the stores.  The first wait of such a tile is a full vmcnt(0): the wave's own epilogue stores are
+// younger than those loads and vmcnt only promises order among loads.
+template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false, bool PERSIST = false>
 __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     constexpr int NWAVES = WW * WX;
     constexpr int RB = KB * 2;                                 // bytes per LDS row
@@ -102,37 +108,40 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         Wp = (const bf16_t*)a.groups[g].W; N = a.groups[g].N; K = a.groups[g].K; ldw = a.groups[g].ldw;
     }
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;        // output features per W tile
-    const int n0 = tw * NPT, m0 = tx * TX;
+    int n0 = tw * NPT, m0 = tx * TX;
     if (n0 >= N) return;
 
     // ---- staging: each wave-instruction moves RPP rows x RB bytes; the per-lane source addresses only
-    // advance by KB elements per K-tile, so they are computed once -------------------------------
+    // advance by KB elements per K-tile, so they are computed once per tile -----------------------
     constexpr int PW = TW / (RPP * NWAVES), PX = TX / (RPP * NWAVES);
     const bf16_t* wsrc[PW];
     const bf16_t* xsrc[PX];
+    auto set_sources = [&]() {
 #pragma unroll
-    for (int p = 0; p < PW; ++p) {
-        const int t = (p * NWAVES + wave) * RPP + lane / CPR;
-        const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
-        if constexpr (EPI == EPI_SWIGLU) {
-            // rows [0,32) of every 64-row group come from W (g), rows [32,64) from W2 (u), same hidden units
-            int n = n0 + (t >> 6) * 32 + (t & 31);
-            n = n < N ? n : N - 1;
-            wsrc[p] = (((t >> 5) & 1) ? a.W2 : Wp) + (size_t)n * ldw + lc * 8;
-        } else {
-            int n = n0 + t;
-            n = n < N ? n : N - 1;
-            wsrc[p] = Wp + (size_t)n * ldw + lc * 8;
+        for (int p = 0; p < PW; ++p) {
+            const int t = (p * NWAVES + wave) * RPP + lane / CPR;
+            const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
+            if constexpr (EPI == EPI_SWIGLU) {
+                // rows [0,32) of every 64-row group come from W (g), rows [32,64) from W2 (u), same hidden units
+                int n = n0 + (t >> 6) * 32 + (t & 31);
+                n = n < N ? n : N - 1;
+                wsrc[p] = (((t >> 5) & 1) ? a.W2 : Wp) + (size_t)n * ldw + lc * 8;
+            } else {
+                int n = n0 + t;
+                n = n < N ? n : N - 1;
+                wsrc[p] = Wp + (size_t)n * ldw + lc * 8;
+            }
         }
-    }
 #pragma unroll
-    for (int p = 0; p < PX; ++p) {
-        const int t = (p * NWAVES + wave) * RPP + lane / CPR;
-        const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
-        int m = m0 + t;
-        m = m < a.M ? m : a.M - 1;
-        xsrc[p] = a.X + (size_t)m * a.ldx + lc * 8;
-    }
+        for (int p = 0; p < PX; ++p) {
+            const int t = (p * NWAVES + wave) * RPP + lane / CPR;
+            const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
+            int m = m0 + t;
+            m = m < a.M ? m : a.M - 1;
+            xsrc[p] = a.X + (size_t)m * a.ldx + lc * 8;
+        }
+    };
+    set_sources();
     auto stage_w = [&](int kt, int buf, int p) {
         __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[p] + kt * KB), LDS_PTR(smem + buf * STAGE + (p * NWAVES + wave) * 1024), 16, 0, 0);
     };
@@ -147,6 +156,22 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     };
 
     f32x16_t acc[FW][FX];
+    const int KT = K / KB;
+    auto prologue = [&]() {
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p)
+            if (p < KT) stage(p, p);
+    };
+    prologue();
+
+    // per-lane constants of the fragment reads
+    const int frow = lane & 31;                          // row inside a 32-row fragment
+    const int fswz = (frow >> SWSH) & (CPR - 1);         // swizzle key (fragment bases are multiples of 32)
+    const int fhi = lane >> 5;
+
+    int t_lin = blockIdx.x;                              // PERSIST: position in the tile order
+    bool first_tile = true;
+    for (;;) {                                           // one pass unless PERSIST
 #pragma unroll
     for (int i = 0; i < FW; ++i)
 #pragma unroll
@@ -154,22 +179,12 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int KT = K / KB;
-#pragma unroll
-    for (int p = 0; p < STAGES - 1; ++p)
-        if (p < KT) stage(p, p);
-
-    // per-lane constants of the fragment reads
-    const int frow = lane & 31;                          // row inside a 32-row fragment
-    const int fswz = (frow >> SWSH) & (CPR - 1);         // swizzle key (fragment bases are multiples of 32)
-    const int fhi = lane >> 5;
-
     if constexpr (PP) {
         static_assert(WW == 2 && NWAVES == 8 && STAGES == 3, "ping-pong schedule: 2 wave rows of 4 waves, 3-deep ring");
         constexpr int KS = KB / 16;                          // MFMA k-steps per K-tile
         constexpr int PIECES = PW + PX;
         const bool lead = ww == 0;
-        if (KT > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        if (KT > 1 && first_tile) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();   // later tiles: also this wave's epilogue stores
         block_barrier();                                     // tile 0 is in LDS for everyone
         if (!lead) block_barrier();                          // the trailing row runs one barrier behind
         int buf = 0;
@@ -253,10 +268,25 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         }
     }
 
+    // ---- PERSIST: next tile's first stages go out before this tile's stores ---------------------
+    const int en0 = n0, em0 = m0;                        // the epilogue below belongs to the tile just finished
+    bool has_next = false;
+    if constexpr (PERSIST) {
+        static_assert(PP && !GROUPED, "persistent tiles are implemented for the dense ping-pong schedule");
+        const int total = a.n_tiles_w * a.n_tiles_x;
+        has_next = t_lin + (int)gridDim.x < total;
+        if (has_next) {
+            t_lin += gridDim.x;
+            const int tile = xcd_remap(t_lin, total);
+            n0 = (tile % a.n_tiles_w) * NPT; m0 = (tile / a.n_tiles_w) * TX;
+            set_sources();
+            prologue();
+        }
+    }
     // ---- epilogue: lane holds, per fragment, 4 groups of 4 consecutive features of one row ---
 #pragma unroll
     for (int j = 0; j < FX; ++j) {
-        const int m = m0 + wx * (TX / WX) + j * 32 + frow;
+        const int m = em0 + wx * (TX / WX) + j * 32 + frow;
         if (m >= a.M) continue;
         if constexpr (EPI == EPI_SWIGLU) {
             bf16_t* gu = (bf16_t*)a.out2 + (size_t)m * a.ldo2;
@@ -264,8 +294,8 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             const bool wide = ((N | a.Hp | a.ldo | a.ldo2) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.out2) & 15) == 0;
 #pragma unroll
             for (int ip = 0; ip < FW / 2; ++ip) {
-                // fragment pair (2ip, 2ip+1) = (g, u) of hidden units n0 + (tile row / 64) * 32 + ...
-                const int hb = n0 + (ww * (TW / WW) / 64 + ip) * 32;
+                // fragment pair (2ip, 2ip+1) = (g, u) of hidden units en0 + (tile row / 64) * 32 + ...
+                const int hb = en0 + (ww * (TW / WW) / 64 + ip) * 32;
                 uint2 pg_[4], pu_[4], pa_[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -303,7 +333,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             const bool wide = ((N | a.ldo | (prow ? a.ldo2 : 0)) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)(prow ? a.out2 : nullptr)) & 15) == 0;
 #pragma unroll
             for (int i = 0; i < FW; ++i) {
-                const int nb = n0 + ww * (TW / WW) + i * 32;
+                const int nb = en0 + ww * (TW / WW) + i * 32;
                 uint2 po[4], pp[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -341,7 +371,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             const bool wide = ((N | a.Hp | a.ldo | a.ldr) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.res) & 15) == 0;
 #pragma unroll
             for (int i = 0; i < FW; ++i) {
-                const int nb = n0 + ww * (TW / WW) + i * 32;
+                const int nb = en0 + ww * (TW / WW) + i * 32;
                 uint2 sg_[4], su_[4], o1[4], o2[4];
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
@@ -388,7 +418,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             for (int i = 0; i < FW; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + ww * (TW / WW) + i * 32 + 8 * g + 4 * fhi;
+                    const int n = en0 + ww * (TW / WW) + i * 32 + 8 * g + 4 * fhi;
                     if (n >= N) continue;
                     float v[4], b[4] = {0.f, 0.f, 0.f, 0.f};
                     if (a.bias) {
@@ -410,6 +440,9 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                     }
                 }
         }
+    }
+    if (!has_next) break;
+    first_tile = false;
     }
 }
 
@@ -688,9 +721,18 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
 }
 
 int g_nt_config = 9, g_nt_prio = 1;
-int g_nt_auto[2] = {2, 7};          // automatic choice: short reductions / long ones (K >= 1536) and the fp32 residual epilogue
+int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
-template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false>
+static int n_compute_units() {
+    static int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+
+template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false, bool PERSIST = false>
 int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (max_n + NPT - 1) / NPT;
@@ -702,7 +744,11 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
         grid = (chunks + 7) / 8 * 8 * a.group_w * 4;
     }
     const size_t lds = (size_t)STAGES * (TW + TX) * KB * 2;
-    auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED, PP>;
+    if (PERSIST) {                                        // one resident workgroup per LDS slot, a multiple of the 8 XCDs
+        const int slots = n_compute_units() * (int)(160 * 1024 / lds) / 8 * 8;
+        if (grid > slots) grid = slots;
+    }
+    auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED, PP, PERSIST>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3(grid), dim3(WW * WX * 64), lds, s, a);
@@ -720,9 +766,11 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
 //   6  128 x 128, 4 waves, K-step 32, 3 stages, 48 KB                      (3 workgroups / CU; grouped path)
 //   7  as 1 with the ping-pong schedule (wave rows one barrier apart: LDS reads of one row under the MFMAs of the other)
 //   8  as 2 with the ping-pong schedule
+//  10  as 7, persistent workgroups (next tile's first stages issued before the store epilogue)
+//  11  as 8, persistent workgroups
 //   +256: s_setprio(1) around the MFMA clusters
-//   9  automatic (default): configuration 7 for long reductions (K >= 1536) and the residual epilogue, else 2
-//      (measured: profiles/r01_v5_nt_config_sweep.txt)
+//   9  automatic (default): 10 for long reductions (K >= 1536) and the reading epilogues, 2 for SwiGLU, else 11
+//      (measured: profiles/r01_v5_nt_config_sweep.txt, profiles/r01_v8_nt_config_sweep.txt)
 template <int EPI, bool GROUPED>
 int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     if constexpr (GROUPED) {
@@ -734,7 +782,8 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     if (a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
     if constexpr (!GROUPED) {
         int cfg = g_nt_config;
-        if (cfg == 9) cfg = g_nt_auto[(a.K >= 1536 || EPI == EPI_RES || EPI == EPI_SWIGLU_BWD || EPI == EPI_GELU_BWD) ? 1 : 0];   // epilogues that READ prefer one workgroup per CU
+        if (cfg == 9)    // epilogues that READ prefer one workgroup per CU; the write-heavy SwiGLU epilogue two lock-step ones
+            cfg = EPI == EPI_SWIGLU ? 2 : g_nt_auto[(a.K >= 1536 || EPI == EPI_RES || EPI == EPI_SWIGLU_BWD || EPI == EPI_GELU_BWD) ? 1 : 0];
         switch (cfg) {
             case 0: return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, false>(a, max_n, s);
             case 1: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false>(a, max_n, s);
@@ -744,6 +793,8 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
             case 6: return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, false>(a, max_n, s);
             case 7: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false, true>(a, max_n, s);
             case 8: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false, true>(a, max_n, s);
+            case 10: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false, true, true>(a, max_n, s);
+            case 11: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false, true, true>(a, max_n, s);
             default: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false>(a, max_n, s);
         }
     }
