@@ -175,7 +175,10 @@ typedef struct fm_mod_desc {
 
 typedef struct fm_select_desc {
     fm_mod_desc mods[FM_MAX_MODS];   /* in concatenation order */
-    int32_t n_mods, batch, dim, n_keep, n_reg, total_len, is_decoder, pad_;
+    int32_t n_mods, batch, dim, n_keep, n_reg, total_len, is_decoder;
+    int32_t raw;             /* 0: select n_keep positions (stable partition), masked slots zeroed — forward_mask_encoder/decoder;
+                                1: every position in place, nothing zeroed — cat_encoder_tensors / cat_decoder_tensors (fm.py:245-336);
+                                2: as 1 for ONE modality's own forward() / forward_embed() (decoder grid tokens embed their ids) */
     const void* reg_tokens;  /* f32 (n_reg, D)                      */
     const void* mask_token;  /* f32 (D), decoder                    */
     /* outputs, Nt = n_reg + n_keep rows per sample */

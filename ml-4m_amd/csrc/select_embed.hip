@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
             } else {
                 um = sel = mk[j] == 0;
             }
-            flag[p] = (uint8_t)sel;
+            flag[p] = (uint8_t)(sel | (um << 1));
         }
         int ts, tp;
         const int es = block_scan_excl(sel, wave_tot, &ts);
@@ -99,13 +99,14 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
     __syncthreads();
     // ---- pass 2: stable partition -> slot table ---------------------------------------------------
     for (int p = tid; p < P; p += 256) {
-        const int s = flag[p] ? rank_sel[p] : n_valid + (p - rank_sel[p]);
+        // raw views (cat_*_tensors / a modality's own forward): every position, in place
+        const int s = d.raw ? p : (flag[p] & 1) ? rank_sel[p] : n_valid + (p - rank_sel[p]);
         if (s < d.n_keep) slot_p[s] = p;
     }
     __syncthreads();
 
     // ---- decoder: cumsum of the compressed attention mask over the kept slots ----------------------
-    if (d.is_decoder) {
+    if (d.is_decoder && !d.raw) {
         // n_keep <= MAXKEEP; serial-by-chunks scan with one wave
         if (wave == 0) {
             int run = 0;
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
         const int m = mod_of(p);
         const fm_mod_desc& md = d.mods[m];
         const int j = p - mod_off[m];
-        const bool masked = flag[p] == 0;
+        const bool masked = (flag[p] & 1) == 0;
+        const bool own_unmasked = (flag[p] & 2) != 0;     // in the modality's own input / target mask
+        const bool raw = d.raw != 0;
         long long id = 0;
         int posrow = 0;
         if (md.kind == FM_KIND_TOK || md.kind == FM_KIND_SEQ) id = load_id(md.ids, md.ids_are_i64, (size_t)b * md.id_stride + j);
@@ -169,32 +172,41 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
         }
         if (lane == 0) {
             ((uint8_t*)d.out_mask)[orow] = masked ? 1 : 0;
-            ((int16_t*)d.out_mod)[orow] = masked ? (int16_t)-1 : (int16_t)md.mod_id;
-            ((int32_t*)d.slot_mod)[orow] = masked ? -1 : m;
+            ((int16_t*)d.out_mod)[orow] = (masked && !raw) ? (int16_t)-1 : (int16_t)md.mod_id;
+            ((int32_t*)d.slot_mod)[orow] = (masked && !raw) ? -1 : m;
             ((int32_t*)d.slot_src)[orow] = (md.kind == FM_KIND_TOK || md.kind == FM_KIND_SEQ) ? (int)id : j;
             ((int32_t*)d.slot_pos)[orow] = posrow;
             if (d.is_decoder) {
                 long long tgt = md.shifted ? load_id(md.ids, md.ids_are_i64, (size_t)b * md.id_stride + j + 1) : id;
-                ((long long*)d.target_ids)[orow] = masked ? 0 : tgt;
-                ((int32_t*)d.out_cs)[orow] = cs_scan[sk];
+                ((long long*)d.target_ids)[orow] = (masked && !raw) ? 0 : tgt;
+                ((int32_t*)d.out_cs)[orow] = raw ? 0 : cs_scan[sk];
                 ((int16_t*)d.out_mod_pre)[orow] = (int16_t)md.mod_id;     // before pads lose their id (fm.py:431-432)
                 ((int32_t*)d.out_mod_index)[orow] = masked ? -1 : md.head_index;
             }
         }
         // token row
         const float* trow = nullptr;
-        if (!masked) {
-            if (d.is_decoder && md.kind == FM_KIND_TOK) trow = (const float*)d.mask_token;
+        if (!masked || raw) {
+            // raw == 2 (a decoder embedding's own forward_embed): grid tokens embed their ids (decoder_embeddings.py:226-255);
+            // in the concatenated decoder views they are queried with the mask token (fm.py:322)
+            if (d.is_decoder && md.kind == FM_KIND_TOK && d.raw != 2) trow = (const float*)d.mask_token;
             else if (md.kind == FM_KIND_TOK || md.kind == FM_KIND_SEQ) trow = (const float*)md.table + (size_t)id * D;
             else if (md.kind == FM_KIND_SEQ_EMB) trow = (const float*)md.proj_bias;   // bias of emb_proj; GEMM adds the rest
         }
         const float* prow = (const float*)md.pos + (size_t)posrow * D;
         const float* mrow = (const float*)md.mod_emb;
+        // raw views keep what the embedding modules produce before forward_mask_* zeroes anything: grids always carry
+        // pos + mod; sequences carry mod alone where their own mask hides the position (encoder_embeddings.py:106-119)
+        const bool seq_kind = md.kind == FM_KIND_SEQ || md.kind == FM_KIND_SEQ_EMB;
+        const bool with_emb = raw ? true : !masked;
+        const bool with_pos = raw ? (!seq_kind || own_unmasked) : true;
         for (int c = lane; c < nch; c += 64) {
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f), e = make_float4(0.f, 0.f, 0.f, 0.f);
             if (trow) t = *(const float4*)(trow + c * 4);
-            if (!masked) {
-                const float4 pp = *(const float4*)(prow + c * 4), mm = *(const float4*)(mrow + c * 4);
+            if (with_emb) {
+                const float4 mm = *(const float4*)(mrow + c * 4);
+                float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (with_pos) pp = *(const float4*)(prow + c * 4);
                 e = make_float4(pp.x + mm.x, pp.y + mm.y, pp.z + mm.z, pp.w + mm.w);
             }
             *(float4*)(tok_o + c * 4) = t;
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
         // dense side inputs gathered for the projection GEMM (zero rows elsewhere)
         if (d.patch_rows) {
             bf16_t* pr = (bf16_t*)d.patch_rows + orow * d.patch_ld;
-            if (!masked && md.kind == FM_KIND_PATCH) {
+            if ((!masked || raw) && md.kind == FM_KIND_PATCH) {
                 // feature f = (py*ps + px)*C + c  <-  img[b][c][gy*ps + py][gx*ps + px]   (encoder_embeddings.py:301)
                 const int ps = md.patch, C = md.channels, gw = md.grid_w;
                 const int gy = j / gw, gx = j % gw;
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
         }
         if (d.seqemb_rows) {
             bf16_t* sr = (bf16_t*)d.seqemb_rows + orow * d.seqemb_ld;
-            if (!masked && md.kind == FM_KIND_SEQ_EMB) {
+            if ((!masked || raw) && md.kind == FM_KIND_SEQ_EMB) {
                 const float* src = (const float*)md.ids + (size_t)b * md.id_stride + (size_t)j * md.orig_dim;
                 for (int f = lane; f < d.seqemb_ld; f += 64) sr[f] = f2bf(f < md.orig_dim ? src[f] : 0.f);
             } else {
@@ -315,7 +327,8 @@ extern "C" int fm_select_embed(const fm_select_desc* d, void* stream) {
     FM_CHECK_ARG(d && d->tokens && d->emb && d->out_mask && d->out_mod && d->slot_mod && d->slot_src && d->slot_pos, "fm_select_embed: null output");
     FM_CHECK_ARG(d->n_mods > 0 && d->n_mods <= FM_MAX_MODS, "fm_select_embed: n_mods=%d out of range (max %d)", d->n_mods, FM_MAX_MODS);
     FM_CHECK_ARG(d->dim > 0 && d->dim % 4 == 0, "fm_select_embed: dim must be a multiple of 4");
-    FM_CHECK_ARG(d->batch > 0 && d->n_keep > 0 && d->n_keep <= MAXKEEP, "fm_select_embed: n_keep=%d out of range (max %d)", d->n_keep, MAXKEEP);
+    FM_CHECK_ARG(d->batch > 0 && d->n_keep > 0 && d->n_keep <= (d->raw ? MAXPOS : MAXKEEP), "fm_select_embed: n_keep=%d out of range (max %d)", d->n_keep,
+                 d->raw ? MAXPOS : MAXKEEP);
     int total = 0;
     for (int m = 0; m < d->n_mods; ++m) {
         const fm_mod_desc& md = d->mods[m];
@@ -323,17 +336,20 @@ extern "C" int fm_select_embed(const fm_select_desc* d, void* stream) {
         FM_CHECK_ARG(md.kind != FM_KIND_PATCH || (d->patch_rows && md.ids), "fm_select_embed: pixel modality needs patch_rows and pixels");
         FM_CHECK_ARG(md.kind != FM_KIND_SEQ_EMB || (d->seqemb_rows && md.ids), "fm_select_embed: seq_emb modality needs seqemb_rows");
         FM_CHECK_ARG(!((md.kind == FM_KIND_TOK || md.kind == FM_KIND_SEQ) && !(d->is_decoder && md.kind == FM_KIND_TOK)) || md.table, "fm_select_embed: modality %d needs a table", m);
-        FM_CHECK_ARG(!d->is_decoder || md.dam, "fm_select_embed: decoder modality %d needs decoder_attention_mask", m);
+        FM_CHECK_ARG(!d->is_decoder || md.dam || d->raw, "fm_select_embed: decoder modality %d needs decoder_attention_mask", m);
+        FM_CHECK_ARG(!(d->raw == 2 && md.kind == FM_KIND_TOK) || md.table, "fm_select_embed: modality %d needs a table", m);
         total += md.L;
     }
     FM_CHECK_ARG(total == d->total_len, "fm_select_embed: total_len=%d but the modalities sum to %d", d->total_len, total);
     FM_CHECK_ARG(total <= MAXPOS, "fm_select_embed: %d concatenated positions exceed %d", total, MAXPOS);
     FM_CHECK_ARG(d->n_keep <= total, "fm_select_embed: n_keep=%d exceeds the %d available positions", d->n_keep, total);
+    FM_CHECK_ARG(d->raw >= 0 && d->raw <= 2 && (!d->raw || (d->n_keep == total && d->n_reg == 0)),
+                 "fm_select_embed: raw views cover every position (n_keep == total_len) and carry no register tokens");
     FM_CHECK_ARG(!d->is_decoder || (d->target_ids && d->out_cs && d->out_mod_pre && d->out_mod_index && d->mask_token), "fm_select_embed: decoder outputs missing");
     FM_CHECK_ARG(d->n_reg == 0 || d->reg_tokens, "fm_select_embed: register tokens missing");
     FM_CHECK_ARG(d->patch_ld % 4 == 0 && d->seqemb_ld % 4 == 0, "fm_select_embed: side buffers need ld %% 4 == 0");
     const size_t lds = (size_t)total * 9 + (size_t)d->n_keep * 4 + 16;
-    static bool once = (hipFuncSetAttribute((const void*)select_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAXPOS * 9 + MAXKEEP * 4 + 16) == hipSuccess);
+    static bool once = (hipFuncSetAttribute((const void*)select_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MAXPOS * 9 + MAXPOS * 4 + 16) == hipSuccess);
     (void)once;
     SelArgs A; A.d = *d;
     const int slices = d->batch >= 2048 ? 1 : d->batch >= 1024 ? 2 : 4;

@@ -80,7 +80,7 @@ class ShadowDesc(C.Structure):
 class SelectDesc(C.Structure):
     _fields_ = [("mods", ModDesc * FM_MAX_MODS),
                 ("n_mods", i32), ("batch", i32), ("dim", i32), ("n_keep", i32), ("n_reg", i32), ("total_len", i32),
-                ("is_decoder", i32), ("pad_", i32),
+                ("is_decoder", i32), ("raw", i32),
                 ("reg_tokens", vp), ("mask_token", vp),
                 ("tokens", vp), ("emb", vp), ("x0", vp), ("out_mask", vp), ("out_mod", vp), ("slot_mod", vp),
                 ("slot_src", vp), ("slot_pos", vp), ("target_ids", vp), ("out_cs", vp), ("out_mod_pre", vp),

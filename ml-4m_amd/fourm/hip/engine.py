@@ -68,6 +68,59 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
+def fill_mod_desc(md, d, emb, is_dec: bool, mod_id: int, head_index: int = 0, raw: int = 0, name: str = "modality"):
+    """One modality of ``mod_dict`` -> ``fm_mod_desc``.  Returns the tensors that must stay alive until the launch.
+    raw == 2 (the embedding's own forward): no teacher-forcing shift, no decoder_attention_mask needed."""
+    kind = emb.kind
+    t = d["tensor"]
+    B = t.shape[0]
+    mask = d["target_mask" if is_dec else "input_mask"]
+    mask = mask.reshape(B, -1)
+    if mask.dtype != torch.bool:
+        mask = mask.bool()
+    mask = mask.contiguous()
+    keep = [mask]
+    md.mask, md.mask_stride = mask.data_ptr(), mask.shape[1]
+    md.kind, md.mod_id, md.head_index = kind, mod_id, head_index
+    md.pos = emb.pos_emb.data_ptr()
+    md.mod_emb = emb.mod_emb.data_ptr()
+    md.shifted = 1 if (is_dec and kind == L.KIND_SEQ and raw != 2) else 0
+    md.max_len = getattr(emb, "max_length", 0) or 0
+    if kind in (L.KIND_TOK, L.KIND_SEQ):
+        ids = t.reshape(B, -1)
+        if ids.dtype not in (torch.int32, torch.int64):
+            ids = ids.long()
+        ids = ids.contiguous()
+        keep.append(ids)
+        md.ids, md.ids_are_i64, md.id_stride = ids.data_ptr(), 1 if ids.dtype == torch.int64 else 0, ids.shape[1]
+        md.table = emb.token_emb.weight.data_ptr()
+        md.L = ids.shape[1] - (1 if md.shifted else 0)
+        if ids.shape[1] != mask.shape[1]:
+            raise ValueError(f"{name}: tensor has {ids.shape[1]} positions but the mask has {mask.shape[1]}")
+    elif kind == L.KIND_PATCH:
+        px = t.float().contiguous()
+        keep.append(px)
+        _, C, Hh, Ww = px.shape
+        ps = emb.patch_size[0]
+        md.ids, md.id_stride = px.data_ptr(), C * Hh * Ww
+        md.patch, md.channels, md.grid_w = ps, C, Ww // ps
+        md.L = (Hh // ps) * (Ww // ps)
+    else:  # KIND_SEQ_EMB
+        e = t.float().contiguous()
+        keep.append(e)
+        md.ids, md.id_stride, md.orig_dim = e.data_ptr(), e.shape[1] * e.shape[2], e.shape[2]
+        md.proj_bias = emb.emb_proj.bias.data_ptr()
+        md.L = e.shape[1]
+    if is_dec and (raw != 2 or "decoder_attention_mask" in d):
+        dam = d["decoder_attention_mask"].reshape(B, -1)
+        if dam.dtype != torch.int32:
+            dam = dam.int()
+        dam = dam.contiguous()
+        keep.append(dam)
+        md.dam = dam.data_ptr()
+    return keep
+
+
 class FourMEngine:
     def __init__(self, model):
         from fourm.models.fm_utils import GatedMlp, NormAttention, act_name
@@ -250,61 +303,14 @@ class FourMEngine:
     # ------------------------------------------------------------------------------------------
     # selection + embedding
     # ------------------------------------------------------------------------------------------
-    def _mod_desc(self, md: L.ModDesc, name, d, emb, is_dec, head_index=0):
-        info = self.model.modality_info[name]
-        kind = emb.kind
-        t = d["tensor"]
-        B = t.shape[0]
-        mask = d["target_mask" if is_dec else "input_mask"]
-        mask = mask.reshape(B, -1)
-        if mask.dtype != torch.bool:
-            mask = mask.bool()
-        mask = mask.contiguous()
-        keep = [mask]
-        md.mask, md.mask_stride = mask.data_ptr(), mask.shape[1]
-        md.kind, md.mod_id, md.head_index = kind, int(info["id"]), head_index
-        md.pos = emb.pos_emb.data_ptr()
-        md.mod_emb = emb.mod_emb.data_ptr()
-        md.shifted = 1 if (is_dec and kind == L.KIND_SEQ) else 0
-        md.max_len = getattr(emb, "max_length", 0) or 0
-        if kind in (L.KIND_TOK, L.KIND_SEQ):
-            ids = t.reshape(B, -1)
-            if ids.dtype not in (torch.int32, torch.int64):
-                ids = ids.long()
-            ids = ids.contiguous()
-            keep.append(ids)
-            md.ids, md.ids_are_i64, md.id_stride = ids.data_ptr(), 1 if ids.dtype == torch.int64 else 0, ids.shape[1]
-            md.table = emb.token_emb.weight.data_ptr()
-            md.L = ids.shape[1] - (1 if md.shifted else 0)
-            if ids.shape[1] != mask.shape[1]:
-                raise ValueError(f"{name}: tensor has {ids.shape[1]} positions but the mask has {mask.shape[1]}")
-        elif kind == L.KIND_PATCH:
-            px = t.float().contiguous()
-            keep.append(px)
-            _, C, Hh, Ww = px.shape
-            ps = emb.patch_size[0]
-            md.ids, md.id_stride = px.data_ptr(), C * Hh * Ww
-            md.patch, md.channels, md.grid_w = ps, C, Ww // ps
-            md.L = (Hh // ps) * (Ww // ps)
-        else:  # KIND_SEQ_EMB
-            e = t.float().contiguous()
-            keep.append(e)
-            md.ids, md.id_stride, md.orig_dim = e.data_ptr(), e.shape[1] * e.shape[2], e.shape[2]
-            md.proj_bias = emb.emb_proj.bias.data_ptr()
-            md.L = e.shape[1]
-        if is_dec:
-            dam = d["decoder_attention_mask"].reshape(B, -1)
-            if dam.dtype != torch.int32:
-                dam = dam.int()
-            dam = dam.contiguous()
-            keep.append(dam)
-            md.dam = dam.data_ptr()
-        return keep
+    def _mod_desc(self, md: L.ModDesc, name, d, emb, is_dec, head_index=0, raw=0):
+        return fill_mod_desc(md, d, emb, is_dec, int(self.model.modality_info[name]["id"]), head_index, raw, name)
 
-    def select(self, mod_dict, n_keep: int, is_dec: bool, order: List[str], prefix: str, want_x0=True, heads=None):
+    def select(self, mod_dict, n_keep: int, is_dec: bool, order: List[str], prefix: str, want_x0=True, heads=None, raw=0):
         """Run the fused concat/partition/embed kernel for one side.  Returns a dict of device tensors.
         With ``want_x0`` the dense projections (pixels, T5 embeddings) are added to ``x0 = tokens + emb``
-        (what the trunk consumes); without it they are added to ``tokens`` (the upstream sub-API view)."""
+        (what the trunk consumes); without it they are added to ``tokens`` (the upstream sub-API view).
+        ``raw`` = 1: every concatenated position in place, nothing zeroed (cat_*_tensors; ``n_keep`` is ignored)."""
         m = self.model
         embs = m.decoder_embeddings if is_dec else m.encoder_embeddings
         names = [n for n in order if n in embs]
@@ -314,9 +320,7 @@ class FourMEngine:
             raise ValueError(f"{len(names)} modalities exceed FM_MAX_MODS={L.FM_MAX_MODS}")
         B = mod_dict[names[0]]["tensor"].shape[0]
         D, ws = self.D, self.ws
-        n_reg = 0 if is_dec else m.num_register_tokens
-        Nt = n_reg + n_keep
-        R, Rp = B * Nt, ru(B * Nt, 128)
+        n_reg = 0 if (is_dec or raw) else m.num_register_tokens
         desc = L.SelectDesc()
         keep, total = [], 0
         # heads = decoder modalities present in this batch, in mod_dict order (fm.py:669-671, :590)
@@ -324,12 +328,17 @@ class FourMEngine:
         out_heads = head_names
         patch_ld = seq_ld = 0
         for i, n in enumerate(names):
-            keep += self._mod_desc(desc.mods[i], n, mod_dict[n], embs[n], is_dec, head_names.index(n) if is_dec else 0)
+            keep += self._mod_desc(desc.mods[i], n, mod_dict[n], embs[n], is_dec, head_names.index(n) if is_dec else 0, raw)
             total += desc.mods[i].L
             if desc.mods[i].kind == L.KIND_PATCH:
                 patch_ld = max(patch_ld, ru(embs[n].proj.weight.shape[1], 64))
             if desc.mods[i].kind == L.KIND_SEQ_EMB:
                 seq_ld = max(seq_ld, ru(embs[n].orig_emb_dim, 64))
+        if raw:
+            n_keep = total
+        Nt = n_reg + n_keep
+        R, Rp = B * Nt, ru(B * Nt, 128)
+        desc.raw = raw
         desc.n_mods, desc.batch, desc.dim, desc.n_keep, desc.n_reg = len(names), B, D, n_keep, n_reg
         desc.total_len, desc.is_decoder = total, 1 if is_dec else 0
         if n_keep > total:

@@ -46,6 +46,53 @@ def linear(x, weight, bias, out_dtype=None):
     return y.reshape(*shp[:-1], N).to(out_dtype or (x.dtype if x.dtype != torch.float32 else torch.float32))
 
 
+def embed_modality(emb, d, is_dec: bool):
+    """A modality embedding's own ``forward(d)`` / ``forward_embed(d)``: token rows ``x`` and ``emb`` = position +
+    modality embedding for EVERY position, nothing zeroed (encoder_embeddings.py:87-121,184-211,280-309,387-421,
+    decoder_embeddings.py:98-139,226-255).  One launch of the selection kernel in its raw view (+ the projection
+    GEMM for pixels / dense embeddings).  Returns (x, emb) as fp32 (B, L, D)."""
+    _no_grad_only(type(emb).__name__)
+    from fourm.hip.engine import fill_mod_desc, ru
+    t = d["tensor"]
+    B, dev, D = t.shape[0], t.device, emb.dim_tokens
+    desc = L.SelectDesc()
+    keep = fill_mod_desc(desc.mods[0], d, emb, is_dec, 0, 0, raw=2, name=type(emb).__name__)
+    Lm = desc.mods[0].L
+    R, Rp = B * Lm, ru(B * Lm, 128)
+    f32, i32 = torch.float32, torch.int32
+    tokens, e = torch.zeros(Rp, D, dtype=f32, device=dev), torch.zeros(Rp, D, dtype=f32, device=dev)
+    side = dict(mask=torch.empty(B, Lm, dtype=torch.bool, device=dev), mod=torch.empty(B, Lm, dtype=torch.int16, device=dev),
+                smod=torch.empty(B, Lm, dtype=i32, device=dev), ssrc=torch.empty(B, Lm, dtype=i32, device=dev),
+                spos=torch.empty(B, Lm, dtype=i32, device=dev))
+    desc.n_mods, desc.batch, desc.dim, desc.n_keep, desc.n_reg, desc.total_len = 1, B, D, Lm, 0, Lm
+    desc.is_decoder, desc.raw = 1 if is_dec else 0, 2
+    desc.tokens, desc.emb = tokens.data_ptr(), e.data_ptr()
+    desc.out_mask, desc.out_mod = side["mask"].data_ptr(), side["mod"].data_ptr()
+    desc.slot_mod, desc.slot_src, desc.slot_pos = side["smod"].data_ptr(), side["ssrc"].data_ptr(), side["spos"].data_ptr()
+    if is_dec:
+        side.update(tgt=torch.empty(B, Lm, dtype=torch.int64, device=dev), cs=torch.empty(B, Lm, dtype=i32, device=dev),
+                    pre=torch.empty(B, Lm, dtype=torch.int16, device=dev), hidx=torch.empty(B, Lm, dtype=i32, device=dev),
+                    mtok=torch.zeros(D, dtype=f32, device=dev))
+        desc.target_ids, desc.out_cs = side["tgt"].data_ptr(), side["cs"].data_ptr()
+        desc.out_mod_pre, desc.out_mod_index, desc.mask_token = side["pre"].data_ptr(), side["hidx"].data_ptr(), side["mtok"].data_ptr()
+    rows = weight = None
+    if emb.kind == L.KIND_PATCH:
+        weight = emb.proj.weight
+        rows = torch.zeros(Rp, ru(weight.shape[1], 64), dtype=torch.bfloat16, device=dev)
+        desc.patch_rows, desc.patch_ld = rows.data_ptr(), rows.shape[1]
+    elif emb.kind == L.KIND_SEQ_EMB:
+        weight = emb.emb_proj.weight
+        rows = torch.zeros(Rp, ru(emb.orig_emb_dim, 64), dtype=torch.bfloat16, device=dev)
+        desc.seqemb_rows, desc.seqemb_ld = rows.data_ptr(), rows.shape[1]
+    L.check(L.select_embed(ops.C.byref(desc), ops._stream()))
+    if rows is not None:      # x = proj(patches) / emb_proj(embeddings) (+ bias, already in the token rows)
+        wb = torch.zeros(weight.shape[0], rows.shape[1], dtype=torch.bfloat16, device=dev)
+        ops.cast_pad(weight.detach().float(), wb)
+        ops.gemm_nt(rows, wb, tokens, epilogue=L.EPI_RESIDUAL, res=tokens, M=R, N=D)
+    del keep
+    return tokens[:R].view(B, Lm, D), e[:R].view(B, Lm, D)
+
+
 def _engine_of(block):
     eng = getattr(block, "_fourm_engine", None)
     if eng is None:

@@ -21,7 +21,11 @@ class _Head:
             self.to_logits.weight = self.token_emb.weight
 
     def forward_embed(self, d):
-        raise NotImplementedError(f"{type(self).__name__}.forward_embed is fused into FourM.forward_mask_decoder in the HIP implementation")
+        """Upstream contract: adds ``x``, ``emb`` and ``ids`` (= the token tensor) to ``d``.  Inference only."""
+        from fourm.hip import functional
+        d["x"], d["emb"] = functional.embed_modality(self, d, is_dec=True)
+        d["ids"] = d["tensor"]
+        return d
 
     def forward_logits(self, x: torch.Tensor) -> torch.Tensor:
         """Decoder states (..., D) -> logits (..., vocab); bf16 GEMM, returned in x's dtype."""

@@ -36,9 +36,11 @@ class _Embedder(nn.Module):
         return set()
 
     def forward(self, d):
-        raise NotImplementedError(
-            f"{type(self).__name__}: per-modality embedding of all positions is fused into "
-            "FourM.forward_mask_encoder / forward_mask_decoder in the HIP implementation")
+        """Upstream contract: adds ``x`` (token / projected rows) and ``emb`` (position + modality embedding) for
+        every position to ``d`` (fp32, (B, L, D)).  Inference only; training embeds inside FourM.forward."""
+        from fourm.hip import functional
+        d["x"], d["emb"] = functional.embed_modality(self, d, is_dec=False)
+        return d
 
 
 class _SeqPos(_Embedder):

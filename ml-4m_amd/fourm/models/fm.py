@@ -193,6 +193,37 @@ class FourM(nn.Module):
     # ------------------------------------------------------------------------------------------
     # selection (upstream sub-API)
     # ------------------------------------------------------------------------------------------
+    def cat_encoder_tensors(self, mod_dict):
+        """Every position of every encoder modality, concatenated, nothing zeroed   [fm.py:245-277]:
+        (tokens (B,O,D), emb (B,O,D), mask (B,O) bool, mod_mask (B,O) int16).  Embeds from ``d['tensor']`` (any
+        precomputed ``d['x']`` / ``d['emb']`` are not read)."""
+        from fourm.hip import functional as Fh
+        Fh._no_grad_only("FourM.cat_encoder_tensors")
+        eng = self.engine
+        eng.prepare()
+        names = [n for n in mod_dict if n in self.encoder_embeddings]
+        s = eng.select(mod_dict, 0, False, names, "api.cat_enc.", want_x0=False, raw=1)
+        B, Nt, D, R = s["B"], s["Nt"], self.dim, s["R"]
+        return (s["tokens"][:R].view(B, Nt, D).clone(), s["emb"][:R].view(B, Nt, D).clone(), s["mask"].clone(), s["mod_mask"].clone())
+
+    def cat_decoder_tensors(self, mod_dict):
+        """The decoder-side concatenation   [fm.py:279-336]: modalities in the shuffled order, sequences shifted for
+        teacher forcing, grid modalities queried with the mask token:
+        (tokens (B,P,D), emb (B,P,D), mask (B,P) bool, target_ids (B,P) int64, attention mask (B,P) int32, mod_mask (B,P) int16)."""
+        from fourm.hip import functional as Fh, _lib as _L
+        Fh._no_grad_only("FourM.cat_decoder_tensors")
+        eng = self.engine
+        eng.prepare()
+        order = eng.dec_order(mod_dict)
+        s = eng.select(mod_dict, 0, True, order, "api.cat_dec.", want_x0=False, raw=1)
+        B, Nt, D, R = s["B"], s["Nt"], self.dim, s["R"]
+        dams = []
+        for n in s["names"]:
+            dam = mod_dict[n]["decoder_attention_mask"].reshape(B, -1)
+            dams.append(dam[:, :-1] if self.decoder_embeddings[n].kind == _L.KIND_SEQ else dam)      # sequences: teacher forcing
+        return (s["tokens"][:R].view(B, Nt, D).clone(), s["emb"][:R].view(B, Nt, D).clone(), s["mask"].clone(),
+                s["target_ids"].clone(), torch.cat(dams, 1), s["mod_mask"].clone())
+
     def forward_mask_encoder(self, mod_dict, num_encoder_tokens: int):
         """(tokens (B,N,D), emb (B,N,D), mask (B,1,N) bool, mod_mask (B,N) int16)   [fm.py:338-390]"""
         eng = self.engine

@@ -138,6 +138,59 @@ def test_eval_forward_and_accumulation():
     assert abs(float(l4) - float(l1)) < 1e-6 and not l4.requires_grad
 
 
+@pytest.mark.parametrize("name", ["micro_swiglu", "micro_gelu", "ti_mod7"])
+def test_embedding_and_cat_sub_api(name):
+    """The pieces generation code calls directly: every embedding's own forward() / forward_embed() and
+    cat_encoder_tensors / cat_decoder_tensors (fm.py:245-336) against the oracle's per-modality embedders."""
+    g, case, model = setup(name)
+    cfg, P = case["cfg"], tie(dict(case["sd"]), case["cfg"], case["share_embedding"])
+    md = to_device(case["mod_dict"])
+    num = O._Num(False)
+    enc_x, enc_e, dec = {}, {}, {}
+    with torch.no_grad():
+        for spec in cfg.mods:
+            d_cpu = case["mod_dict"][spec.name]
+            if spec.in_enc:
+                x, e = O.embed_encoder_modality(P, spec, d_cpu, num)
+                enc_x[spec.name], enc_e[spec.name] = x.float(), e
+                out = model.encoder_embeddings[spec.name](dict(md[spec.name]))
+                tol = 2e-2 if spec.kind in ("patch", "seq_emb") else 0.0          # bf16 projection vs gathers
+                assert rel(out["x"], x) <= tol, (spec.name, "x", rel(out["x"], x))
+                assert torch.equal(out["emb"].cpu(), e.float()), (spec.name, "emb")
+            if spec.in_dec:
+                x, e, ids = O.embed_decoder_modality(P, spec, d_cpu)
+                dec[spec.name] = (x, e, ids)
+                out = model.decoder_embeddings[spec.name].forward_embed(dict(md[spec.name]))
+                assert torch.equal(out["x"].cpu(), x) and torch.equal(out["emb"].cpu(), e.float()), spec.name
+                assert torch.equal(out["ids"].cpu().reshape(ids.shape).long(), ids.long())
+        # encoder concatenation, in mod_dict order
+        names = [n for n in case["mod_dict"] if n in enc_x]
+        tok, emb, mask, mod = model.cat_encoder_tensors(md)
+        want_mask = torch.cat([case["mod_dict"][n]["input_mask"].bool().reshape(tok.shape[0], -1) for n in names], 1)
+        assert torch.equal(mask.cpu(), want_mask)
+        assert torch.equal(emb.cpu(), torch.cat([enc_e[n].float() for n in names], 1))
+        assert rel(tok, torch.cat([enc_x[n] for n in names], 1)) < 2e-2
+        want_mod = torch.cat([torch.full(enc_e[n].shape[:2], cfg.mod(n).id, dtype=torch.int16) for n in names], 1)
+        assert torch.equal(mod.cpu(), want_mod)
+        # decoder concatenation: shuffled order, teacher forcing on sequences, mask token on grids
+        random.seed(case["order_seed"])
+        tok, emb, mask, tgt, dam, mod = model.cat_decoder_tensors(md)
+        order = [str(n) for n in g["meta/order"]]
+        xs, es, ms, ts, am = [], [], [], [], []
+        for n in order:
+            x, e, ids = dec[n]
+            d_cpu = case["mod_dict"][n]
+            tm = d_cpu["target_mask"].bool().reshape(x.shape[0], -1)
+            a = d_cpu["decoder_attention_mask"].reshape(x.shape[0], -1)
+            if cfg.mod(n).is_seq:
+                xs.append(x[:, :-1]); es.append(e[:, :-1]); ts.append(ids[:, 1:]); ms.append(tm[:, 1:] | tm[:, :-1]); am.append(a[:, :-1])
+            else:
+                xs.append(P["mask_token"].expand(x.shape[0], x.shape[1], -1)); es.append(e); ts.append(ids); ms.append(tm); am.append(a)
+        assert torch.equal(tok.cpu(), torch.cat(xs, 1)) and torch.equal(emb.cpu(), torch.cat(es, 1).float())
+        assert torch.equal(mask.cpu(), torch.cat(ms, 1)) and torch.equal(tgt.cpu(), torch.cat(ts, 1).long())
+        assert torch.equal(dam.cpu().int(), torch.cat(am, 1).int())
+
+
 def test_unsupported_config_is_loud():
     """head_dim != 64 has no attention kernel: the model must refuse, not fall back."""
     import dataclasses
