@@ -169,6 +169,31 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     const int fswz = (frow >> SWSH) & (CPR - 1);         // swizzle key (fragment bases are multiples of 32)
     const int fhi = lane >> 5;
 
+    // Residual epilogue on the ping-pong schedule: the fp32 residual values of the tile are requested at tile START and
+    // ride in registers through the main loop (1 workgroup per CU: registers are free), so the epilogue is stores
+    // only.  They are the youngest loads when the loop is entered, hence the + RES_LOADS in its first wait.
+    constexpr bool RES_PREFETCH = (EPI == EPI_RES) && PP && FW * FX <= 4;      // 64 registers at most
+    constexpr int RES_LOADS = RES_PREFETCH ? FW * FX * 4 : 0;
+    float4 rpre[RES_PREFETCH ? FW : 1][RES_PREFETCH ? FX : 1][4];
+    auto load_res = [&]() {
+        if constexpr (RES_PREFETCH) {
+#pragma unroll
+            for (int j = 0; j < FX; ++j) {
+                int m = m0 + wx * (TX / WX) + j * 32 + frow;
+                m = m < a.M ? m : a.M - 1;
+#pragma unroll
+                for (int i = 0; i < FW; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int n = n0 + ww * (TW / WW) + i * 32 + 8 * g + 4 * fhi;
+                        n = n + 4 <= N ? n : (N >= 4 ? N - 4 : 0);           // stay inside the row; the value is unused there
+                        rpre[i][j][g] = *(const float4*)(a.res + (size_t)m * a.ldr + n);
+                    }
+            }
+        }
+    };
+    load_res();
+
     int t_lin = blockIdx.x;                              // PERSIST: position in the tile order
     bool first_tile = true;
     for (;;) {                                           // one pass unless PERSIST
@@ -184,7 +209,10 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         constexpr int KS = KB / 16;                          // MFMA k-steps per K-tile
         constexpr int PIECES = PW + PX;
         const bool lead = ww == 0;
-        if (KT > 1 && first_tile) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();   // later tiles: also this wave's epilogue stores
+        // Only loads are ordered by vmcnt, and the youngest LOADS + RES_LOADS of them are stage 1 and the residual values:
+        // at most that many operations outstanding => stage 0 has landed (epilogue stores of the previous tile still in
+        // flight only make the condition stricter).
+        if (KT > 1) wait_vmcnt<LOADS + RES_LOADS>(); else wait_vmcnt<RES_LOADS>();
         block_barrier();                                     // tile 0 is in LDS for everyone
         if (!lead) block_barrier();                          // the trailing row runs one barrier behind
         int buf = 0;
@@ -428,7 +456,9 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + ((EPI == EPI_F32) ? b[e] : bfround(b[e]));
                     if constexpr (EPI == EPI_RES) {
-                        const float4 r = *(const float4*)(a.res + (size_t)m * a.ldr + n);
+                        float4 r;
+                        if constexpr (RES_PREFETCH) r = rpre[i][j][g];
+                        else r = *(const float4*)(a.res + (size_t)m * a.ldr + n);
                         float4 o = make_float4(r.x + bfround(v[0]), r.y + bfround(v[1]), r.z + bfround(v[2]), r.w + bfround(v[3]));
                         *(float4*)((float*)a.out + (size_t)m * a.ldo + n) = o;
                     } else {  // EPI_F32 (optionally + res, no rounding)
@@ -443,6 +473,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     }
     if (!has_next) break;
     first_tile = false;
+    load_res();                                          // n0 / m0 already name the next tile
     }
 }
 
