@@ -137,13 +137,17 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("
 // issue bound, not byte bound).  `col` = first feature of group g; features >= N are not written.
 // The read-side mirror of store_bf16_groups: one 16-byte load per half-wave (lower half: group g, upper half:
 // group g+1), two swaps, and every lane has its 4 features of both groups.  Features >= N read as zero.
+// second half of the wide load_bf16_groups: a 16-byte value loaded by each half-wave -> this lane's 4 features of both groups
+__device__ __forceinline__ void split_bf16_groups(uint4 t, uint2& pg, uint2& pg1) {
+    const auto x = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
+    const auto y = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
+    pg = make_uint2(x[0], y[0]); pg1 = make_uint2(x[1], y[1]);
+}
+
 __device__ __forceinline__ void load_bf16_groups(const bf16_t* row, int col, int fhi, int N, bool wide, uint2& pg, uint2& pg1) {
     if (wide) {
         const int c = col + 8 * fhi;
-        const uint4 t = c < N ? *(const uint4*)(row + c) : make_uint4(0u, 0u, 0u, 0u);
-        const auto x = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
-        const auto y = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
-        pg = make_uint2(x[0], y[0]); pg1 = make_uint2(x[1], y[1]);
+        split_bf16_groups(c < N ? *(const uint4*)(row + c) : make_uint4(0u, 0u, 0u, 0u), pg, pg1);
     } else {
         const int c = col + 4 * fhi;
         pg = c < N ? *(const uint2*)(row + c) : make_uint2(0u, 0u);

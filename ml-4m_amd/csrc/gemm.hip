@@ -169,12 +169,19 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     const int fswz = (frow >> SWSH) & (CPR - 1);         // swizzle key (fragment bases are multiples of 32)
     const int fhi = lane >> 5;
 
-    // Residual epilogue on the ping-pong schedule: the fp32 residual values of the tile are requested at tile START and
-    // ride in registers through the main loop (1 workgroup per CU: registers are free), so the epilogue is stores
-    // only.  They are the youngest loads when the loop is entered, hence the + RES_LOADS in its first wait.
+    // Epilogues that READ (fp32 residual; saved activations of the activation-backward forms) on the ping-pong
+    // schedules: the values of the tile are requested at tile START and ride in registers through the main loop (one
+    // workgroup per CU: registers are free), so the epilogue is arithmetic + stores only.  They are the youngest loads
+    // when the loop is entered, hence the + epi_loads in its first wait.
     constexpr bool RES_PREFETCH = (EPI == EPI_RES) && PP && FW * FX <= 4;      // 64 registers at most
-    constexpr int RES_LOADS = RES_PREFETCH ? FW * FX * 4 : 0;
+    constexpr bool ACT_PREFETCH = (EPI == EPI_SWIGLU_BWD || EPI == EPI_GELU_BWD) && PP && FW * FX <= 4;
+    constexpr int NSRC = (EPI == EPI_SWIGLU_BWD) ? 2 : 1;                       // (g | u) or the pre-activation
+    constexpr int EPI_LOADS = RES_PREFETCH ? FW * FX * 4 : ACT_PREFETCH ? FW * FX * 2 * NSRC : 0;
     float4 rpre[RES_PREFETCH ? FW : 1][RES_PREFETCH ? FX : 1][4];
+    uint4 apre[ACT_PREFETCH ? FW : 1][ACT_PREFETCH ? FX : 1][2][NSRC];
+    // 16-byte accesses need the 8-element granularity (else the epilogue falls back to its own narrow loads)
+    const bool act_wide = ACT_PREFETCH && ((N | a.Hp | a.ldo | a.ldr) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.res) & 15) == 0;
+    const bool epi_prefetch = RES_PREFETCH || act_wide;
     auto load_res = [&]() {
         if constexpr (RES_PREFETCH) {
 #pragma unroll
@@ -189,6 +196,25 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                         n = n + 4 <= N ? n : (N >= 4 ? N - 4 : 0);           // stay inside the row; the value is unused there
                         rpre[i][j][g] = *(const float4*)(a.res + (size_t)m * a.ldr + n);
                     }
+            }
+        }
+        if constexpr (ACT_PREFETCH) {
+            if (act_wide) {
+#pragma unroll
+                for (int j = 0; j < FX; ++j) {
+                    int m = m0 + wx * (TX / WX) + j * 32 + frow;
+                    m = m < a.M ? m : a.M - 1;
+                    const bf16_t* srow = (const bf16_t*)a.res + (size_t)m * a.ldr;
+#pragma unroll
+                    for (int i = 0; i < FW; ++i)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            int c = n0 + ww * (TW / WW) + i * 32 + 16 * gp + 8 * fhi;
+                            c = c + 8 <= N ? c : N - 8;                      // N % 8 == 0 here
+#pragma unroll
+                            for (int q = 0; q < NSRC; ++q) apre[i][j][gp][q] = *(const uint4*)(srow + q * a.Hp + c);
+                        }
+                }
             }
         }
     };
@@ -209,10 +235,11 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         constexpr int KS = KB / 16;                          // MFMA k-steps per K-tile
         constexpr int PIECES = PW + PX;
         const bool lead = ww == 0;
-        // Only loads are ordered by vmcnt, and the youngest LOADS + RES_LOADS of them are stage 1 and the residual values:
+        // Only loads are ordered by vmcnt, and the youngest LOADS + EPI_LOADS of them are stage 1 and the epilogue's values:
         // at most that many operations outstanding => stage 0 has landed (epilogue stores of the previous tile still in
         // flight only make the condition stricter).
-        if (KT > 1) wait_vmcnt<LOADS + RES_LOADS>(); else wait_vmcnt<RES_LOADS>();
+        if (epi_prefetch) { if (KT > 1) wait_vmcnt<LOADS + EPI_LOADS>(); else wait_vmcnt<EPI_LOADS>(); }
+        else { if (KT > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); }
         block_barrier();                                     // tile 0 is in LDS for everyone
         if (!lead) block_barrier();                          // the trailing row runs one barrier behind
         int buf = 0;
@@ -403,8 +430,13 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                 uint2 sg_[4], su_[4], o1[4], o2[4];
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
-                    load_bf16_groups(srow, nb + 8 * g, fhi, N, wide, sg_[g], sg_[g + 1]);
-                    if constexpr (EPI == EPI_SWIGLU_BWD) load_bf16_groups(srow + a.Hp, nb + 8 * g, fhi, N, wide, su_[g], su_[g + 1]);
+                    if (ACT_PREFETCH && act_wide) {              // requested at tile start
+                        split_bf16_groups(apre[ACT_PREFETCH ? i : 0][ACT_PREFETCH ? j : 0][g / 2][0], sg_[g], sg_[g + 1]);
+                        if constexpr (EPI == EPI_SWIGLU_BWD) split_bf16_groups(apre[ACT_PREFETCH ? i : 0][ACT_PREFETCH ? j : 0][g / 2][NSRC - 1], su_[g], su_[g + 1]);
+                    } else {
+                        load_bf16_groups(srow, nb + 8 * g, fhi, N, wide, sg_[g], sg_[g + 1]);
+                        if constexpr (EPI == EPI_SWIGLU_BWD) load_bf16_groups(srow + a.Hp, nb + 8 * g, fhi, N, wide, su_[g], su_[g + 1]);
+                    }
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
