@@ -287,12 +287,14 @@ def main():
     value = tokens_per_step * a.steps / dt
     head_vocabs = [model.decoder_embeddings[m].vocab_size for m in MOD7_OUT]
     flops_step = train_flops_per_sample(model, a.n_in, a.n_out, head_vocabs) * a.batch
+    n_params = sum(p.numel() for p in {id(p): p for p in model.parameters()}.values())
+    family = {"fm_tiny": "4M-Ti", "fm_small": "4M-S", "fm_base": "4M-B", "fm_large": "4M-L", "fm_xlarge": "4M-XL"}.get(a.model.rsplit("_", 4)[0], a.model)
     out = {
-        "metric": "multimodal tokens/sec (4M-B train step, whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
+        "metric": f"multimodal tokens/sec ({family} train step, whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "4M-B mod7 (fm_base_12e_12d_swiglu_nobias, 360.8M params) masked-modeling train step, 224^2 token grids, "
-                               "128 input + 128 target tokens/sample, AdamW", "model": a.model, "per_gpu_batch": a.batch,
+        "config": {"workload": f"{family} mod7 ({a.model}, {n_params / 1e6:.1f}M params) masked-modeling train step, 224^2 token grids, "
+                               f"{a.n_in} input + {a.n_out} target tokens/sample, AdamW", "model": a.model, "per_gpu_batch": a.batch,
                    "global_batch": a.batch * world, "seq_len": a.n_in + a.n_out, "parallelism": f"dp{world}"},
         "tokens_per_sec_per_gpu": value / world,
         "mfu": flops_step * a.steps / dt / (BF16_PEAK_TFLOPS * 1e12),
