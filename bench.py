@@ -313,8 +313,9 @@ def main():
     if rank == 0 and not a.no_kernel_profile:
         agg = prof.summary()
         tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
-        symbol = {"gemm_nt": "gemm_nt_kernel<128,256,2,4,{{32|64}},3,EPI={epi},false>  (csrc/gemm.hip)",
-                  "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,32,3>  (csrc/gemm.hip)",
+        symbol = {"gemm_nt": "gemm_nt_kernel<128,256,2,4,{{32|64}},3,EPI={epi},GROUPED=false,PP=true,PERSIST=true>  (csrc/gemm.hip; "
+                             "K-step 32 for K < 1536, 64 above)",
+                  "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,64,3,PP=true>  (csrc/gemm.hip)",
                   "attn_fwd": "attn_fwd_kernel<true,MASK>", "attn_bwd": "attn_bwd_kernel<true,MASK>",
                   "layernorm_fwd": "ln_fwd_kernel<bf16,3>", "layernorm_bwd": "ln_bwd_kernel<3>"}
         name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
