@@ -32,7 +32,7 @@ enum fm_epilogue {
     FM_EPI_BF16 = 0,     /* out(bf16)  = bf16(acc + bias)                                            */
     FM_EPI_GELU = 1,     /* out(bf16)  = gelu(bf16(acc + bias)); out2(bf16, optional) = pre-activation */
     FM_EPI_RESIDUAL = 2, /* out(f32)   = res(f32) + bf16(acc + bias)      (out may alias res)         */
-    FM_EPI_SWIGLU = 3,   /* W -> g, W2 -> u: out(bf16)[m][h] = silu(g)*u; out2(bf16)[m][h] = g, [m][Hp+h] = u */
+    FM_EPI_SWIGLU = 3,   /* W -> g, W2 -> u: out(bf16)[m][h] = silu(g)*u; out2(bf16, optional)[m][h] = g, [m][Hp+h] = u */
     FM_EPI_F32 = 4,      /* out(f32)   = acc + bias (+ res(f32) when given; no rounding)              */
     FM_EPI_TANH = 5,     /* out(bf16)  = tanh(bf16(acc + bias))                                       */
     FM_EPI_SWIGLU_BWD = 6, /* acc = d(silu(g)*u); res(bf16,(M,2*Hp)) = g|u saved by FM_EPI_SWIGLU;

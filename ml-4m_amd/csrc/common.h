@@ -129,6 +129,16 @@ __device__ __forceinline__ bf16x8_t lds_col_frag_tr_async(AddrFn addr_of, int rA
 }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
+// erf to ~1.5e-7 absolute (Abramowitz & Stegun 7.1.26): one v_exp + one v_rcp + a degree-5 polynomial instead of
+// libdevice's erff (several times the VALU work); exact-GELU epilogues and their backward use it.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * __expf(-ax * ax);
+    return x < 0.f ? -r : r;
+}
+
 // ---- 16-byte accesses for MFMA 32x32 accumulator rows (used by the GEMM epilogues and attention) ----------------
 // bf16 epilogue store of two adjacent 8-feature groups of one row.  After the 32x32 MFMA chain lane l holds
 // features [8g+4h, 8g+4h+4) of its row (h = l >> 5; lanes l and l+32 share the row), packed in `pg` for group g

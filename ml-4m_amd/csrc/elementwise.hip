@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float cdf = 0.5f * (1.0f + erff(xv[e] * 0.70710678118654752f));
+            const float cdf = 0.5f * (1.0f + erf_fast(xv[e] * 0.70710678118654752f));
             const float pdf = 0.3989422804014327f * __expf(-0.5f * xv[e] * xv[e]);
             o[e] = (c + e < H) ? dv[e] * (cdf + xv[e] * pdf) : 0.f;
         }

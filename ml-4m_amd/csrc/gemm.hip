@@ -35,7 +35,7 @@ struct NTArgs {
     int prio;                                             // raise the wave priority around the MFMA clusters
 };
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
@@ -344,9 +344,9 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         const int m = em0 + wx * (TX / WX) + j * 32 + frow;
         if (m >= a.M) continue;
         if constexpr (EPI == EPI_SWIGLU) {
-            bf16_t* gu = (bf16_t*)a.out2 + (size_t)m * a.ldo2;
+            bf16_t* gu = a.out2 ? (bf16_t*)a.out2 + (size_t)m * a.ldo2 : nullptr;      // (g | u) only when a backward will need it
             bf16_t* ao = (bf16_t*)a.out + (size_t)m * a.ldo;
-            const bool wide = ((N | a.Hp | a.ldo | a.ldo2) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.out2) & 15) == 0;
+            const bool wide = ((N | a.Hp | a.ldo | (gu ? a.ldo2 : 0)) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.out2) & 15) == 0;
 #pragma unroll
             for (int ip = 0; ip < FW / 2; ++ip) {
                 // fragment pair (2ip, 2ip+1) = (g, u) of hidden units en0 + (tile row / 64) * 32 + ...
@@ -377,8 +377,10 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
-                    store_bf16_groups(gu, hb + 8 * g, pg_[g], pg_[g + 1], fhi, N, wide);
-                    store_bf16_groups(gu + a.Hp, hb + 8 * g, pu_[g], pu_[g + 1], fhi, N, wide);
+                    if (gu) {
+                        store_bf16_groups(gu, hb + 8 * g, pg_[g], pg_[g + 1], fhi, N, wide);
+                        store_bf16_groups(gu + a.Hp, hb + 8 * g, pu_[g], pu_[g + 1], fhi, N, wide);
+                    }
                     store_bf16_groups(ao, hb + 8 * g, pa_[g], pa_[g + 1], fhi, N, wide);
                 }
             }
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float cdf = 0.5f * (1.0f + erff(xv[e] * 0.70710678118654752f));
+                            const float cdf = 0.5f * (1.0f + erf_fast(xv[e] * 0.70710678118654752f));
                             const float pdf = 0.3989422804014327f * __expf(-0.5f * xv[e] * xv[e]);
                             r1[e] = (n + e < N) ? bfround(acc[i][j][4 * g + e]) * (cdf + xv[e] * pdf) : 0.f;
                         }
@@ -897,7 +899,7 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
             FM_CHECK_ARG(p->res && p->ldr % 4 == 0, "fm_gemm_nt: residual epilogue needs res / ldr%%4==0");
             return launch_nt<EPI_RES, false>(a, max_n, s);
         case FM_EPI_SWIGLU:
-            FM_CHECK_ARG(p->W2 && p->out2 && p->Hp % 4 == 0 && p->ldo2 % 4 == 0, "fm_gemm_nt: SwiGLU epilogue needs W2, out2, Hp%%4==0");
+            FM_CHECK_ARG(p->W2 && p->Hp % 4 == 0 && (!p->out2 || p->ldo2 % 4 == 0), "fm_gemm_nt: SwiGLU epilogue needs W2, Hp%%4==0");
             return launch_nt<EPI_SWIGLU, false>(a, max_n, s);
         case FM_EPI_F32: return launch_nt<EPI_F32, false>(a, max_n, s);
         case FM_EPI_TANH: return launch_nt<EPI_TANH, false>(a, max_n, s);

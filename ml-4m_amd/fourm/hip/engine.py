@@ -409,12 +409,12 @@ class FourMEngine:
     def _mlp_fwd(self, mlp, h, x_res, x_out, R, Rp, sv, tag):
         bf = torch.bfloat16
         if self.gated:
-            gu = self._buf(sv, tag, "gu", (Rp, 2 * self.Hp), bf)
+            gu = self._buf(sv, tag, "gu", (Rp, 2 * self.Hp), bf) if sv is not None else None       # inference: nothing to save
             act = self._buf(sv, tag, "act", (Rp, self.Hp), bf)
             ops.gemm_nt(h, self.w(mlp.fc1.weight), act, epilogue=L.EPI_SWIGLU, w2=self.w(mlp.fc3.weight), out2=gu, Hp=self.Hp,
                         bias=mlp.fc1.bias, bias2=mlp.fc3.bias, M=R, N=self.Hd, K=self.D)
         else:
-            pre = self._buf(sv, tag, "pre", (Rp, self.Hp), bf)
+            pre = self._buf(sv, tag, "pre", (Rp, self.Hp), bf) if sv is not None else None     # inference: nothing to save
             act = self._buf(sv, tag, "act", (Rp, self.Hp), bf)
             ops.gemm_nt(h, self.w(mlp.fc1.weight), act, epilogue=L.EPI_GELU, out2=pre, bias=mlp.fc1.bias, M=R, N=self.Hd, K=self.D)
         ops.gemm_nt(act, self.w(mlp.fc2.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=mlp.fc2.bias, M=R, N=self.D, K=self.Hp)
