@@ -245,6 +245,7 @@ int fm_cross_entropy(void* logits, int ldl, const int32_t* perm, const int32_t* 
 /* ------------------------------------------------------------------------------------------------
  * Element-wise / reductions
  * ---------------------------------------------------------------------------------------------- */
+/* fm_swiglu_bwd: Hp and the leading dims multiples of 8, buffers 16-byte aligned (16-byte accesses). */
 int fm_swiglu_bwd(const void* da, int ldda, const void* gu, int ldgu, void* dgu, int lddgu, int R, int H, int Hp, void* stream);
 int fm_gelu_bwd(const void* dh, int lddh, const void* pre, int ldp, void* dpre, int lddp, int R, int H, int Hp, void* stream);
 /* One launch refreshing many bf16 weight shadows from their fp32 masters (what autocast's per-call weight

@@ -19,24 +19,34 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __ex
 // gu / dgu: (R, 2*Hp) with g | u halves;  da: (R, Hp).  Pad columns (>= H) are written as zero.
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ da, int ldda, const bf16_t* __restrict__ gu, int ldgu,
                                                          bf16_t* __restrict__ dgu, int lddgu, int R, int H, int Hp) {
-    const int cpr = Hp / 4;
+    // 8 features per thread, all six 16-byte loads issued before the arithmetic (a pure HBM stream)
+    const int cpr = Hp / 8;
     const size_t total = (size_t)R * cpr;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int r = i / cpr, c = (i % cpr) * 4;
-        const float4 d = ld_bf4(da + (size_t)r * ldda + c);
-        const float4 g = ld_bf4(gu + (size_t)r * ldgu + c), u = ld_bf4(gu + (size_t)r * ldgu + Hp + c);
-        float dg[4], du[4];
-        const float dv[4] = {d.x, d.y, d.z, d.w}, gv[4] = {g.x, g.y, g.z, g.w}, uv[4] = {u.x, u.y, u.z, u.w};
+        const int r = i / cpr, c = (i % cpr) * 8;
+        const uint4 dp = *(const uint4*)(da + (size_t)r * ldda + c);
+        const uint4 gp = *(const uint4*)(gu + (size_t)r * ldgu + c), up = *(const uint4*)(gu + (size_t)r * ldgu + Hp + c);
+        const uint32_t dw[4] = {dp.x, dp.y, dp.z, dp.w}, gw[4] = {gp.x, gp.y, gp.z, gp.w}, uw[4] = {up.x, up.y, up.z, up.w};
+        uint32_t og[4], ou[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float sg = sigmoid_f(gv[e]);
-            const float s = bfround(gv[e] * sg);
-            const float ds = bfround(dv[e] * uv[e]);
-            du[e] = (c + e < H) ? dv[e] * s : 0.f;
-            dg[e] = (c + e < H) ? ds * (sg * (1.0f + gv[e] * (1.0f - sg))) : 0.f;
+        for (int q = 0; q < 4; ++q) {
+            float dg[2], du[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float dv = bf2f((bf16_t)(e ? dw[q] >> 16 : dw[q] & 0xffff));
+                const float gv = bf2f((bf16_t)(e ? gw[q] >> 16 : gw[q] & 0xffff));
+                const float uv = bf2f((bf16_t)(e ? uw[q] >> 16 : uw[q] & 0xffff));
+                const float sg = sigmoid_f(gv);
+                const float sl = bfround(gv * sg);
+                const float ds = bfround(dv * uv);
+                const bool live = c + 2 * q + e < H;
+                du[e] = live ? dv * sl : 0.f;
+                dg[e] = live ? ds * (sg * (1.0f + gv * (1.0f - sg))) : 0.f;
+            }
+            og[q] = pack2bf(dg[0], dg[1]); ou[q] = pack2bf(du[0], du[1]);
         }
-        st_bf4(dgu + (size_t)r * lddgu + c, dg[0], dg[1], dg[2], dg[3]);
-        st_bf4(dgu + (size_t)r * lddgu + Hp + c, du[0], du[1], du[2], du[3]);
+        *(uint4*)(dgu + (size_t)r * lddgu + c) = make_uint4(og[0], og[1], og[2], og[3]);
+        *(uint4*)(dgu + (size_t)r * lddgu + Hp + c) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
     }
 }
 
@@ -261,9 +271,10 @@ inline int grid_for(size_t work_items) {
 }  // namespace
 
 extern "C" int fm_swiglu_bwd(const void* da, int ldda, const void* gu, int ldgu, void* dgu, int lddgu, int R, int H, int Hp, void* stream) {
-    FM_CHECK_ARG(da && gu && dgu && R > 0 && H > 0 && Hp >= H && Hp % 4 == 0, "fm_swiglu_bwd: bad argument");
-    FM_CHECK_ARG(ldda % 4 == 0 && ldgu % 4 == 0 && lddgu % 4 == 0, "fm_swiglu_bwd: leading dims must be multiples of 4");
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((size_t)R * Hp / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)da, ldda,
+    FM_CHECK_ARG(da && gu && dgu && R > 0 && H > 0 && Hp >= H && Hp % 8 == 0, "fm_swiglu_bwd: bad argument (Hp must be a multiple of 8)");
+    FM_CHECK_ARG(ldda % 8 == 0 && ldgu % 8 == 0 && lddgu % 8 == 0 && ((((uintptr_t)da | (uintptr_t)gu | (uintptr_t)dgu) & 15) == 0),
+                 "fm_swiglu_bwd: 16-byte aligned buffers with leading dims that are multiples of 8");
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((size_t)R * Hp / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)da, ldda,
                        (const bf16_t*)gu, ldgu, (bf16_t*)dgu, lddgu, R, H, Hp);
     FM_CHECK_LAUNCH("fm_swiglu_bwd");
     return 0;
