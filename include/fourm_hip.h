@@ -64,7 +64,8 @@ typedef struct fm_gemm_nt_args {
 int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
 /* tile configuration of fm_gemm_nt, for A/B measurements (table in csrc/gemm.hip): low byte 0-8 = fixed
  * configuration, 9 = automatic (default); +256 = raise the wave priority around the MFMA clusters;
- * bits 16-19 / 20-23 (when non-zero) = the configurations "automatic" picks for K < 1536 / K >= 1536. */
+ * bits 16-19 / 20-23 (when non-zero) = the configurations "automatic" picks for K < 1536 / K >= 1536 (and reading
+ * epilogues); bits 24-27 (when non-zero) = its choice for the SwiGLU epilogue. */
 void fm_set_gemm_nt_config(int cfg);
 int fm_get_gemm_nt_config(void);
 

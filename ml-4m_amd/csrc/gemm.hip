@@ -786,6 +786,7 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
 }
 
 int g_nt_config = 9, g_nt_prio = 1;
+int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
 static int n_compute_units() {
@@ -833,6 +834,7 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
 //   8  as 2 with the ping-pong schedule
 //  10  as 7, persistent workgroups (next tile's first stages issued before the store epilogue)
 //  11  as 8, persistent workgroups
+//  12  as 3 (256 x 256), persistent workgroups
 //   +256: s_setprio(1) around the MFMA clusters
 //   9  automatic (default): 10 for long reductions (K >= 1536) and the reading epilogues, 2 for SwiGLU, else 11
 //      (measured: profiles/r01_v5_nt_config_sweep.txt, profiles/r01_v8_nt_config_sweep.txt)
@@ -847,8 +849,12 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     if (a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
     if constexpr (!GROUPED) {
         int cfg = g_nt_config;
-        if (cfg == 9)    // epilogues that READ prefer one workgroup per CU; the write-heavy SwiGLU epilogue two lock-step ones
-            cfg = EPI == EPI_SWIGLU ? 2 : g_nt_auto[(a.K >= 1536 || EPI == EPI_RES || EPI == EPI_SWIGLU_BWD || EPI == EPI_GELU_BWD) ? 1 : 0];
+        if (cfg == 9) {  // epilogues that READ and long reductions: one workgroup per CU (10); SwiGLU: 256 x 256 tiles (12)
+            cfg = EPI == EPI_SWIGLU ? g_nt_swiglu : g_nt_auto[(a.K >= 1536 || EPI == EPI_RES || EPI == EPI_SWIGLU_BWD || EPI == EPI_GELU_BWD) ? 1 : 0];
+            // short reductions whose 256 x 256 tiling fills the chip in whole rounds (N = 2048, 1536 at 32768 rows): +5 %
+            const long t256 = (long)((max_n + 255) / 256) * ((a.M + 255) / 256);
+            if (cfg == g_nt_auto[0] && g_nt_auto[0] == 11 && max_n % 256 == 0 && t256 % n_compute_units() == 0) cfg = 12;
+        }
         switch (cfg) {
             case 0: return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI, false>(a, max_n, s);
             case 1: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false>(a, max_n, s);
@@ -860,6 +866,7 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
             case 8: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false, true>(a, max_n, s);
             case 10: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false, true, true>(a, max_n, s);
             case 11: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false, true, true>(a, max_n, s);
+            case 12: return launch_nt_cfg<256, 256, 2, 4, 32, 3, EPI, false, true, true>(a, max_n, s);
             default: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false>(a, max_n, s);
         }
     }
@@ -917,7 +924,8 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
 
 extern "C" void fm_set_gemm_nt_config(int cfg) {
     g_nt_config = cfg & 0xff; g_nt_prio = (cfg >> 8) & 1;
-    if (cfg >> 16) { g_nt_auto[0] = (cfg >> 16) & 0xf; g_nt_auto[1] = (cfg >> 20) & 0xf; }   // bits 16-19 / 20-23: automatic pair
+    if ((cfg >> 16) & 0xff) { g_nt_auto[0] = (cfg >> 16) & 0xf; g_nt_auto[1] = (cfg >> 20) & 0xf; }   // bits 16-19 / 20-23: automatic pair
+    if ((cfg >> 24) & 0xf) g_nt_swiglu = (cfg >> 24) & 0xf;                                             // bits 24-27: the SwiGLU choice
 }
 extern "C" int fm_get_gemm_nt_config(void) { return g_nt_config; }
 static int g_tn_config = 1;

@@ -37,7 +37,7 @@ def randn(*shape, scale=1.0, seed=None):
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12])
 def test_gemm_nt_tile_configs(cfg):
     """Every tile configuration of fm_gemm_nt (fm_set_gemm_nt_config) on ragged shapes and all epilogue kinds."""
     ops, L = _ops()
