@@ -396,19 +396,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
             bf16_t* dkrow = a.dK + ((size_t)b * a.Nk + kc) * a.lddk + h * HD;
             bf16_t* dvrow = a.dV + ((size_t)b * a.Nk + kc) * a.lddv + h * HD;
             const int lim = k < a.Nk ? HD : 0;           // rows past Nk write nothing
+            // one output after the other: the four 32-byte pieces of a row's 128-byte line leave back to back
 #pragma unroll
-            for (int df = 0; df < 2; ++df)
+            for (int which = 0; which < 2; ++which)
 #pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    uint2 pk[2], pv2[2];
+                for (int df = 0; df < 2; ++df)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        pk[u] = make_uint2(pack2bf(dKt[df][4 * (g + u)], dKt[df][4 * (g + u) + 1]), pack2bf(dKt[df][4 * (g + u) + 2], dKt[df][4 * (g + u) + 3]));
-                        pv2[u] = make_uint2(pack2bf(dVt[df][4 * (g + u)], dVt[df][4 * (g + u) + 1]), pack2bf(dVt[df][4 * (g + u) + 2], dVt[df][4 * (g + u) + 3]));
+                    for (int g = 0; g < 4; g += 2) {
+                        const f32x16_t& t = which ? dVt[df] : dKt[df];
+                        uint2 pk[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            pk[u] = make_uint2(pack2bf(t[4 * (g + u)], t[4 * (g + u) + 1]), pack2bf(t[4 * (g + u) + 2], t[4 * (g + u) + 3]));
+                        store_bf16_groups(which ? dvrow : dkrow, df * 32 + 8 * g, pk[0], pk[1], fhi, lim, which ? wide_v : wide_k);
                     }
-                    store_bf16_groups(dkrow, df * 32 + 8 * g, pk[0], pk[1], fhi, lim, wide_k);
-                    store_bf16_groups(dvrow, df * 32 + 8 * g, pv2[0], pv2[1], fhi, lim, wide_v);
-                }
         }
     }
 

@@ -347,11 +347,13 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             bf16_t* gu = a.out2 ? (bf16_t*)a.out2 + (size_t)m * a.ldo2 : nullptr;      // (g | u) only when a backward will need it
             bf16_t* ao = (bf16_t*)a.out + (size_t)m * a.ldo;
             const bool wide = ((N | a.Hp | a.ldo | (gu ? a.ldo2 : 0)) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.out2) & 15) == 0;
+            // all values of this row first, then the stores output by output: the 16-byte pieces of one 128-byte line
+            // (one line per row and output for a 64-hidden wave tile) leave back to back and merge in L2
+            uint2 pg_[FW / 2][4], pu_[FW / 2][4], pa_[FW / 2][4];
 #pragma unroll
             for (int ip = 0; ip < FW / 2; ++ip) {
-                // fragment pair (2ip, 2ip+1) = (g, u) of hidden units en0 + (tile row / 64) * 32 + ...
+                // fragment pair (2ip, 2ip+1) = (g, u) of hidden units n0 + (tile row / 64) * 32 + ...
                 const int hb = en0 + (ww * (TW / WW) / 64 + ip) * 32;
-                uint2 pg_[4], pu_[4], pa_[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int h = hb + 8 * g + 4 * fhi;
@@ -371,17 +373,24 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                         uv[e] = live ? bfround(acc[2 * ip + 1][j][4 * g + e] + b2[e]) : 0.f;
                         av[e] = bfround(silu_f(gv[e])) * uv[e];
                     }
-                    pg_[g] = make_uint2(pack2bf(gv[0], gv[1]), pack2bf(gv[2], gv[3]));
-                    pu_[g] = make_uint2(pack2bf(uv[0], uv[1]), pack2bf(uv[2], uv[3]));
-                    pa_[g] = make_uint2(pack2bf(av[0], av[1]), pack2bf(av[2], av[3]));
+                    pg_[ip][g] = make_uint2(pack2bf(gv[0], gv[1]), pack2bf(gv[2], gv[3]));
+                    pu_[ip][g] = make_uint2(pack2bf(uv[0], uv[1]), pack2bf(uv[2], uv[3]));
+                    pa_[ip][g] = make_uint2(pack2bf(av[0], av[1]), pack2bf(av[2], av[3]));
                 }
+            }
 #pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    if (gu) {
-                        store_bf16_groups(gu, hb + 8 * g, pg_[g], pg_[g + 1], fhi, N, wide);
-                        store_bf16_groups(gu + a.Hp, hb + 8 * g, pu_[g], pu_[g + 1], fhi, N, wide);
+            for (int which = 0; which < 3; ++which) {
+                if (which < 2 && !gu) continue;
+                bf16_t* dst = which == 0 ? gu : which == 1 ? gu + a.Hp : ao;
+#pragma unroll
+                for (int ip = 0; ip < FW / 2; ++ip) {
+                    const int hb = en0 + (ww * (TW / WW) / 64 + ip) * 32;
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) {
+                        const uint2 lo = which == 0 ? pg_[ip][g] : which == 1 ? pu_[ip][g] : pa_[ip][g];
+                        const uint2 hi = which == 0 ? pg_[ip][g + 1] : which == 1 ? pu_[ip][g + 1] : pa_[ip][g + 1];
+                        store_bf16_groups(dst, hb + 8 * g, lo, hi, fhi, N, wide);
                     }
-                    store_bf16_groups(ao, hb + 8 * g, pa_[g], pa_[g + 1], fhi, N, wide);
                 }
             }
         } else if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU || EPI == EPI_TANH) {
