@@ -421,11 +421,13 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                     }
                     po[g] = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                 }
+                // one output after the other (the pieces of a 128-byte line leave back to back; see the SwiGLU epilogue)
 #pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    store_bf16_groups(orow, nb + 8 * g, po[g], po[g + 1], fhi, N, wide);
-                    if constexpr (EPI == EPI_GELU) {
-                        if (prow) store_bf16_groups(prow, nb + 8 * g, pp[g], pp[g + 1], fhi, N, wide);
+                for (int g = 0; g < 4; g += 2) store_bf16_groups(orow, nb + 8 * g, po[g], po[g + 1], fhi, N, wide);
+                if constexpr (EPI == EPI_GELU) {
+                    if (prow) {
+#pragma unroll
+                        for (int g = 0; g < 4; g += 2) store_bf16_groups(prow, nb + 8 * g, pp[g], pp[g + 1], fhi, N, wide);
                     }
                 }
             }
@@ -435,10 +437,11 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             const bf16_t* srow = (const bf16_t*)a.res + (size_t)m * a.ldr;
             bf16_t* orow = (bf16_t*)a.out + (size_t)m * a.ldo;
             const bool wide = ((N | a.Hp | a.ldo | a.ldr) & 7) == 0 && (((uintptr_t)a.out | (uintptr_t)a.res) & 15) == 0;
+            uint2 o1[FW][4], o2[FW][4];
 #pragma unroll
             for (int i = 0; i < FW; ++i) {
                 const int nb = en0 + ww * (TW / WW) + i * 32;
-                uint2 sg_[4], su_[4], o1[4], o2[4];
+                uint2 sg_[4], su_[4];
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
                     if (ACT_PREFETCH && act_wide) {              // requested at tile start
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                             r2[e] = live ? d * sl : 0.f;
                             r1[e] = live ? ds * (sg * (1.0f + xv[e] * (1.0f - sg))) : 0.f;
                         }
-                        o2[g] = make_uint2(pack2bf(r2[0], r2[1]), pack2bf(r2[2], r2[3]));
+                        o2[i][g] = make_uint2(pack2bf(r2[0], r2[1]), pack2bf(r2[2], r2[3]));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -476,13 +479,19 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
                             r1[e] = (n + e < N) ? bfround(acc[i][j][4 * g + e]) * (cdf + xv[e] * pdf) : 0.f;
                         }
                     }
-                    o1[g] = make_uint2(pack2bf(r1[0], r1[1]), pack2bf(r1[2], r1[3]));
+                    o1[i][g] = make_uint2(pack2bf(r1[0], r1[1]), pack2bf(r1[2], r1[3]));
                 }
+            }
+            // one output after the other: the pieces of a row's 128-byte line leave back to back (see the SwiGLU epilogue)
 #pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    store_bf16_groups(orow, nb + 8 * g, o1[g], o1[g + 1], fhi, N, wide);
-                    if constexpr (EPI == EPI_SWIGLU_BWD) store_bf16_groups(orow + a.Hp, nb + 8 * g, o2[g], o2[g + 1], fhi, N, wide);
-                }
+            for (int i = 0; i < FW; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) store_bf16_groups(orow, en0 + ww * (TW / WW) + i * 32 + 8 * g, o1[i][g], o1[i][g + 1], fhi, N, wide);
+            if constexpr (EPI == EPI_SWIGLU_BWD) {
+#pragma unroll
+                for (int i = 0; i < FW; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; g += 2) store_bf16_groups(orow + a.Hp, en0 + ww * (TW / WW) + i * 32 + 8 * g, o2[i][g], o2[i][g + 1], fhi, N, wide);
             }
         } else {
 #pragma unroll
