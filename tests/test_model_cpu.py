@@ -117,3 +117,46 @@ def test_c_abi_exports_every_declared_symbol():
         assert re.search(rf"{name}\s*(=|\s)\s*{val}\b", header), name
     # struct sizes agree with the C compiler's layout rules (natural alignment, no packing)
     assert ctypes.sizeof(_lib.GemmGroup) == 32 and ctypes.sizeof(_lib.ModDesc) % 8 == 0
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """Every struct of include/fourm_hip.h: sizeof and the offset of every field, as gcc lays them out, against the
+    ctypes mirrors the Python side passes to libfourm_hip.so (a silent mismatch would corrupt arguments)."""
+    import shutil
+    import subprocess
+    from fourm.hip import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    pairs = {"fm_gemm_group": _lib.GemmGroup, "fm_gemm_nt_args": _lib.GemmNTArgs, "fm_gemm_tn_args": _lib.GemmTNArgs,
+             "fm_attn_args": _lib.AttnArgs, "fm_mod_desc": _lib.ModDesc, "fm_select_desc": _lib.SelectDesc,
+             "fm_embed_bwd_mod": _lib.EmbedBwdMod, "fm_embed_bwd_desc": _lib.EmbedBwdDesc, "fm_shadow_desc": _lib.ShadowDesc}
+    header = open(os.path.join(ROOT, "include", "fourm_hip.h")).read()
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "fourm_hip.h"', 'int main(void) {']
+    fields = {}
+    for cname in pairs:
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                nm = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?\s*$", part.strip()).group(1)
+                names.append(nm)
+        fields[cname] = names
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for nm in names:
+            lines.append(f'  printf("{cname}.{nm} %zu\\n", offsetof({cname}, {nm}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert ctypes.sizeof(cls) == int(out[cname]), (cname, ctypes.sizeof(cls), out[cname])
+        mirror = [f[0] for f in cls._fields_]
+        assert mirror == fields[cname], (cname, mirror, fields[cname])
+        for nm in mirror:
+            assert getattr(cls, nm).offset == int(out[f"{cname}.{nm}"]), (cname, nm)
