@@ -160,3 +160,29 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
         assert mirror == fields[cname], (cname, mirror, fields[cname])
         for nm in mirror:
             assert getattr(cls, nm).offset == int(out[f"{cname}.{nm}"]), (cname, nm)
+
+
+def test_ctypes_prototypes_match_the_header():
+    """Number and kind (pointer / int / float) of parameters of every fm_* entry point: header vs the ctypes argtypes."""
+    from fourm.hip import _lib
+    header = open(os.path.join(ROOT, "include", "fourm_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = re.findall(r"\b(?:int|void|const char\*)\s+(fm_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header)
+    assert len(protos) >= 30
+    for name, params in protos:
+        fn = getattr(_lib.lib, name)
+        plist = [p.strip() for p in params.split(",") if p.strip() and p.strip() != "void"]
+        if fn.argtypes is None:
+            assert name in ("fm_abi_version", "fm_last_error", "fm_get_gemm_nt_config", "fm_get_gemm_tn_config", "fm_get_tn_transpose_read",
+                            "fm_get_attn_transpose_read", "fm_set_gemm_nt_config", "fm_set_attn_transpose_read"), name
+            continue
+        assert len(fn.argtypes) == len(plist), (name, len(fn.argtypes), plist)
+        for at, decl in zip(fn.argtypes, plist):
+            if "*" in decl:
+                assert at in (ctypes.c_void_p,) or hasattr(at, "_type_"), (name, decl, at)
+            elif decl.startswith("float"):
+                assert at is ctypes.c_float, (name, decl, at)
+            elif decl.startswith("int64_t"):
+                assert at is ctypes.c_int64, (name, decl, at)
+            else:
+                assert at in (ctypes.c_int, ctypes.c_int32), (name, decl, at)
