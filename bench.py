@@ -112,7 +112,7 @@ KERNEL_REGEX = {   # profiler family -> regex on the demangled kernel name (7th 
 }
 
 
-def pmc_traffic(kernel_regex, timeout_s=240):
+def pmc_traffic(kernel_regex, timeout_s=240, worker_args=()):
     """HBM-side bytes per launch of one kernel from rocprofv3 PMC counters (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
     and WRITE_SIZE are collected in SEPARATE passes (TCC slot limit) over two train steps in a child process, per
     dispatch; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 reports half of a wide coalesced read; WRITE_SIZE is
@@ -124,7 +124,7 @@ def pmc_traffic(kernel_regex, timeout_s=240):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="fm_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-               sys.executable, os.path.abspath(__file__), "--pmc-worker"]
+               sys.executable, os.path.abspath(__file__), "--pmc-worker", *worker_args]
         try:
             subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=timeout_s, capture_output=True)
             f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
@@ -324,7 +324,8 @@ def main():
                   "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms,
                   "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
         if world == 1 and not a.no_traffic and fam in KERNEL_REGEX:
-            common["traffic"], common["traffic_detail"] = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0"))
+            same_job = ["--model", a.model, "--batch", str(a.batch), "--n-in", str(a.n_in), "--n-out", str(a.n_out)]
+            common["traffic"], common["traffic_detail"] = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0"), worker_args=same_job)
         if d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS, **common}
