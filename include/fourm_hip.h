@@ -71,7 +71,7 @@ int fm_get_gemm_nt_config(void);
 
 /* out[n][k] += sum_r A[r][n] * B[r][k]   (fp32 atomic accumulation, reduction split over blocks).
  * Replaces the weight-gradient matmul autograd runs for nn.Linear (dW = dY^T X).
- * R % 64 == 0 with zero rows beyond the live ones; lda/ldb % 8 == 0; a_cols/b_cols = number of
+ * Any R >= 1: reduction rows >= R are masked inside the kernel (A / B need no padding rows); lda/ldb % 8 == 0; a_cols/b_cols = number of
  * readable columns of A/B (0 = lda/ldb).  splits <= 0 picks a split count; force_tr: -1 = library
  * default, 0 = 2-byte LDS gathers, 1 = ds_read_b64_tr_b16 transpose reads.
  * Grouped mode: group g reduces rows [seg_start[g], seg_start[g] + roundup64(seg_count[g])) into

@@ -41,6 +41,7 @@ struct AttnArgs {
     // backward only
     const bf16_t* dO; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
     int lddo, lddq, lddk, lddv;
+    int chunk;                    // rows of the two LDS tiles of the backward (a multiple of 32; >= max(Nq, Nk) padded when one chunk does)
 };
 
 __device__ __forceinline__ const char* tile_addr(const char* tile, int row, int col) {
@@ -249,16 +250,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: one workgroup per (b, h); Q, K, V, dO of that head live in LDS (Nq, Nk <= 256).
-//   pass A  (a wave owns 32 keys, loops over queries)   -> dK, dV
-//   pass B  (a wave owns 32 queries, loops over keys)   -> dQ
+// backward: one workgroup per (b, h).
+//   pass A  (a wave owns 32 keys, loops over queries)   -> dK, dV      LDS: (Q, dO)
+//   pass B  (a wave owns 32 queries, loops over keys)   -> dQ          LDS: (K, V)
 // S and dP are recomputed in both passes, so no atomics and no register-tile transposes.
+// Sequences of up to `chunk` (512) rows sit in LDS whole; longer ones (upstream trains 1024 + 1024 tokens,
+// cfgs/default/4m/models/main/*1024*) are walked in chunks that are re-staged once per round of 4 x 32 owned rows.
 // ------------------------------------------------------------------------------------------------
 template <bool TR, int MASK>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
-    const int NP = NqP > NkP ? NqP : NkP;
+    const int NP = a.chunk;                              // rows per LDS tile
+    const int nQC = (NqP + NP - 1) / NP, nKC = (NkP + NP - 1) / NP;
     // Two LDS tiles, used twice: (Q, dO) during pass A, then (K, V) during pass B.  The operand a wave keeps in
     // registers for a whole pass (its K/V block in A, its Q/dO block in B) comes straight from global memory.
     // Half the LDS of holding all four tiles -> twice the resident workgroups: this kernel streams 400 MB per
@@ -281,8 +285,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     const bf16_t* Ob = a.O + (size_t)b * a.Nq * a.ldo + h * HD;
     const bf16_t* dOb = a.dO + (size_t)b * a.Nq * a.lddo + h * HD;
 
-    stage_rows<4>(Qb, a.ldq, 0, a.Nq, NqP, Ql, wave, lane);
-    stage_rows<4>(dOb, a.lddo, 0, a.Nq, NqP, dOl, wave, lane);
+    if (nQC == 1) {
+        stage_rows<4>(Qb, a.ldq, 0, a.Nq, NqP, Ql, wave, lane);
+        stage_rows<4>(dOb, a.lddo, 0, a.Nq, NqP, dOl, wave, lane);
+    }
     // delta[q] = sum_d dO[q][d] * O[q][d]: two threads per query row, 4 x 16-byte loads each from O and dO,
     // all independent (one memory round trip for the whole prologue)
     for (int q0 = 0; q0 < NqP; q0 += 128) {
@@ -333,7 +339,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     const bool wide_v = (a.lddv & 7) == 0 && (((uintptr_t)a.dV) & 15) == 0;
 
     // ---- pass A: dK, dV -------------------------------------------------------------------------
-    for (int kb = wave; kb < nKB; kb += 4) {
+    for (int kb0 = 0; kb0 < nKB; kb0 += 4) {
+        const bool live = kb0 + wave < nKB;              // (a dead wave of the last round still joins the chunk barriers)
+        const int kb = live ? kb0 + wave : nKB - 1;
         const int k = kb * 32 + (lane & 31);            // this lane's key
         const int kc = k < a.Nk ? k : a.Nk - 1;
         const int mk = modk_l[kc];
@@ -349,14 +357,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dKt[i][r] = dVt[i][r] = 0.f;
-        for (int qb = 0; qb < nQB; ++qb) {
+        for (int qc_ = 0; qc_ < nQC; ++qc_) {
+        const int qrow0 = qc_ * NP, qrows = min(NP, NqP - qrow0);
+        if (nQC > 1) {
+            __syncthreads();                             // everyone is done with the previous chunk
+            stage_rows<4>(Qb, a.ldq, qrow0, a.Nq, qrows, Ql, wave, lane);
+            stage_rows<4>(dOb, a.lddo, qrow0, a.Nq, qrows, dOl, wave, lane);
+            __syncthreads();
+        }
+        for (int qb = qrow0 / 32; qb < (qrow0 + qrows) / 32; ++qb) {
+            const int lq = qb * 32 - qrow0;              // LDS row of the block's first query
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ql, qb * 32 + (lane & 31), kk, fhi), kf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOl, qb * 32 + (lane & 31), kk, fhi), vf[kk], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ql, lq + (lane & 31), kk, fhi), kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOl, lq + (lane & 31), kk, fhi), vf[kk], dp, 0, 0, 0);
             }
             float pv[16], dsv[16];
 #pragma unroll
@@ -382,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int sblk = 0; sblk < 2; ++sblk) {
                 const bf16x8_t pb = pack8(&pv[8 * sblk]), db = pack8(&dsv[8 * sblk]);
-                const int rA = qb * 32 + sblk * 16 + 4 * fhi;
+                const int rA = lq + sblk * 16 + 4 * fhi;
 #pragma unroll
                 for (int df = 0; df < 2; ++df) {
                     const bf16x8_t dof = lds_col_frag<TR>([&](int r, int c) { return tile_addr(dOl, r, c); }, rA, rA + 8, df * 32);
@@ -392,7 +409,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                 }
             }
         }
-        {   // lanes l and l+32 own the same key row: 16-byte stores through v_permlane32_swap (store_bf16_groups)
+        }
+        if (live) {   // lanes l and l+32 own the same key row: 16-byte stores through v_permlane32_swap (store_bf16_groups)
             bf16_t* dkrow = a.dK + ((size_t)b * a.Nk + kc) * a.lddk + h * HD;
             bf16_t* dvrow = a.dV + ((size_t)b * a.Nk + kc) * a.lddv + h * HD;
             const int lim = k < a.Nk ? HD : 0;           // rows past Nk write nothing
@@ -415,13 +433,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
 
     // ---- (K, V) take the place of (Q, dO) in LDS -------------------------------------------------
     __syncthreads();
-    stage_rows<4>(Kb, a.ldk, 0, a.Nk, NkP, Kl, wave, lane);
-    stage_rows<4>(Vb, a.ldv, 0, a.Nk, NkP, Vl, wave, lane);
-
-    __syncthreads();
+    if (nKC == 1) {
+        stage_rows<4>(Kb, a.ldk, 0, a.Nk, NkP, Kl, wave, lane);
+        stage_rows<4>(Vb, a.ldv, 0, a.Nk, NkP, Vl, wave, lane);
+        __syncthreads();
+    }
 
     // ---- pass B: dQ -----------------------------------------------------------------------------
-    for (int qb = wave; qb < nQB; qb += 4) {
+    for (int qb0 = 0; qb0 < nQB; qb0 += 4) {
+        const bool live = qb0 + wave < nQB;
+        const int qb = live ? qb0 + wave : nQB - 1;
         const int q = qb * 32 + (lane & 31);
         const int qc = q < a.Nq ? q : a.Nq - 1;
         const float4 qs = qs_l[q];
@@ -438,14 +459,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
-        for (int kb = 0; kb < nKB; ++kb) {
+        for (int kc_ = 0; kc_ < nKC; ++kc_) {
+        const int krow0 = kc_ * NP, krows = min(NP, NkP - krow0);
+        if (nKC > 1) {
+            __syncthreads();
+            stage_rows<4>(Kb, a.ldk, krow0, a.Nk, krows, Kl, wave, lane);
+            stage_rows<4>(Vb, a.ldv, krow0, a.Nk, krows, Vl, wave, lane);
+            __syncthreads();
+        }
+        for (int kb = krow0 / 32; kb < (krow0 + krows) / 32; ++kb) {
+            const int lk = kb * 32 - krow0;              // LDS row of the block's first key
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, kb * 32 + (lane & 31), kk, fhi), qf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vl, kb * 32 + (lane & 31), kk, fhi), dof[kk], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kl, lk + (lane & 31), kk, fhi), qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vl, lk + (lane & 31), kk, fhi), dof[kk], dp, 0, 0, 0);
             }
             float dsv[16];
             unsigned long long bits = 0;
@@ -471,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int sblk = 0; sblk < 2; ++sblk) {
                 const bf16x8_t db = pack8(&dsv[8 * sblk]);
-                const int rA = kb * 32 + sblk * 16 + 4 * fhi;
+                const int rA = lk + sblk * 16 + 4 * fhi;
 #pragma unroll
                 for (int df = 0; df < 2; ++df) {
                     const bf16x8_t kcf = lds_col_frag<TR>([&](int r, int c) { return tile_addr(Kl, r, c); }, rA, rA + 8, df * 32);
@@ -479,7 +509,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                 }
             }
         }
-        {
+        }
+        if (live) {
             bf16_t* dqrow = a.dQ + ((size_t)b * a.Nq + qc) * a.lddq + h * HD;
             const int lim = q < a.Nq ? HD : 0;
 #pragma unroll
@@ -551,10 +582,14 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     AttnArgs a{};
     if (int rc = fill(a, p, "fm_attn_bwd")) return rc;
     FM_CHECK_ARG(a.dO && a.dQ && a.dK && a.dV && a.stat_m && a.stat_l, "fm_attn_bwd: null pointer");
-    FM_CHECK_ARG(a.Nq <= 256 && a.Nk <= 256, "fm_attn_bwd: Nq=%d Nk=%d exceed the 256-token training budget of this kernel", a.Nq, a.Nk);
     FM_CHECK_ARG(p->lddo % 8 == 0 && p->lddq % 4 == 0 && p->lddk % 4 == 0 && p->lddv % 4 == 0, "fm_attn_bwd: leading dims");
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
-    const size_t lds = (size_t)2 * (NqP > NkP ? NqP : NkP) * ROWB + NqP * 16 + NkP * (2 + 1) + 64;
+    // up to 512 rows per tile in one piece (128 KB of tiles); longer sequences in chunks of 256 rows (two workgroups per CU)
+    const int NPmax = NqP > NkP ? NqP : NkP;
+    a.chunk = NPmax <= 512 ? NPmax : 256;
+    const size_t lds = (size_t)2 * a.chunk * ROWB + (size_t)NqP * 16 + (size_t)NkP * (2 + 1) + 64;
+    FM_CHECK_ARG(lds <= 160 * 1024, "fm_attn_bwd: Nq=%d Nk=%d need %zu bytes of LDS for the per-row statistics", a.Nq, a.Nk, lds);
+    FM_CHECK_ARG(a.Nq < 0x7fff && a.Nk < 0x7fff, "fm_attn_bwd: sequence too long for the packed 15-bit mask bounds");
     dim3 grid(a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
 #define BWD(TR, MK)                                                                                                   \

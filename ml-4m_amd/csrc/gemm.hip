@@ -12,7 +12,7 @@
 // address and again on the read (guide rule 21).
 //
 // Contracts (the Python layer allocates every bf16 buffer and guarantees them):
-//   * the reduction dimension is a multiple of 64 and zero padded;
+//   * NT: the reduction dimension K is a multiple of 64 and zero padded (TN masks its reduction rows itself);
 //   * leading dimensions are multiples of 8 elements (16-byte aligned rows).
 #include <type_traits>
 #include "common.h"
@@ -540,6 +540,11 @@ struct TNArgs {
     int n_tiles_a, n_tiles_b;
 };
 
+// Reduction rows past the live row count contribute nothing: their LDS-DMA pieces are fetched from this 16-byte zero block
+// instead of the operand (the caller's buffers need no zeroed padding rows, and a workspace reused with fewer live rows
+// cannot leak stale rows into a weight gradient).
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
 // element (row, col) of a row-major [64][cols] bf16 LDS tile with RB bytes per row; 16-byte chunks are
 // XOR-swizzled by (row & 3) << 2 so that the 4 rows a transpose read touches fall on different banks
 template <int RB>
@@ -593,14 +598,16 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     }
     const int split = item / nwg, tile = item % nwg;
     const int ta = tile / a.n_tiles_b, tb = tile % a.n_tiles_b;
-    int N = a.N, r_begin = 0, r_end = a.R;
+    int N = a.N, r_begin = 0, r_end = (a.R + KB - 1) / KB * KB, r_lim = a.R;
     float* out = a.out;
     if constexpr (GROUPED) {
         const int g = blockIdx.z;
         N = a.groups[g].N; out = (float*)a.groups[g].out;
         r_begin = a.seg_start[g];
+        r_lim = r_begin + a.seg_count[g];
         r_end = r_begin + ((a.seg_count[g] + 63) / 64) * 64;
     }
+    const bf16_t* zsrc = (const bf16_t*)g_zero16;
     const int n0 = ta * TA, k0 = tb * TB;
     if (n0 >= N || k0 >= a.K) return;
     const int nt = (r_end - r_begin) / KB;                      // reduction tiles in total
@@ -618,7 +625,8 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
             const int row = piece * RPP + lane / LPR;
             const int lc = (lane % LPR) ^ ((row & 3) << 2);
             int ca = n0 + lc * 8; ca = ca <= a.a_cols - 8 ? ca : a.a_cols - 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a.A + (size_t)(r0 + row) * a.lda + ca), LDS_PTR(base + piece * 1024), 16, 0, 0);
+            const bf16_t* src = r0 + row < r_lim ? a.A + (size_t)(r0 + row) * a.lda + ca : zsrc;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + piece * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < PB / NWAVES; ++p) {
@@ -627,7 +635,8 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
             const int row = piece * RPP + lane / LPR;
             const int lc = (lane % LPR) ^ ((row & 3) << 2);
             int cb = k0 + lc * 8; cb = cb <= a.b_cols - 8 ? cb : a.b_cols - 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
+            const bf16_t* src = r0 + row < r_lim ? a.B + (size_t)(r0 + row) * a.ldb + cb : zsrc;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
         }
     };
     // the same pieces, a share of them per call (ping-pong: spread between the MFMA groups of the leading wave row)
@@ -644,14 +653,16 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
                 const int row = piece * RPP + lane / LPR;
                 const int lc = (lane % LPR) ^ ((row & 3) << 2);
                 int ca = n0 + lc * 8; ca = ca <= a.a_cols - 8 ? ca : a.a_cols - 8;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(a.A + (size_t)(r0 + row) * a.lda + ca), LDS_PTR(base + piece * 1024), 16, 0, 0);
+                const bf16_t* src = r0 + row < r_lim ? a.A + (size_t)(r0 + row) * a.lda + ca : zsrc;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + piece * 1024), 16, 0, 0);
             } else {
                 constexpr int LPR = RBB / 16, RPP = 1024 / RBB;
                 const int piece = (q - PA / NWAVES) * NWAVES + wave;
                 const int row = piece * RPP + lane / LPR;
                 const int lc = (lane % LPR) ^ ((row & 3) << 2);
                 int cb = k0 + lc * 8; cb = cb <= a.b_cols - 8 ? cb : a.b_cols - 8;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(a.B + (size_t)(r0 + row) * a.ldb + cb), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
+                const bf16_t* src = r0 + row < r_lim ? a.B + (size_t)(r0 + row) * a.ldb + cb : zsrc;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
             }
         }
     };
@@ -958,7 +969,6 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     const bool grouped = p->groups != nullptr;
     FM_CHECK_ARG(grouped || p->out, "fm_gemm_tn: out is null");
     FM_CHECK_ARG(p->K > 0 && (grouped || (p->N > 0 && p->R > 0)), "fm_gemm_tn: bad shape");
-    FM_CHECK_ARG(grouped || p->R % BK == 0, "fm_gemm_tn: R=%d must be a multiple of %d (zero padded rows)", p->R, BK);
     FM_CHECK_ARG(p->lda % 8 == 0 && p->ldb % 8 == 0, "fm_gemm_tn: leading dims must be multiples of 8");
     TNArgs a{};
     a.A = (const bf16_t*)p->A; a.B = (const bf16_t*)p->B; a.out = (float*)p->out;
@@ -980,7 +990,7 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
         // Fill the chip in ONE round (e.g. 66 tiles on 512 slots take 7 splits = 462 workgroups; 8 would leave 16
         // workgroups for a second round).
         const int tiles = a.n_tiles_a * a.n_tiles_b;
-        const int nt = grouped ? (p->max_R + kb - 1) / kb : p->R / kb;
+        const int nt = grouped ? (p->max_R + kb - 1) / kb : (p->R + kb - 1) / kb;
         splits = tiles >= slots ? 1 : slots / tiles;
         while (splits > 1 && nt / splits < 8) --splits;                // keep >= 8 reduction tiles per workgroup
         if (splits > 64) splits = 64;

@@ -237,14 +237,52 @@ class FourMEngine:
         o, k = self._slices[id(p)]
         return self.flat_grads[o:o + k].view(p.shape)
 
-    def attach_grads(self, zero: bool):
+    def grads_were_cleared(self) -> bool:
+        """True when the parameters that carried a gradient view after the previous backward no longer do (the trainer ran
+        ``zero_grad(set_to_none=True)``, or this is the first backward): the flat store must be zeroed before accumulating."""
+        live = getattr(self, "_attached", None)
+        if not live:
+            return True
+        for p in live[:4] + live[-4:]:
+            if p.grad is None or p.grad.data_ptr() != self.grad_view(p).data_ptr():
+                return True
+        return False
+
+    def untouched_params(self):
+        """Parameters no token of the last training forward can reach: embeddings / heads of modalities absent from
+        ``mod_dict``.  Upstream leaves their ``.grad`` None (autograd never sees them), so AdamW skips them - no weight
+        decay, no moment decay, no step count.  With a gradient reducer attached every rank must take the same optimizer
+        step, so nothing is skipped there (DDP itself only skips parameters unused on EVERY rank)."""
+        c = self._ctx
+        if c is None or self.reducer is not None:
+            return []
+        m, touched, cand = self.model, set(), []
+        for names, embs in ((c["enc"]["names"], m.encoder_embeddings), (c["dec"]["names"], m.decoder_embeddings)):
+            for n, e in embs.items():
+                if n in names:
+                    touched.update(id(p) for p in e.parameters())
+                else:
+                    cand.extend(e.parameters())
+        return [p for p in cand if id(p) not in touched]
+
+    def attach_grads(self, zero: bool, untouched=()):
         """param.grad := view into the flat gradient store.  ``zero`` clears the store first (a fresh
-        accumulation window: the trainer called optimizer.zero_grad())."""
+        accumulation window: the trainer called optimizer.zero_grad()).  ``untouched`` parameters (see
+        ``_untouched_params``) keep ``grad = None`` unless an earlier micro-batch of the window reached them."""
         if zero:
             self.flat_grads.zero_()
+            self._window_touched = set()
+        skip = {id(p) for p in untouched} - getattr(self, "_window_touched", set())
+        self._attached = []
         for n, p in self._named:
-            if p.requires_grad:
-                p.grad = self.grad_view(p)
+            if not p.requires_grad:
+                continue
+            if id(p) in skip:
+                p.grad = None
+                continue
+            self._window_touched.add(id(p))
+            p.grad = self.grad_view(p)
+            self._attached.append(p)
 
     # ------------------------------------------------------------------------------------------
     # weight shadows
@@ -641,7 +679,7 @@ class FourMEngine:
     def _mlp_bwd(self, mlp, sv, g_bf, R, Rp):
         """In: g_bf = d(out) bf16.  Out: dh (bf16 scratch) = gradient w.r.t. the norm2 output."""
         bf, D, Hp, Hd = torch.bfloat16, self.D, self.Hp, self.Hd
-        R64 = ru(R, 64)
+        R64 = R           # the TN kernel masks the reduction past the live rows itself (no reliance on zeroed padding)
         ws = self.ws
         self._dW(g_bf, sv["act"], mlp.fc2, R64)
         dh = ws.get("bwd.dh", (Rp, D), bf)
@@ -673,7 +711,7 @@ class FourMEngine:
 
     def _self_attn_bwd(self, attn, sv, g_bf, B, N, R, Rp, mask):
         bf, D = torch.bfloat16, self.D
-        R64, ws = ru(R, 64), self.ws
+        R64, ws = R, self.ws
         self._dW(g_bf, sv["o"], attn.proj, R64)
         do = ws.get("bwd.do", (Rp, D), bf)
         ops.gemm_nt(g_bf, self.wt(attn.proj.weight), do, M=R, N=D, K=D)
@@ -707,7 +745,7 @@ class FourMEngine:
         self._ln_bwd(blk.norm2, dh, sv["y2"], sv, "n2", g, g_bf, Rq, dres=g)
         # cross attention
         xa = blk.cross_attn
-        self._dW(g_bf, sv["o2"], xa.proj, ru(Rq, 64))
+        self._dW(g_bf, sv["o2"], xa.proj, Rq)
         do = ws.get("bwd.do", (Rqp, D), bf)
         ops.gemm_nt(g_bf, self.wt(xa.proj.weight), do, M=Rq, N=D, K=D)
         dq = ws.get("bwd.dq", (Rqp, D), bf)
@@ -722,11 +760,11 @@ class FourMEngine:
         else:
             ops.attn_bwd(sv["q"], kv[:, :D], kv[:, D:], sv["o2"], do, dq, dkv[:, :D], dkv[:, D:], B, self.H, M, N, self.scale,
                          sv["sm2"], sv["sl2"], **xa_mask)
-        self._dW(dq, sv["hq"], xa.q, ru(Rq, 64))
+        self._dW(dq, sv["hq"], xa.q, Rq)
         dhq = ws.get("bwd.dh", (Rqp, D), bf)
         ops.gemm_nt(dq, self.wt(xa.q.weight), dhq, M=Rq, N=D, K=D)
         self._ln_bwd(blk.query_norm, dhq, sv["y1"], sv, "nq", g, g_bf, Rq, dres=g)
-        self._dW(dkv, sv["hc"], xa.kv, ru(Rc, 64))
+        self._dW(dkv, sv["hc"], xa.kv, Rc)
         dhc = ws.get("bwd.dhc", (Rcp, D), bf)
         ops.gemm_nt(dkv, self.wt(xa.kv.weight), dhc, M=Rc, N=D, K=2 * D)
         self._ln_bwd(blk.context_norm, dhc, ctx, sv, "nc", dctx, dctx_bf, Rc, dres=dctx)     # accumulates over layers
@@ -819,7 +857,7 @@ class FourMEngine:
         top = st["top"]
         if len(m.decoder) == 0:
             ops.f32_to_bf16(dctx, dctx_bf)
-        self._dW(dctx_bf, top["xn"], m.decoder_proj_context, ru(Rc, 64))
+        self._dW(dctx_bf, top["xn"], m.decoder_proj_context, Rc)
         dxn = ws.get("bwd.dh", (Rcp, D), bf)
         ops.gemm_nt(dctx_bf, self.wt(m.decoder_proj_context.weight), dxn, M=Rc, N=D, K=D)
         ge = ws.get("bwd.g_enc", (Rcp, D), f32)
@@ -833,9 +871,9 @@ class FourMEngine:
         for n in enc["names"]:
             e = m.encoder_embeddings[n]
             if e.kind == L.KIND_PATCH and e.proj.weight.requires_grad:
-                ops.gemm_tn(ge_bf, enc["patch_rows"], self.grad_view(e.proj.weight), N=D, K=e.proj.weight.shape[1], R=ru(Rc, 64))
+                ops.gemm_tn(ge_bf, enc["patch_rows"], self.grad_view(e.proj.weight), N=D, K=e.proj.weight.shape[1], R=Rc)
             elif e.kind == L.KIND_SEQ_EMB and e.emb_proj.weight.requires_grad:
-                ops.gemm_tn(ge_bf, enc["seqemb_rows"], self.grad_view(e.emb_proj.weight), N=D, K=e.emb_proj.weight.shape[1], R=ru(Rc, 64))
+                ops.gemm_tn(ge_bf, enc["seqemb_rows"], self.grad_view(e.emb_proj.weight), N=D, K=e.emb_proj.weight.shape[1], R=Rc)
         self._embed_bwd(enc, ge, dctx, False)
         if self.reducer is not None:
             self.reducer.finish()        # remaining slices + wait: gradients are averaged when backward returns

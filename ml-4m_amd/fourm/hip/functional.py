@@ -37,6 +37,8 @@ def linear(x, weight, bias, out_dtype=None):
     x2 = x.reshape(-1, shp[-1])
     R, K = x2.shape
     N = weight.shape[0]
+    if R == 0:                       # e.g. y[mod_mask == id] of a modality without rows (fm.py:535-541 returns (0, V) too)
+        return x2.new_zeros((*shp[:-1], N), dtype=out_dtype or x.dtype)
     xb = _bf16_rows(x2)
     wb = torch.zeros(N, ru(K, 64), dtype=torch.bfloat16, device=x.device)
     ops.cast_pad(weight.detach().float(), wb)
@@ -93,11 +95,25 @@ def embed_modality(emb, d, is_dec: bool):
     return tokens[:R].view(B, Lm, D), e[:R].view(B, Lm, D)
 
 
+# block module -> weak reference to the FourM that owns it (filled by FourM.__init__ / FourM.engine; a registry rather than an
+# attribute on the block so that pickling / deepcopy of the modules never meets a weakref)
+import weakref
+_BLOCK_OWNER = weakref.WeakKeyDictionary()
+
+
+def register_blocks(model):
+    ref = weakref.ref(model)
+    for blk in list(model.encoder) + list(model.decoder):
+        _BLOCK_OWNER[blk] = ref
+
+
 def _engine_of(block):
-    eng = getattr(block, "_fourm_engine", None)
-    if eng is None:
-        raise RuntimeError("this block is not attached to a FourM model (blocks compute through the model's engine)")
-    return eng()
+    ref = _BLOCK_OWNER.get(block)
+    model = ref() if ref is not None else None
+    if model is None:
+        raise RuntimeError("this block is not attached to a live FourM model (blocks compute through the model's engine; "
+                           "after copy.deepcopy / unpickling touch model.engine once)")
+    return model.engine
 
 
 def _mask_args(mask, B, Nq, Nk):

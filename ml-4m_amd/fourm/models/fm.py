@@ -40,10 +40,9 @@ class _TrainStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         eng = ctx.engine
-        first = eng._named[0][1]
-        fresh = any(p.grad is None for _, p in eng._named[:8] if p.requires_grad) or first.grad is None \
-            or first.grad.data_ptr() != eng.grad_view(first).data_ptr()
-        eng.attach_grads(zero=fresh)
+        # a fresh accumulation window = the trainer cleared the gradients (zero_grad(set_to_none=True)) since the last
+        # backward; judged on the TRAINABLE parameters this engine attached last time (frozen ones never get a grad)
+        eng.attach_grads(zero=eng.grads_were_cleared(), untouched=eng.untouched_params())
         eng.train_backward(grad_out.reshape(1).float().contiguous())
         return None, None, None
 
@@ -117,6 +116,11 @@ class FourM(nn.Module):
             self.register_tokens = None
         self.init_weights()
         self._engine = None
+        try:        # stand-alone ``blk(x, mask)`` calls find the engine through this registry (fourm/hip/functional.py)
+            from fourm.hip.functional import register_blocks
+            register_blocks(self)
+        except ImportError:      # no libfourm_hip.so: the model is a parameter container only (state_dict tools)
+            pass
 
     # ------------------------------------------------------------------------------------------
     def share_modality_embeddings(self):
@@ -175,9 +179,8 @@ class FourM(nn.Module):
                 raise RuntimeError("FourM computes on an MI355X through libfourm_hip.so; move the model to the GPU first "
                                    "(there is no CPU implementation of the hot path)")
             self._engine = FourMEngine(self)
-            ref = weakref.ref(self._engine)
-            for blk in list(self.encoder) + list(self.decoder):
-                object.__setattr__(blk, "_fourm_engine", ref)
+            from fourm.hip.functional import register_blocks
+            register_blocks(self)
         return self._engine
 
     def _apply(self, fn, *a, **k):

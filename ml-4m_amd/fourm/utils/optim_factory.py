@@ -55,8 +55,21 @@ class FusedAdamW(optim.AdamW):
         if kw.get("amsgrad") or kw.get("maximize"):
             raise NotImplementedError("FusedAdamW: amsgrad / maximize are not implemented")
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        for g in self.param_groups:
+            for p in g["params"]:
+                # fm_adamw reinterprets the storage as float*: anything else would be silently corrupted
+                if p.dtype != torch.float32 or not p.is_contiguous() or not p.is_cuda:
+                    raise TypeError(f"FusedAdamW handles contiguous fp32 device parameters only (got {p.dtype}, "
+                                    f"{'contiguous' if p.is_contiguous() else 'strided'}, {p.device}); use torch.optim.AdamW")
         self._clip_coef = None        # device scalar set by fused_grad_norm(clip=...)
         self._runs = None
+
+    @staticmethod
+    def _check_grad(p):
+        g = p.grad
+        if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+            raise TypeError(f"FusedAdamW: gradient of a {tuple(p.shape)} parameter is {g.dtype} / "
+                            f"{'contiguous' if g.is_contiguous() else 'strided'} on {g.device}; fp32 contiguous expected")
 
     # -- contiguous runs ------------------------------------------------------------------------
     def _build_runs(self):
@@ -65,13 +78,17 @@ class FusedAdamW(optim.AdamW):
         runs = []
         for gi, g in enumerate(self.param_groups):
             ps = [p for p in g["params"] if p.grad is not None]
+            for p in ps:
+                self._check_grad(p)
             ps.sort(key=lambda p: p.data_ptr())
             cur = []
             for p in ps:
                 if cur:
                     q = cur[-1]
+                    # adjacent AND carved from the same allocation (two autograd-allocated tensors that merely sit
+                    # back to back in the caching allocator are separate storages: a merged view would be out of bounds)
                     adj = (p.data_ptr() == q.data_ptr() + q.numel() * 4 and p.grad.data_ptr() == q.grad.data_ptr() + q.numel() * 4
-                           and self._state_adjacent(q, p))
+                           and _same_storage(p, q) and _same_storage(p.grad, q.grad) and self._state_adjacent(q, p))
                     if not adj:
                         runs.append((gi, cur))
                         cur = []
@@ -88,6 +105,7 @@ class FusedAdamW(optim.AdamW):
             return False
         return (sp["exp_avg"].data_ptr() == sq["exp_avg"].data_ptr() + q.numel() * 4
                 and sp["exp_avg_sq"].data_ptr() == sq["exp_avg_sq"].data_ptr() + q.numel() * 4
+                and _same_storage(sp["exp_avg"], sq["exp_avg"]) and _same_storage(sp["exp_avg_sq"], sq["exp_avg_sq"])
                 and float(sp["step"]) == float(sq["step"]))
 
     def _init_state(self, run):
@@ -111,7 +129,12 @@ class FusedAdamW(optim.AdamW):
         """L2 norm of every gradient, computed on the device; with ``clip`` the coefficient
         min(1, clip / (norm + 1e-6)) is folded into the next step().  Returns a device scalar."""
         from fourm.hip import ops
-        grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+        grads = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None:
+                    self._check_grad(p)
+                    grads.append(p.grad)
         if not grads:
             return torch.tensor(0.)
         dev = grads[0].device
@@ -125,7 +148,7 @@ class FusedAdamW(optim.AdamW):
             if t.data_ptr() in seen:
                 continue
             seen.add(t.data_ptr())
-            if start is not None and t.data_ptr() == start.data_ptr() + n * 4:
+            if start is not None and t.data_ptr() == start.data_ptr() + n * 4 and _same_storage(t, start):
                 n += t.numel()
                 continue
             if start is not None:
@@ -170,7 +193,12 @@ class FusedAdamW(optim.AdamW):
                 st["step"] = st["step"].detach().float().cpu()
 
 
+def _same_storage(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+
+
 def _flat_view(t: torch.Tensor, n: int) -> torch.Tensor:
+    """n elements starting at t's first one; the callers only merge tensors of ONE storage, so the view is in bounds."""
     return torch.as_strided(t, (n,), (1,))
 
 
@@ -202,6 +230,9 @@ def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filt
     if kind == "adam":
         return optim.Adam(parameters, **opt_args)
     if kind == "adamw":
-        on_gpu = next(model.parameters()).is_cuda
-        return FusedAdamW(parameters, **opt_args) if on_gpu else optim.AdamW(parameters, **opt_args)
+        # the fused kernel is for engine-backed models (flat fp32 parameter / gradient stores); anything else gets torch's AdamW
+        inner = getattr(model, "module", model)
+        ps = list(model.parameters())
+        fused_ok = hasattr(inner, "engine") and ps and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+        return FusedAdamW(parameters, **opt_args) if fused_ok else optim.AdamW(parameters, **opt_args)
     raise ValueError(f"Invalid optimizer {args.opt}")

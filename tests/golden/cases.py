@@ -54,6 +54,9 @@ CASES = {
                    B=2, N=256, M=256, bud=(256, 256), seed=11),
     # BASELINE.json configs[0]: 4M-Ti mod7, one masked-modeling step, seq_len 128+128, batch 2
     "ti_mod7": dict(cfg=lambda: O.named_cfg("tiny", O.mod7_specs()), B=2, N=128, M=128, bud=(128, 128), seed=0),
+    # BASELINE.json configs[1]: the benched model (4M-B mod7, 12+12 blocks, D=768, hidden 2048), batch 2 of the same
+    # 128+128-token batches (the fixture keeps summaries only)
+    "b_mod7": dict(cfg=lambda: O.named_cfg("base", O.mod7_specs()), B=2, N=128, M=128, bud=(128, 128), seed=4),
 }
 
 

@@ -169,6 +169,24 @@ def test_gemm_tn_pingpong_schedule(R, N, K, splits):
             L.lib.fm_set_gemm_tn_config(1)
 
 
+@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("R,Rbuf", [(1000, 1024), (37, 64), (4100, 4224), (300, 300)])
+def test_gemm_tn_masks_rows_past_R(cfg, R, Rbuf):
+    """Reduction rows >= R never reach the result, whatever the buffers hold there (a workspace reused with fewer live rows)."""
+    ops, L = _ops()
+    N, K = 200, 264
+    a, b = bf(randn(Rbuf, N, seed=16)), bf(randn(Rbuf, K, seed=17))
+    a[R:] = 1e4; b[R:] = float("nan")
+    ref = a[:R].float().t() @ b[:R].float()
+    L.lib.fm_set_gemm_tn_config(cfg)
+    try:
+        out = torch.zeros(N, K, device=DEV, dtype=torch.float32)
+        ops.gemm_tn(a, b, out, R=R)
+        assert rel_err(out, ref) < 1e-4, (cfg, R, rel_err(out, ref))
+    finally:
+        L.lib.fm_set_gemm_tn_config(1)
+
+
 def test_gemm_tn_identity_layout():
     ops, L = _ops()
     R = 128
@@ -348,7 +366,11 @@ def make_masks(kind, B, Nq, Nk, seed):
 @pytest.mark.parametrize("kind,Nq,Nk", [("none", 128, 128), ("keypad", 128, 128), ("decoder", 128, 128), ("dense", 96, 160),
                                         ("keypad", 40, 200), ("none", 196, 196), ("decoder", 256, 256),
                                         # ragged query / key counts
-                                        ("dense", 200, 100), ("keypad", 70, 50), ("decoder", 96, 96), ("none", 33, 128)])
+                                        ("dense", 200, 100), ("keypad", 70, 50), ("decoder", 96, 96), ("none", 33, 128),
+                                        # beyond 256 tokens: whole sequence in LDS (<= 512 rows), then the chunked backward
+                                        # (upstream trains 1024 + 1024-token configs; registers push the encoder past 256)
+                                        ("keypad", 260, 260), ("decoder", 512, 384), ("decoder", 1024, 1024), ("keypad", 600, 1030),
+                                        ("dense", 530, 70)])
 def test_attention(kind, Nq, Nk, tr):
     ops, L = _ops()
     B, H = 3, 2

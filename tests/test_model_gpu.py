@@ -12,11 +12,12 @@ import torch
 
 from oracle import fourm_oracle as O
 from tests.golden.cases import build_case
+from tests.parity_log import record
 from tests.util_model import build_hip_model, tie, to_device
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "micro_qknorm", "ti_mod7", "l_like"]
+HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "micro_qknorm", "ti_mod7", "l_like", "b_mod7"]
 
 
 def setup(name):
@@ -96,27 +97,48 @@ def test_loss_and_gradients(name):
             continue
         worst.append((rel(p.grad, og), n))
     worst.sort(reverse=True)
-    assert worst[0][0] < 6e-2, worst[:8]
+    record("model.loss_and_gradients", case=name, loss_hip=float(loss), loss_bf16_oracle=float(o_loss.sum()), loss_fp32_upstream=float(g["loss"][0]),
+           grad_rel_worst=worst[0][0], grad_rel_worst_name=worst[0][1], grad_rel_median=float(np.median([w[0] for w in worst])))
+    # measured r02: worst tensor 1.0e-2 ... 2.4e-2 (a LayerNorm weight of a deep decoder block), median 5.6e-3 ... 1.0e-2
+    assert worst[0][0] < 4.8e-2, worst[:8]
     assert float(np.median([w[0] for w in worst])) < 2e-2, worst[:8]
 
 
-@pytest.mark.parametrize("name", ["micro_swiglu", "ti_mod7"])
+# Measured on MI355X (gpurun_out/parity.jsonl -> profiles/r02_parity.jsonl): per-modality relative Frobenius error of
+# the bf16 HIP logits against (a) the oracle with bf16 rounding at upstream's autocast points, (b) the upstream fp32
+# fixture.  The asserts hold them to <= 2x the measured worst case per model (never looser than that).
+#   measured r02 (worst modality)   HIP vs bf16 oracle   HIP vs fp32   [bf16 oracle vs fp32 = upstream's own autocast gap]
+#   micro_swiglu                    7.2e-3               7.6e-3        7.6e-3
+#   ti_mod7  (4M-Ti, 6+6)           5.6e-3               7.4e-3        7.5e-3
+#   b_mod7   (4M-B, 12+12, benched) 5.9e-3               9.7e-3        9.6e-3
+LOGIT_BOUNDS = {"micro_swiglu": (1.4e-2, 1.5e-2), "ti_mod7": (1.1e-2, 1.5e-2), "b_mod7": (1.2e-2, 1.9e-2)}
+
+
+@pytest.mark.parametrize("name", ["micro_swiglu", "ti_mod7", "b_mod7"])
 def test_logits(name):
     g, case, model = setup(name)
+    cfg = case["cfg"]
     model.eval()
     random.seed(case["order_seed"])
     with torch.no_grad():
         logits = model(to_device(case["mod_dict"]), case["N"], case["M"], return_logits=True)
+    order = g["meta/order"].tolist()
+    P = tie({k: v.clone() for k, v in case["sd"].items()}, cfg, case["share_embedding"])
+    with torch.no_grad():
+        emu = O.fourm_forward(P, cfg, case["mod_dict"], case["N"], case["M"], order, return_logits=True, emulate_bf16=True)
+        f32 = O.fourm_forward(P, cfg, case["mod_dict"], case["N"], case["M"], order, return_logits=True)
+    b_emu, b_f32 = LOGIT_BOUNDS[name]
+    errs = {}
     for k, v in logits.items():
-        assert tuple(v.shape[:2]) == (case["mod_dict"][k]["tensor"].shape[0], case["M"])
-        fro = float(v.double().norm())
-        # "logits within 1e-3 rel" is not reachable in bf16 (the upstream model's own bf16 autocast
-        # misses its fp32 self by 7e-3); the bf16 pipeline is held to 2e-2 on the norm
-        # and, where the fixture keeps the values, on the relative Frobenius error.
-        assert abs(fro - float(g[f"logits_fro/{k}"])) < 2e-2 * float(g[f"logits_fro/{k}"]), k
-        head = torch.from_numpy(g[f"logits_head/{k}"])
-        mine = v.float().cpu() if head.shape == v.shape else v.float().cpu()[:, :8, :16]
-        assert rel(mine, head) < 3e-2, (k, rel(mine, head))
+        assert tuple(v.shape) == tuple(f32[k].shape) == (case["mod_dict"][k]["tensor"].shape[0], case["M"], cfg.mod(k).vocab)
+        # the oracle's fp32 logits are the upstream model's (pinned by make_golden.py; norm + head slice rechecked here)
+        assert abs(float(f32[k].double().norm()) - float(g[f"logits_fro/{k}"])) < 1e-4 * float(g[f"logits_fro/{k}"]), k
+        errs[k] = dict(hip_vs_bf16_oracle=rel(v, emu[k]), hip_vs_fp32=rel(v, f32[k]), bf16_oracle_vs_fp32=rel(emu[k], f32[k]))
+    record("model.logits", case=name, per_modality=errs)
+    worst_emu = max(e["hip_vs_bf16_oracle"] for e in errs.values())
+    worst_f32 = max(e["hip_vs_fp32"] for e in errs.values())
+    assert worst_emu < b_emu, errs
+    assert worst_f32 < b_f32, errs
 
 
 def test_eval_forward_and_accumulation():
