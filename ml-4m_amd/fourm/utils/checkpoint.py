@@ -29,6 +29,9 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, lo
         blob["optimizer"] = optimizer.state_dict()
     if loss_balancer is not None:
         blob["loss_balancer"] = loss_balancer.state_dict()
+    if model_ema is not None:      # upstream stores the EMA module's weights under 'model_ema' (checkpoint.py:113-114)
+        ema = getattr(model_ema, "ema", getattr(model_ema, "module", model_ema))
+        blob["model_ema"] = ema.state_dict()
     torch.save(blob, out / f"checkpoint-{ckpt_name or str(epoch)}.pth")
 
 
@@ -54,6 +57,13 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
         if "scaler" in ckpt:
             loss_scaler.load_state_dict(ckpt["scaler"])
         print("With optim & sched!")
+    if getattr(args, "model_ema", False):       # upstream checkpoint.py:154-156
+        if model_ema is None or "model_ema" not in ckpt:
+            raise ValueError("args.model_ema is set but " + ("no model_ema object was passed" if model_ema is None
+                                                               else f"{args.resume} holds no 'model_ema' entry"))
+        ema = getattr(model_ema, "ema", getattr(model_ema, "module", model_ema))
+        ema.load_state_dict(ckpt["model_ema"])
+        print("With EMA!")
 
 
 def _parse_meta(meta):

@@ -233,6 +233,6 @@ def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filt
         # the fused kernel is for engine-backed models (flat fp32 parameter / gradient stores); anything else gets torch's AdamW
         inner = getattr(model, "module", model)
         ps = list(model.parameters())
-        fused_ok = hasattr(inner, "engine") and ps and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
+        fused_ok = hasattr(type(inner), "engine") and ps and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
         return FusedAdamW(parameters, **opt_args) if fused_ok else optim.AdamW(parameters, **opt_args)
     raise ValueError(f"Invalid optimizer {args.opt}")

@@ -99,6 +99,21 @@ def test_optimizer_groups_and_checkpoint_layout(tmp_path):
     assert args.start_epoch == 4
     for a, b in zip(model.state_dict().values(), model2.state_dict().values()):
         assert torch.equal(a, b)
+    # model_ema is stored and restored like upstream does (checkpoint.py:113-114,154-156), never dropped silently
+    import copy
+    ema = SimpleNamespace(ema=copy.deepcopy(model))
+    with torch.no_grad():
+        for p in ema.ema.parameters():
+            p.mul_(0.5)
+    save_model(args, 5, model, model, opt, scaler, model_ema=ema)
+    assert "model_ema" in torch.load(tmp_path / "checkpoint-5.pth", weights_only=False)
+    args.resume, args.model_ema = str(tmp_path / "checkpoint-5.pth"), True
+    ema2 = SimpleNamespace(ema=copy.deepcopy(model2))
+    auto_load_model(args, model2, model2, opt2, scaler, model_ema=ema2)
+    for a, b in zip(ema.ema.state_dict().values(), ema2.ema.state_dict().values()):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError, match="model_ema"):
+        auto_load_model(args, model2, model2, opt2, scaler, model_ema=None)
 
 
 def test_c_abi_exports_every_declared_symbol():
