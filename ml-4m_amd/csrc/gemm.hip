@@ -15,6 +15,7 @@
 //   * NT: the reduction dimension K is a multiple of 64 and zero padded (TN masks its reduction rows itself);
 //   * leading dimensions are multiples of 8 elements (16-byte aligned rows).
 #include <type_traits>
+#include <cstdlib>
 #include "common.h"
 #include "fourm_hip.h"
 
@@ -33,6 +34,8 @@ struct NTArgs {
     int n_tiles_w, n_tiles_x;
     int group_w;                                          // grouped: W-tiles per column block
     int prio;                                             // raise the wave priority around the MFMA clusters
+    int abl;                                              // timing ablations (FOURM_NT_ABLATE, tools/gemm_lab): 1 no main-loop DMA,
+                                                          // 4 no epilogue stores, 8 no MFMAs; results are garbage when set
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
@@ -241,15 +244,25 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         if (epi_prefetch) { if (KT > 1) wait_vmcnt<LOADS + EPI_LOADS>(); else wait_vmcnt<EPI_LOADS>(); }
         else { if (KT > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); }
         block_barrier();                                     // tile 0 is in LDS for everyone
-        if (!lead) block_barrier();                          // the trailing row runs one barrier behind
+        if (!lead && !(a.abl & 16)) block_barrier();         // the trailing row runs one barrier behind
         int buf = 0;
+        bf16x8_t wf[KS][FW], xf[KS][FX];
+        if (a.abl & 2) {                                     // ablation: fragments read once, not per K-tile
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < FW; ++i) wf[kk][i] = *(const bf16x8_t*)(smem + (ww * (TW / WW) + frow + i * 32) * RB + kk * 32);
+#pragma unroll
+                for (int j = 0; j < FX; ++j) xf[kk][j] = *(const bf16x8_t*)(smem + TW * RB + (wx * (TX / WX) + frow + j * 32) * RB + kk * 32);
+            }
+        }
         for (int kt = 0; kt < KT; ++kt) {
             const bool more = kt + 2 < KT;
             const int nbuf = buf >= 1 ? buf - 1 : 2;         // (buf + 2) % 3: the buffer tile kt-1 lived in
             // ---- MEM half: every fragment of tile kt ------------------------------------------------
             const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * RB;
             const char* xt = smem + buf * STAGE + TW * RB + (wx * (TX / WX) + frow) * RB;
-            bf16x8_t wf[KS][FW], xf[KS][FX];
+            if (!(a.abl & 2)) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 const int off = ((kk * 2 + fhi) ^ fswz) * 16;
@@ -258,22 +271,25 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
                 for (int j = 0; j < FX; ++j) xf[kk][j] = *(const bf16x8_t*)(xt + j * 32 * RB + off);
             }
+            }
             if (!lead) {                                     // odd slot: the trailing row stages from its MEM half
-                if (more) { stage(kt + 2, nbuf); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
+                if (more) { if (!(a.abl & 1)) stage(kt + 2, nbuf); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
             }
             wait_lgkmcnt<0>();
-            block_barrier();
+            if (!(a.abl & 16)) block_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // ---- MFMA half (the leading row also stages here: same odd slot) -------------------------
             if (a.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
+                if (!(a.abl & 8)) {
 #pragma unroll
                 for (int i = 0; i < FW; ++i)
 #pragma unroll
                     for (int j = 0; j < FX; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
-                if (lead && more) {                          // DMA pieces spread between the MFMA groups
+                } else { acc[0][0][0] += (float)wf[kk][0][0] + (float)xf[kk][0][0]; }
+                if (lead && more && !(a.abl & 1)) {          // DMA pieces spread between the MFMA groups
 #pragma unroll
                     for (int q = kk * PIECES / KS; q < (kk + 1) * PIECES / KS; ++q) {
                         if (q < PW) stage_w(kt + 2, nbuf, q); else stage_x(kt + 2, nbuf, q - PW);
@@ -283,7 +299,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             if (a.prio) __builtin_amdgcn_s_setprio(0);
             if (lead) { if (more) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); }
             __builtin_amdgcn_sched_barrier(0);
-            if (lead || kt + 1 < KT) block_barrier();        // barrier counts: lead 1+2*KT, trailing 2+2*KT-1
+            if ((lead || kt + 1 < KT) && !(a.abl & 16)) block_barrier();        // barrier counts: lead 1+2*KT, trailing 2+2*KT-1
             buf = buf + 1 == STAGES ? 0 : buf + 1;
         }
     } else {
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
     for (int j = 0; j < FX; ++j) {
         const int m = em0 + wx * (TX / WX) + j * 32 + frow;
-        if (m >= a.M) continue;
+        if (m >= a.M || (a.abl & 4)) continue;
         if constexpr (EPI == EPI_SWIGLU) {
             bf16_t* gu = a.out2 ? (bf16_t*)a.out2 + (size_t)m * a.ldo2 : nullptr;      // (g | u) only when a backward will need it
             bf16_t* ao = (bf16_t*)a.out + (size_t)m * a.ldo;
@@ -921,6 +937,8 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     a.M = p->M; a.N = p->N; a.K = p->K; a.ldw = p->ldw; a.ldx = p->ldx; a.ldo = p->ldo; a.ldo2 = p->ldo2; a.ldr = p->ldr; a.Hp = p->Hp;
     a.groups = p->groups; a.tile_group = p->tile_group;
     a.prio = g_nt_prio;
+    static const int abl = [] { const char* e = getenv("FOURM_NT_ABLATE"); return e ? atoi(e) : 0; }();
+    a.abl = abl;
     hipStream_t s = (hipStream_t)stream;
     const int max_n = grouped ? p->max_N : p->N;
     if (grouped) {

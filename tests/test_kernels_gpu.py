@@ -369,7 +369,7 @@ def make_masks(kind, B, Nq, Nk, seed):
                                         ("dense", 200, 100), ("keypad", 70, 50), ("decoder", 96, 96), ("none", 33, 128),
                                         # beyond 256 tokens: whole sequence in LDS (<= 512 rows), then the chunked backward
                                         # (upstream trains 1024 + 1024-token configs; registers push the encoder past 256)
-                                        ("keypad", 260, 260), ("decoder", 512, 384), ("decoder", 1024, 1024), ("keypad", 600, 1030),
+                                        ("keypad", 260, 260), ("decoder", 512, 512), ("dense", 500, 384), ("decoder", 1024, 1024), ("keypad", 600, 1030),
                                         ("dense", 530, 70)])
 def test_attention(kind, Nq, Nk, tr):
     ops, L = _ops()

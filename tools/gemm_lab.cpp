@@ -1,0 +1,126 @@
+// Stand-alone timing of fm_gemm_nt / fm_gemm_tn at the 4M-B shapes (no Python, no torch: a GPU-box call costs seconds).
+//   hipcc --offload-arch=gfx950 -O2 -I include tools/gemm_lab.cpp -L ml-4m_amd/fourm/_lib -lfourm_hip -o tools/bin/gemm_lab
+//   tools/bin/gemm_lab nt <cfg,cfg,...>  |  tools/bin/gemm_lab tn  |  FOURM_NT_ABLATE=1 tools/bin/gemm_lab nt 10
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <string>
+#include "fourm_hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static void* dev_rand_bf16(size_t n, unsigned seed, float scale = 0.5f) {
+    std::vector<uint16_t> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = f2bf(scale * (((s >> 8) & 0xffff) / 32768.0f - 1.0f)); }
+    void* d; CK(hipMalloc(&d, n * 2)); CK(hipMemcpy(d, h.data(), n * 2, hipMemcpyHostToDevice)); return d;
+}
+static void* dev_zero(size_t bytes) { void* d; CK(hipMalloc(&d, bytes)); CK(hipMemset(d, 0, bytes)); return d; }
+
+template <typename F> static double time_us(F fn, int iters = 20, int warm = 3) {
+    for (int i = 0; i < warm; ++i) fn();
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) fn();
+    CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms * 1e3 / iters;
+}
+
+struct NTCase { const char* name; int N, K, epi; };
+
+// the clocks of an idle box ramp up over hundreds of milliseconds: spin a GEMM before the first timing
+static void warm_gpu(int ms_target) {
+    const int R = 8192, N = 2048, K = 2048;
+    void* W = dev_rand_bf16((size_t)N * K, 7), *X = dev_rand_bf16((size_t)R * K, 8), *out = dev_zero((size_t)R * N * 2);
+    fm_gemm_nt_args a{};
+    a.W = W; a.X = X; a.out = out; a.M = R; a.N = N; a.K = K; a.ldw = K; a.ldx = K; a.ldo = N; a.epilogue = FM_EPI_BF16;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms = 0;
+    CK(hipEventRecord(e0, 0));
+    while (ms < ms_target) { for (int i = 0; i < 50; ++i) fm_gemm_nt(&a, 0); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); }
+    CK(hipFree(W)); CK(hipFree(X)); CK(hipFree(out));
+}
+
+int main(int argc, char** argv) {
+    const int R = 256 * 128;
+    std::string mode = argc > 1 ? argv[1] : "nt";
+    warm_gpu(600);
+    if (mode == "nt") {
+        std::vector<int> cfgs;
+        if (argc > 2) { char* t = strtok(argv[2], ","); while (t) { cfgs.push_back(atoi(t)); t = strtok(nullptr, ","); } }
+        else cfgs = {265};
+        NTCase cases[] = {{"qkv      N2304 K768 ", 2304, 768, FM_EPI_BF16}, {"proj/dX  N768  K768 ", 768, 768, FM_EPI_BF16},
+                          {"dX fc2   N2048 K768 ", 2048, 768, FM_EPI_BF16}, {"kv       N1536 K768 ", 1536, 768, FM_EPI_BF16},
+                          {"dX fc13  N768  K4096", 768, 4096, FM_EPI_BF16}, {"dX qkv   N768  K2304", 768, 2304, FM_EPI_BF16},
+                          {"fc2+res  N768  K2048", 768, 2048, FM_EPI_RESIDUAL}, {"proj+res N768  K768 ", 768, 768, FM_EPI_RESIDUAL},
+                          {"swiglu   N2x2048 K768", 2048, 768, FM_EPI_SWIGLU}};
+        double tot[32] = {0};
+        const double per_step[] = {24, 61, 24, 12, 24, 24, 24, 38, 24};       // launches per 4M-B train step (profiles/r01_v10_shape_table.txt)
+        int ci = 0;
+        for (auto& c : cases) {
+            void* W = dev_rand_bf16((size_t)c.N * c.K, 1), *W2 = dev_rand_bf16((size_t)c.N * c.K, 2), *X = dev_rand_bf16((size_t)R * c.K, 3);
+            const bool f32out = c.epi == FM_EPI_RESIDUAL;
+            const int two = c.epi == FM_EPI_SWIGLU ? 2 : 1;
+            void* out = dev_zero((size_t)R * c.N * (f32out ? 4 : 2));
+            void* out2 = c.epi == FM_EPI_SWIGLU ? dev_zero((size_t)R * c.N * 2 * 2) : nullptr;
+            void* res = f32out ? dev_zero((size_t)R * c.N * 4) : nullptr;
+            fm_gemm_nt_args a{};
+            a.W = W; a.W2 = c.epi == FM_EPI_SWIGLU ? W2 : nullptr; a.X = X; a.out = out; a.out2 = out2; a.res = res;
+            a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.ldo2 = 2 * c.N; a.ldr = c.N; a.Hp = c.N; a.epilogue = c.epi;
+            printf("%s |", c.name);
+            std::vector<double> best(cfgs.size(), 1e30);
+            for (int rep = 0; rep < 3; ++rep)                   // interleaved A/B: every configuration sees the same clock history
+                for (size_t k = 0; k < cfgs.size(); ++k) {
+                    fm_set_gemm_nt_config(cfgs[k]);
+                    if (fm_gemm_nt(&a, 0) != 0) { printf(" cfg%d: %s", cfgs[k], fm_last_error()); continue; }
+                    double us = time_us([&] { fm_gemm_nt(&a, 0); }, 20, 2);
+                    if (us < best[k]) best[k] = us;
+                }
+            for (size_t k = 0; k < cfgs.size(); ++k) {
+                printf("  c%d: %7.1f us %5.0f TF", cfgs[k], best[k], 2.0 * R * c.N * c.K * two / best[k] / 1e6);
+                tot[k] += best[k] * per_step[ci];
+            }
+            printf("\n"); fflush(stdout);
+            CK(hipFree(W)); CK(hipFree(W2)); CK(hipFree(X)); CK(hipFree(out)); if (out2) CK(hipFree(out2)); if (res) CK(hipFree(res));
+            ++ci;
+        }
+        printf("sum over a 4M-B step (ms):");
+        for (size_t k = 0; k < cfgs.size(); ++k) printf("  c%d: %.2f", cfgs[k], tot[k] / 1e3);
+        printf("\n");
+    } else if (mode == "tn") {
+        struct { const char* name; int N, K; double per_step; } cases[] = {{"dW fc1/3 N2048 K768 ", 2048, 768, 48}, {"dW proj  N768  K768 ", 768, 768, 50},
+            {"dW qkv   N2304 K768 ", 2304, 768, 24}, {"dW fc2   N768  K2048", 768, 2048, 24}, {"dW kv    N1536 K768 ", 1536, 768, 12}};
+        std::vector<int> cfgs = {1, 0};
+        if (argc > 2) { cfgs.clear(); char* t = strtok(argv[2], ","); while (t) { cfgs.push_back(atoi(t)); t = strtok(nullptr, ","); } }
+        double tot[8] = {0};
+        for (auto& c : cases) {
+            void* A = dev_rand_bf16((size_t)R * c.N, 4), *B = dev_rand_bf16((size_t)R * c.K, 5);
+            void* out = dev_zero((size_t)c.N * c.K * 4);
+            fm_gemm_tn_args a{};
+            a.A = A; a.B = B; a.out = out; a.R = R; a.N = c.N; a.K = c.K; a.lda = c.N; a.ldb = c.K; a.ldo = c.K; a.force_tr = -1;
+            printf("%s |", c.name);
+            std::vector<double> best(cfgs.size(), 1e30);
+            for (int rep = 0; rep < 3; ++rep)
+                for (size_t k = 0; k < cfgs.size(); ++k) {
+                    fm_set_gemm_tn_config(cfgs[k]);
+                    if (fm_gemm_tn(&a, 0) != 0) { printf(" cfg%d: %s", cfgs[k], fm_last_error()); continue; }
+                    double us = time_us([&] { fm_gemm_tn(&a, 0); }, 20, 2);
+                    if (us < best[k]) best[k] = us;
+                }
+            for (size_t k = 0; k < cfgs.size(); ++k) {
+                printf("  c%d: %7.1f us %5.0f TF", cfgs[k], best[k], 2.0 * R * c.N * c.K / best[k] / 1e6);
+                tot[k] += best[k] * c.per_step;
+            }
+            printf("\n"); fflush(stdout);
+            CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(out));
+        }
+        printf("sum over a 4M-B step (ms):");
+        for (size_t k = 0; k < cfgs.size(); ++k) printf("  c%d: %.2f", cfgs[k], tot[k] / 1e3);
+        printf("\n");
+    }
+    return 0;
+}
