@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "fourm", "_lib", "libfourm_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "layernorm.hip", "attention.hip", "select_embed.hip", "loss.hip", "elementwise.hip", "vq.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "gemm_nt_flat.hip", "layernorm.hip", "attention.hip", "select_embed.hip", "loss.hip", "elementwise.hip", "vq.hip"]
 
 
 def hipcc() -> str:
@@ -24,7 +24,7 @@ def up_to_date(srcs) -> bool:
     if not os.path.exists(OUT):
         return False
     t = os.path.getmtime(OUT)
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "fourm_hip.h"), __file__]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(ROOT, "include", "fourm_hip.h"), __file__]
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and os.path.getmtime(o) >= max(
-                os.path.getmtime(s), os.path.getmtime(os.path.join(CSRC, "common.h")),
+                os.path.getmtime(s), os.path.getmtime(os.path.join(CSRC, "common.h")), os.path.getmtime(os.path.join(CSRC, "gemm_args.h")),
                 os.path.getmtime(os.path.join(ROOT, "include", "fourm_hip.h"))):
             continue
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",

@@ -18,28 +18,12 @@
 #include <cstdlib>
 #include "common.h"
 #include "fourm_hip.h"
+#include "gemm_args.h"
 
 namespace {
+using namespace fmk;
 
 constexpr int BK = 64;           // reduction elements per LDS stage
-
-enum { EPI_BF16 = FM_EPI_BF16, EPI_GELU = FM_EPI_GELU, EPI_RES = FM_EPI_RESIDUAL, EPI_SWIGLU = FM_EPI_SWIGLU,
-       EPI_F32 = FM_EPI_F32, EPI_TANH = FM_EPI_TANH, EPI_SWIGLU_BWD = FM_EPI_SWIGLU_BWD, EPI_GELU_BWD = FM_EPI_GELU_BWD };
-
-struct NTArgs {
-    const bf16_t* W; const bf16_t* W2; const bf16_t* X;
-    void* out; void* out2; const float* res; const float* bias; const float* bias2;
-    int M, N, K, ldw, ldx, ldo, ldo2, ldr, Hp;
-    const fm_gemm_group* groups; const int* tile_group;   // grouped mode (may be null)
-    int n_tiles_w, n_tiles_x;
-    int group_w;                                          // grouped: W-tiles per column block
-    int prio;                                             // raise the wave priority around the MFMA clusters
-    int abl;                                              // timing ablations (FOURM_NT_ABLATE, tools/gemm_lab): 1 no main-loop DMA,
-                                                          // 4 no epilogue stores, 8 no MFMAs; results are garbage when set
-};
-
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ------------------------------------------------------------------------------------------------
 // NT kernel
@@ -941,6 +925,11 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     a.abl = abl;
     hipStream_t s = (hipStream_t)stream;
     const int max_n = grouped ? p->max_N : p->N;
+    if (!grouped && g_nt_config == 9) {       // the flattened persistent kernel takes the big dense launches it handles
+        const int r = fm_launch_nt_flat(a, p->epilogue, s);
+        if (r < 0) { fm_set_error("fm_gemm_nt (flat): launch failed"); return -2; }
+        if (r > 0) return 0;
+    }
     if (grouped) {
         FM_CHECK_ARG(p->tile_group && p->max_N > 0, "fm_gemm_nt: grouped mode needs tile_group and max_N");
         FM_CHECK_ARG(p->epilogue == FM_EPI_BF16, "fm_gemm_nt: grouped mode supports FM_EPI_BF16 only");
@@ -969,8 +958,10 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     return -1;
 }
 
+extern int g_nt_flat;
 extern "C" void fm_set_gemm_nt_config(int cfg) {
     g_nt_config = cfg & 0xff; g_nt_prio = (cfg >> 8) & 1;
+    g_nt_flat = ((cfg >> 28) & 1) ? 0 : 1;                                                             // bit 28: tile-at-a-time kernels only
     if ((cfg >> 16) & 0xff) { g_nt_auto[0] = (cfg >> 16) & 0xf; g_nt_auto[1] = (cfg >> 20) & 0xf; }   // bits 16-19 / 20-23: automatic pair
     if ((cfg >> 24) & 0xf) g_nt_swiglu = (cfg >> 24) & 0xf;                                             // bits 24-27: the SwiGLU choice
 }

@@ -1,0 +1,31 @@
+// Argument record and epilogue helpers shared by the NT GEMM kernels (gemm.hip, gemm_nt_flat.hip).
+#pragma once
+#include "common.h"
+#include "fourm_hip.h"
+
+namespace fmk {
+
+enum { EPI_BF16 = FM_EPI_BF16, EPI_GELU = FM_EPI_GELU, EPI_RES = FM_EPI_RESIDUAL, EPI_SWIGLU = FM_EPI_SWIGLU,
+       EPI_F32 = FM_EPI_F32, EPI_TANH = FM_EPI_TANH, EPI_SWIGLU_BWD = FM_EPI_SWIGLU_BWD, EPI_GELU_BWD = FM_EPI_GELU_BWD };
+
+struct NTArgs {
+    const bf16_t* W; const bf16_t* W2; const bf16_t* X;
+    void* out; void* out2; const float* res; const float* bias; const float* bias2;
+    int M, N, K, ldw, ldx, ldo, ldo2, ldr, Hp;
+    const fm_gemm_group* groups; const int* tile_group;   // grouped mode (may be null)
+    int n_tiles_w, n_tiles_x;
+    int group_w;                                          // grouped: W-tiles per column block
+    int prio;                                             // raise the wave priority around the MFMA clusters
+    int abl;                                              // timing ablations (FOURM_NT_ABLATE, tools/gemm_lab): 1 no main-loop DMA,
+                                                          // 4 no epilogue stores, 8 no MFMAs; results are garbage when set
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+
+}  // namespace fmk
+
+// gemm_nt_flat.hip: the flattened persistent kernel.  Returns 1 when it took the launch, 0 when the arguments are outside what it
+// handles (the caller then uses the tile-at-a-time kernels of gemm.hip), < 0 on a launch error.
+int fm_launch_nt_flat(const fmk::NTArgs& a, int epilogue, hipStream_t s);

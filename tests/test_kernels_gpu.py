@@ -66,6 +66,56 @@ def test_gemm_nt_tile_configs(cfg):
         L.lib.fm_set_gemm_nt_config(9 + 256)
 
 
+NT_TILED = 9 + 256 + (1 << 28)       # automatic configuration, tile-at-a-time kernels only (no flattened persistent kernel)
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 768, 768), (6000, 2304, 768), (2048, 128, 512), (4100, 768, 4096), (33000, 1536, 1024)])
+def test_gemm_nt_flat_bit_identical(M, N, K):
+    """The flattened persistent kernel (gemm_nt_flat.hip: one K-tile stream across all tiles of a workgroup, deferred
+    stores) accumulates in the same order as the tile-at-a-time kernels: outputs must be bit-identical, run after run (a race
+    in the staggered LDS ring or a miscounted vmcnt wait would show as rare wrong tiles), and right against fp32."""
+    ops, L = _ops()
+    x = bf(randn(M, K, seed=21) * 0.7)
+    w = bf(randn(N, K, seed=22) * 0.05)
+    L.lib.fm_set_gemm_nt_config(NT_TILED)
+    try:
+        ref = torch.full((M, N), 5.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w, ref)
+    finally:
+        L.lib.fm_set_gemm_nt_config(9 + 256)
+    rows = torch.randperm(M, device=DEV)[:512]
+    assert rel_err(ref[rows], x[rows].float() @ w.float().t()) < 4e-3
+    for rep in range(6):
+        out = torch.full((M, N), -3.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w, out)
+        assert torch.equal(out, ref), (rep, int((out != ref).sum()))
+
+
+@pytest.mark.parametrize("M,H,K,save", [(32768, 2048, 768, True), (5000, 448, 768, True), (4096, 2048, 768, False)])
+def test_gemm_nt_flat_swiglu_bit_identical(M, H, K, save):
+    ops, L = _ops()
+    x, w1, w3 = bf(randn(M, K, seed=23) * 0.7), bf(randn(H, K, seed=24) * 0.05), bf(randn(H, K, seed=25) * 0.05)
+
+    def run():
+        gu = torch.full((M, 2 * H), 3.0, device=DEV, dtype=torch.bfloat16) if save else None
+        act = torch.full((M, H), 3.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w1, act, epilogue=L.EPI_SWIGLU, w2=w3, out2=gu, Hp=H, N=H)
+        return act, gu
+    L.lib.fm_set_gemm_nt_config(NT_TILED)
+    try:
+        act0, gu0 = run()
+    finally:
+        L.lib.fm_set_gemm_nt_config(9 + 256)
+    rows = torch.randperm(M, device=DEV)[:256]
+    g, u = bf(x[rows].float() @ w1.float().t()).float(), bf(x[rows].float() @ w3.float().t()).float()
+    assert rel_err(act0[rows], bf(torch.nn.functional.silu(g)).float() * u) < 8e-3
+    for rep in range(4):
+        act, gu = run()
+        assert torch.equal(act, act0), rep
+        if save:
+            assert torch.equal(gu, gu0), rep
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 260, 192), (1024, 768, 768), (70, 2304, 768)])
 def test_gemm_nt_plain(M, N, K):
     ops, L = _ops()
@@ -394,7 +444,8 @@ def test_attention(kind, Nq, Nk, tr):
     vh = v2.reshape(B, Nk, H, 64).transpose(1, 2).float().requires_grad_(True)
     ref, p = ref_attention(qh, kh, vh, mk["blocked"], scale)
     oh = o.reshape(B, Nq, H, 64).transpose(1, 2).float()
-    assert rel_err(oh, ref) < 8e-3, (kind, tr, rel_err(oh, ref))
+    # (long key sequences: p = 1/Nk in fully blocked rows rounds to bf16 with a systematic 2^-9 relative error)
+    assert rel_err(oh, ref) < (8e-3 if Nk <= 512 else 1.2e-2), (kind, tr, rel_err(oh, ref))
     assert max_err(oh, ref) < 0.06
     # backward (straight-through the rounding points, like autograd upstream)
     do = bf(randn(B * Nq, D, seed=43))
