@@ -270,6 +270,19 @@ int fm_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream);
  * grad_mult: optional device scalar multiplied into the gradient (clipping). */
 int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
              float weight_decay, int64_t step, const void* grad_mult, void* stream);
+/* AdamW on weight MATRICES with their plain bf16 shadow (the W operand of y = x W^T) rewritten in the same streaming pass: the
+ * update already reads and writes every master weight, the bf16 copy costs 2 B/param on top instead of a separate 6 B/param pass.
+ * One launch walks a device table of jobs in tiles of FM_ADAMW_CHUNK (8192) consecutive elements; job i owns tiles
+ * [tile_start_i, tile_start_{i+1}); p, g, m, v: contiguous fp32 (rows, cols); dst_plain (optional): bf16 [r][c], row stride ld_plain.
+ * dst_t / ld_t are reserved (transposed shadows are refreshed by fm_shadow_refresh).  All jobs of a launch share the
+ * hyper-parameters and the step count.  Same arithmetic as fm_adamw. */
+#define FM_ADAMW_CHUNK 8192
+typedef struct fm_adamw_job {
+    void* p; const void* g; void* m; void* v; void* dst_plain; void* dst_t;
+    int32_t rows, cols, ld_plain, ld_t, tile_start, pad_;
+} fm_adamw_job;
+int fm_adamw_shadow(const fm_adamw_job* jobs, int n_jobs, int total_tiles, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, const void* grad_mult, void* stream);
 int fm_sumsq(const void* x, int64_t n, void* out, void* stream);                         /* out[0] += sum x^2 */
 int fm_clip_coef(const void* sumsq, float max_norm, void* norm_out, void* coef_out, void* stream);
 

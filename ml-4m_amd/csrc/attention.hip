@@ -257,12 +257,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // Sequences of up to `chunk` (512) rows sit in LDS whole; longer ones (upstream trains 1024 + 1024 tokens,
 // cfgs/default/4m/models/main/*1024*) are walked in chunks that are re-staged once per round of 4 x 32 owned rows.
 // ------------------------------------------------------------------------------------------------
-template <bool TR, int MASK>
+template <bool TR, int MASK, bool CHUNKED>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
     const int NP = a.chunk;                              // rows per LDS tile
-    const int nQC = (NqP + NP - 1) / NP, nKC = (NkP + NP - 1) / NP;
+    // !CHUNKED (every 4M training configuration up to 512 tokens): one chunk, known at compile time - the loops below fold to the
+    // single-pass kernel, dead waves leave instead of idling through barriers
+    const int nQC = CHUNKED ? (NqP + NP - 1) / NP : 1, nKC = CHUNKED ? (NkP + NP - 1) / NP : 1;
     // Two LDS tiles, used twice: (Q, dO) during pass A, then (K, V) during pass B.  The operand a wave keeps in
     // registers for a whole pass (its K/V block in A, its Q/dO block in B) comes straight from global memory.
     // Half the LDS of holding all four tiles -> twice the resident workgroups: this kernel streams 400 MB per
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
 
     // ---- pass A: dK, dV -------------------------------------------------------------------------
     for (int kb0 = 0; kb0 < nKB; kb0 += 4) {
+        if (!CHUNKED && kb0 + wave >= nKB) break;
         const bool live = kb0 + wave < nKB;              // (a dead wave of the last round still joins the chunk barriers)
         const int kb = live ? kb0 + wave : nKB - 1;
         const int k = kb * 32 + (lane & 31);            // this lane's key
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
 
     // ---- pass B: dQ -----------------------------------------------------------------------------
     for (int qb0 = 0; qb0 < nQB; qb0 += 4) {
+        if (!CHUNKED && qb0 + wave >= nQB) break;
         const bool live = qb0 + wave < nQB;
         const int qb = live ? qb0 + wave : nQB - 1;
         const int q = qb * 32 + (lane & 31);
@@ -593,23 +597,26 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     dim3 grid(a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
 #define BWD(TR, MK)                                                                                                   \
+    if (a.chunk < NPmax) BWD2(TR, MK, true) else BWD2(TR, MK, false)
+#define BWD2(TR, MK, CH)                                                                                              \
     {                                                                                                                 \
-        auto k = attn_bwd_kernel<TR, MK>;                                                                             \
+        auto k = attn_bwd_kernel<TR, MK, CH>;                                                                         \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once;                                                                                                   \
         hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, a);                                          \
     }
 #define BWD_MASK(TR)                                                        \
     switch (a.mask_kind) {                                                  \
-        case FM_MASK_NONE: BWD(TR, FM_MASK_NONE) break;                     \
-        case FM_MASK_KEYPAD: BWD(TR, FM_MASK_KEYPAD) break;                 \
-        case FM_MASK_DECODER: BWD(TR, FM_MASK_DECODER) break;               \
-        case FM_MASK_DENSE: BWD(TR, FM_MASK_DENSE) break;                   \
+        case FM_MASK_NONE: BWD(TR, FM_MASK_NONE); break;                    \
+        case FM_MASK_KEYPAD: BWD(TR, FM_MASK_KEYPAD); break;                \
+        case FM_MASK_DECODER: BWD(TR, FM_MASK_DECODER); break;              \
+        case FM_MASK_DENSE: BWD(TR, FM_MASK_DENSE); break;                  \
         default: fm_set_error("fm_attn_bwd: unknown mask kind %d", a.mask_kind); return -1; \
     }
     if (tr) { BWD_MASK(true) } else { BWD_MASK(false) }
 #undef BWD_MASK
 #undef BWD
+#undef BWD2
     FM_CHECK_LAUNCH("fm_attn_bwd");
     return 0;
 }

@@ -227,6 +227,71 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// AdamW on weight matrices + their plain bf16 shadow in one STREAMING pass: see fm_adamw_shadow in the header.  A "tile" is a run of
+// ADAMW_CHUNK consecutive elements of one matrix (linear in memory: full-width HBM bursts; the 64x64 tile walk of the transposing
+// refresh reaches 0.8 TB/s, this 5 TB/s), the bf16 copy goes to dst_plain[r * ld_plain + c].  Transposed shadows stay with
+// fm_shadow_refresh.  The update is adamw_kernel's, term by term.
+constexpr int ADAMW_CHUNK = 8192;           // elements per tile: 256 threads x 8 quads
+
+__global__ __launch_bounds__(256) void adamw_shadow_kernel(const fm_adamw_job* __restrict__ jobs, int n, int total_tiles, float lr, float beta1,
+                                                           float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                           const float* __restrict__ grad_mult) {
+    const float gm = grad_mult ? grad_mult[0] : 1.0f;
+    const float step = lr / bc1;
+    auto update = [&](float& pe, float& me, float& ve, float ge) {
+        ge *= gm;
+        pe *= 1.0f - lr * wd;
+        me = beta1 * me + (1.0f - beta1) * ge;
+        ve = beta2 * ve + (1.0f - beta2) * ge * ge;
+        pe -= step * me / (sqrtf(ve) / bc2_sqrt + eps);
+    };
+    for (int tt = blockIdx.x; tt < total_tiles; tt += gridDim.x) {
+        int lo = 0, hi = n - 1;                               // last job with tile_start <= tt
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].tile_start <= tt) lo = mid; else hi = mid - 1;
+        }
+        const fm_adamw_job d = jobs[lo];
+        const size_t total = (size_t)d.rows * d.cols;
+        const size_t base = (size_t)(tt - d.tile_start) * ADAMW_CHUNK;
+        float* P = (float*)d.p; const float* G = (const float*)d.g; float* M = (float*)d.m; float* V = (float*)d.v;
+        bf16_t* dst = (bf16_t*)d.dst_plain;
+        const bool vec = (d.cols % 4 == 0) && ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0);
+        const bool vec_dst = dst && ((((uintptr_t)dst) & 7) == 0) && (d.ld_plain % 4 == 0);
+        if (vec) {
+            // two sweeps of 4 quads per thread: all 16 loads of a sweep in flight before the arithmetic
+#pragma unroll
+            for (int sweep = 0; sweep < 2; ++sweep) {
+                float4 Pq[4], Gq[4], Mq[4], Vq[4];
+                size_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = base + ((size_t)(sweep * 4 + i) * 256 + threadIdx.x) * 4;
+                    if (o[i] < total) { Pq[i] = *(const float4*)(P + o[i]); Gq[i] = *(const float4*)(G + o[i]); Mq[i] = *(const float4*)(M + o[i]); Vq[i] = *(const float4*)(V + o[i]); }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (o[i] >= total) continue;
+                    update(Pq[i].x, Mq[i].x, Vq[i].x, Gq[i].x); update(Pq[i].y, Mq[i].y, Vq[i].y, Gq[i].y);
+                    update(Pq[i].z, Mq[i].z, Vq[i].z, Gq[i].z); update(Pq[i].w, Mq[i].w, Vq[i].w, Gq[i].w);
+                    *(float4*)(P + o[i]) = Pq[i]; *(float4*)(M + o[i]) = Mq[i]; *(float4*)(V + o[i]) = Vq[i];
+                    if (dst) {
+                        const size_t r = o[i] / d.cols, c = o[i] % d.cols;       // a quad never straddles rows (cols % 4 == 0)
+                        bf16_t* dp = dst + r * d.ld_plain + c;
+                        if (vec_dst) *(uint2*)dp = make_uint2(pack2bf(Pq[i].x, Pq[i].y), pack2bf(Pq[i].z, Pq[i].w));
+                        else { dp[0] = f2bf(Pq[i].x); dp[1] = f2bf(Pq[i].y); dp[2] = f2bf(Pq[i].z); dp[3] = f2bf(Pq[i].w); }
+                    }
+                }
+            }
+        } else {
+            for (size_t o = base + threadIdx.x; o < min(total, base + ADAMW_CHUNK); o += 256) {
+                update(P[o], M[o], V[o], G[o]);
+                if (dst) dst[(o / d.cols) * d.ld_plain + o % d.cols] = f2bf(P[o]);
+            }
+        }
+    }
+}
+
 // out[0] += sum x^2   (fp32 partials per workgroup, one atomic each)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
     __shared__ float red[4];
@@ -332,6 +397,17 @@ extern "C" int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, flo
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (float*)p, (const float*)g, (float*)m,
                        (float*)v, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult);
     FM_CHECK_LAUNCH("fm_adamw");
+    return 0;
+}
+
+extern "C" int fm_adamw_shadow(const fm_adamw_job* jobs, int n_jobs, int total_tiles, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, const void* grad_mult, void* stream) {
+    FM_CHECK_ARG(jobs && n_jobs > 0 && total_tiles > 0 && step > 0, "fm_adamw_shadow: bad argument");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const int blocks = total_tiles < 8192 ? total_tiles : 8192;
+    hipLaunchKernelGGL(adamw_shadow_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs, total_tiles, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult);
+    FM_CHECK_LAUNCH("fm_adamw_shadow");
     return 0;
 }
 

@@ -228,25 +228,15 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         if (epi_prefetch) { if (KT > 1) wait_vmcnt<LOADS + EPI_LOADS>(); else wait_vmcnt<EPI_LOADS>(); }
         else { if (KT > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); }
         block_barrier();                                     // tile 0 is in LDS for everyone
-        if (!lead && !(a.abl & 16)) block_barrier();         // the trailing row runs one barrier behind
+        if (!lead) block_barrier();                          // the trailing row runs one barrier behind
         int buf = 0;
-        bf16x8_t wf[KS][FW], xf[KS][FX];
-        if (a.abl & 2) {                                     // ablation: fragments read once, not per K-tile
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-#pragma unroll
-                for (int i = 0; i < FW; ++i) wf[kk][i] = *(const bf16x8_t*)(smem + (ww * (TW / WW) + frow + i * 32) * RB + kk * 32);
-#pragma unroll
-                for (int j = 0; j < FX; ++j) xf[kk][j] = *(const bf16x8_t*)(smem + TW * RB + (wx * (TX / WX) + frow + j * 32) * RB + kk * 32);
-            }
-        }
         for (int kt = 0; kt < KT; ++kt) {
             const bool more = kt + 2 < KT;
             const int nbuf = buf >= 1 ? buf - 1 : 2;         // (buf + 2) % 3: the buffer tile kt-1 lived in
             // ---- MEM half: every fragment of tile kt ------------------------------------------------
             const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * RB;
             const char* xt = smem + buf * STAGE + TW * RB + (wx * (TX / WX) + frow) * RB;
-            if (!(a.abl & 2)) {
+            bf16x8_t wf[KS][FW], xf[KS][FX];
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
                 const int off = ((kk * 2 + fhi) ^ fswz) * 16;
@@ -255,25 +245,22 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
                 for (int j = 0; j < FX; ++j) xf[kk][j] = *(const bf16x8_t*)(xt + j * 32 * RB + off);
             }
-            }
             if (!lead) {                                     // odd slot: the trailing row stages from its MEM half
-                if (more) { if (!(a.abl & 1)) stage(kt + 2, nbuf); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
+                if (more) { stage(kt + 2, nbuf); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
             }
             wait_lgkmcnt<0>();
-            if (!(a.abl & 16)) block_barrier();
+            block_barrier();
             __builtin_amdgcn_sched_barrier(0);
             // ---- MFMA half (the leading row also stages here: same odd slot) -------------------------
             if (a.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
-                if (!(a.abl & 8)) {
 #pragma unroll
                 for (int i = 0; i < FW; ++i)
 #pragma unroll
                     for (int j = 0; j < FX; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], xf[kk][j], acc[i][j], 0, 0, 0);
-                } else { acc[0][0][0] += (float)wf[kk][0][0] + (float)xf[kk][0][0]; }
-                if (lead && more && !(a.abl & 1)) {          // DMA pieces spread between the MFMA groups
+                if (lead && more) {                          // DMA pieces spread between the MFMA groups
 #pragma unroll
                     for (int q = kk * PIECES / KS; q < (kk + 1) * PIECES / KS; ++q) {
                         if (q < PW) stage_w(kt + 2, nbuf, q); else stage_x(kt + 2, nbuf, q - PW);
@@ -283,7 +270,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             if (a.prio) __builtin_amdgcn_s_setprio(0);
             if (lead) { if (more) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); }
             __builtin_amdgcn_sched_barrier(0);
-            if ((lead || kt + 1 < KT) && !(a.abl & 16)) block_barrier();        // barrier counts: lead 1+2*KT, trailing 2+2*KT-1
+            if (lead || kt + 1 < KT) block_barrier();        // barrier counts: lead 1+2*KT, trailing 2+2*KT-1
             buf = buf + 1 == STAGES ? 0 : buf + 1;
         }
     } else {
@@ -342,7 +329,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
 #pragma unroll
     for (int j = 0; j < FX; ++j) {
         const int m = em0 + wx * (TX / WX) + j * 32 + frow;
-        if (m >= a.M || (a.abl & 4)) continue;
+        if (m >= a.M) continue;
         if constexpr (EPI == EPI_SWIGLU) {
             bf16_t* gu = a.out2 ? (bf16_t*)a.out2 + (size_t)m * a.ldo2 : nullptr;      // (g | u) only when a backward will need it
             bf16_t* ao = (bf16_t*)a.out + (size_t)m * a.ldo;
@@ -563,7 +550,9 @@ __device__ __forceinline__ s16x4_t tr_read(uint32_t lds_addr) {
 // PP = the ping-pong schedule of gemm_nt_kernel (wave rows one barrier apart; see there) on the TN operands: the
 // fragment addresses of one lane differ between k-steps only by constants (the swizzle key (row & 3) does not
 // change), so a K-tile's 8 * KB/16 transpose reads use immediate offsets on four per-lane base addresses.
-template <bool TR, bool GROUPED, int TA, int TB, int WA, int WB, int KB, int STAGES, bool PP = false>
+// MASKED: reduction rows >= the live row count are fetched from a zero block (grouped segments, R % KB != 0); the unmasked
+// instantiation carries no per-lane select and no extra branch in its DMA path.
+template <bool TR, bool GROUPED, int TA, int TB, int WA, int WB, int KB, int STAGES, bool PP = false, bool MASKED = true>
 __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     constexpr int NWAVES = WA * WB;
     constexpr int RBA = TA * 2, RBB = TB * 2;                         // bytes per LDS tile row
@@ -615,56 +604,40 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     const int t_begin = split * per, t_end = min(nt, t_begin + per);
     if (t_begin >= t_end) return;
 
-    auto stage = [&](int t, int buf) {
+    // piece q of K-tile t (q < PA/NWAVES: A rows, else B rows)
+    auto stage_piece = [&](int t, int buf, int q) {
         char* base = smem + buf * STAGE;
         const int r0 = r_begin + t * KB;
-#pragma unroll
-        for (int p = 0; p < PA / NWAVES; ++p) {
+        if (q < PA / NWAVES) {
             constexpr int LPR = RBA / 16, RPP = 1024 / RBA;        // lanes per row, rows per piece
-            const int piece = p * NWAVES + wave;
+            const int piece = q * NWAVES + wave;
             const int row = piece * RPP + lane / LPR;
             const int lc = (lane % LPR) ^ ((row & 3) << 2);
             int ca = n0 + lc * 8; ca = ca <= a.a_cols - 8 ? ca : a.a_cols - 8;
-            const bf16_t* src = r0 + row < r_lim ? a.A + (size_t)(r0 + row) * a.lda + ca : zsrc;
+            const bf16_t* src = a.A + (size_t)(r0 + row) * a.lda + ca;
+            if constexpr (MASKED) src = r0 + row < r_lim ? src : zsrc;
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + piece * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int p = 0; p < PB / NWAVES; ++p) {
+        } else {
             constexpr int LPR = RBB / 16, RPP = 1024 / RBB;
-            const int piece = p * NWAVES + wave;
+            const int piece = (q - PA / NWAVES) * NWAVES + wave;
             const int row = piece * RPP + lane / LPR;
             const int lc = (lane % LPR) ^ ((row & 3) << 2);
             int cb = k0 + lc * 8; cb = cb <= a.b_cols - 8 ? cb : a.b_cols - 8;
-            const bf16_t* src = r0 + row < r_lim ? a.B + (size_t)(r0 + row) * a.ldb + cb : zsrc;
+            const bf16_t* src = a.B + (size_t)(r0 + row) * a.ldb + cb;
+            if constexpr (MASKED) src = r0 + row < r_lim ? src : zsrc;
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
         }
     };
+    constexpr int NP = PA / NWAVES + PB / NWAVES;
+    auto stage = [&](int t, int buf) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) stage_piece(t, buf, q);
+    };
     // the same pieces, a share of them per call (ping-pong: spread between the MFMA groups of the leading wave row)
     auto stage_part = [&](int t, int buf, int part, int nparts) {
-        char* base = smem + buf * STAGE;
-        const int r0 = r_begin + t * KB;
-        constexpr int NP = PA / NWAVES + PB / NWAVES;
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            if (q < part * NP / nparts || q >= (part + 1) * NP / nparts) continue;
-            if (q < PA / NWAVES) {
-                constexpr int LPR = RBA / 16, RPP = 1024 / RBA;
-                const int piece = q * NWAVES + wave;
-                const int row = piece * RPP + lane / LPR;
-                const int lc = (lane % LPR) ^ ((row & 3) << 2);
-                int ca = n0 + lc * 8; ca = ca <= a.a_cols - 8 ? ca : a.a_cols - 8;
-                const bf16_t* src = r0 + row < r_lim ? a.A + (size_t)(r0 + row) * a.lda + ca : zsrc;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + piece * 1024), 16, 0, 0);
-            } else {
-                constexpr int LPR = RBB / 16, RPP = 1024 / RBB;
-                const int piece = (q - PA / NWAVES) * NWAVES + wave;
-                const int row = piece * RPP + lane / LPR;
-                const int lc = (lane % LPR) ^ ((row & 3) << 2);
-                int cb = k0 + lc * 8; cb = cb <= a.b_cols - 8 ? cb : a.b_cols - 8;
-                const bf16_t* src = r0 + row < r_lim ? a.B + (size_t)(r0 + row) * a.ldb + cb : zsrc;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
-            }
-        }
+        for (int q = 0; q < NP; ++q)
+            if (q >= part * NP / nparts && q < (part + 1) * NP / nparts) stage_piece(t, buf, q);
     };
 
     f32x16_t acc[2][2];
@@ -921,8 +894,6 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     a.M = p->M; a.N = p->N; a.K = p->K; a.ldw = p->ldw; a.ldx = p->ldx; a.ldo = p->ldo; a.ldo2 = p->ldo2; a.ldr = p->ldr; a.Hp = p->Hp;
     a.groups = p->groups; a.tile_group = p->tile_group;
     a.prio = g_nt_prio;
-    static const int abl = [] { const char* e = getenv("FOURM_NT_ABLATE"); return e ? atoi(e) : 0; }();
-    a.abl = abl;
     hipStream_t s = (hipStream_t)stream;
     const int max_n = grouped ? p->max_N : p->N;
     if (!grouped && g_nt_config == 9) {       // the flattened persistent kernel takes the big dense launches it handles
@@ -961,7 +932,7 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
 extern int g_nt_flat;
 extern "C" void fm_set_gemm_nt_config(int cfg) {
     g_nt_config = cfg & 0xff; g_nt_prio = (cfg >> 8) & 1;
-    g_nt_flat = ((cfg >> 28) & 1) ? 0 : 1;                                                             // bit 28: tile-at-a-time kernels only
+    g_nt_flat = (cfg >> 29) & 1;                                                                         // bit 29: flattened persistent kernel (gemm_nt_flat.hip) where it applies
     if ((cfg >> 16) & 0xff) { g_nt_auto[0] = (cfg >> 16) & 0xf; g_nt_auto[1] = (cfg >> 20) & 0xf; }   // bits 16-19 / 20-23: automatic pair
     if ((cfg >> 24) & 0xf) g_nt_swiglu = (cfg >> 24) & 0xf;                                             // bits 24-27: the SwiGLU choice
 }
@@ -1011,18 +982,22 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     const int deal = grouped ? 8 * 4 * a.n_tiles_b : 8;                // grouped: chunks of 4 A-tiles x all B-tiles per XCD
     dim3 grid((total_items + deal - 1) / deal * deal, 1, grouped ? p->n_groups : 1);
     hipStream_t s = (hipStream_t)stream;
+    const bool masked = grouped || p->R % kb != 0;
 #define LAUNCH_TN(TR, G, KBV, PPV)                                                                  \
+    if (masked) LAUNCH_TN2(TR, G, KBV, PPV, true) else LAUNCH_TN2(TR, G, KBV, PPV, false)
+#define LAUNCH_TN2(TR, G, KBV, PPV, MK)                                                             \
     {                                                                                               \
-        auto k = gemm_tn_kernel<TR, G, TN_TA, TN_TB, 2, 4, KBV, TN_STAGES, PPV>;                    \
+        auto k = gemm_tn_kernel<TR, G, TN_TA, TN_TB, 2, 4, KBV, TN_STAGES, PPV, MK>;                \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true); \
         (void)once;                                                                                 \
         hipLaunchKernelGGL(k, grid, dim3(512), lds, s, a);                                          \
     }
     const int tr = p->force_tr >= 0 ? p->force_tr : g_tn_use_tr;
-    if (pp) { if (grouped) LAUNCH_TN(true, true, 64, true) else LAUNCH_TN(true, false, 64, true) }
-    else if (tr) { if (grouped) LAUNCH_TN(true, true, 32, false) else LAUNCH_TN(true, false, 32, false) }
-    else { if (grouped) LAUNCH_TN(false, true, 32, false) else LAUNCH_TN(false, false, 32, false) }
+    if (pp) { if (grouped) { LAUNCH_TN(true, true, 64, true); } else { LAUNCH_TN(true, false, 64, true); } }
+    else if (tr) { if (grouped) { LAUNCH_TN(true, true, 32, false); } else { LAUNCH_TN(true, false, 32, false); } }
+    else { if (grouped) { LAUNCH_TN(false, true, 32, false); } else { LAUNCH_TN(false, false, 32, false); } }
 #undef LAUNCH_TN
+#undef LAUNCH_TN2
     FM_CHECK_LAUNCH("fm_gemm_tn");
     return 0;
 }

@@ -16,8 +16,6 @@ struct NTArgs {
     int n_tiles_w, n_tiles_x;
     int group_w;                                          // grouped: W-tiles per column block
     int prio;                                             // raise the wave priority around the MFMA clusters
-    int abl;                                              // timing ablations (FOURM_NT_ABLATE, tools/gemm_lab): 1 no main-loop DMA,
-                                                          // 4 no epilogue stores, 8 no MFMAs; results are garbage when set
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }

@@ -48,6 +48,7 @@ constexpr uint32_t OOB = 0x80000000u;
 
 template <int TW, int TX, int KB, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_flat_kernel(NTArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)      // (the host pass only needs the stub: the body is all device builtins)
     constexpr int WW = 2, WX = 4, NWAVES = 8, STAGES = 3;
     constexpr int RB = KB * 2, CPR = RB / 16, RPP = 1024 / RB, SWSH = (RB == 128) ? 1 : 2;
     constexpr int PW = TW / (RPP * NWAVES), PX = TX / (RPP * NWAVES), LOADS = PW + PX;
@@ -76,9 +77,14 @@ __global__ __launch_bounds__(512) void gemm_nt_flat_kernel(NTArgs a) {
     const int G = n_my * KT;
     const int N = a.N;
 
-    // ---- the DMA stream: (tile s_j, k-tile s_kt) of stage s_g; per-lane source pointers of the current tile ------------------
-    const bf16_t* wsrc[PW];
-    const bf16_t* xsrc[PX];
+    // ---- the DMA stream: (tile s_j, k-tile s_kt) of stage s_g ---------------------------------------------------------------------
+    // Sources are addressed through buffer descriptors (one for the W rows, one for the X rows of the current tile) with a
+    // per-lane 32-bit byte offset computed once per tile and the k advance in the scalar offset operand: a piece is
+    // `s_mov m0; buffer_load_dwordx4 voff, rsrc, soff offen lds` - no vector address arithmetic in the MFMA half, and half the
+    // address payload of a flat 64-bit load.  (Offsets stay below 2^31: a tile's rows span at most TX * ld * 2 bytes.)
+    uint32_t woff[PW], xoff[PX];
+    __amdgpu_buffer_rsrc_t rs_w = make_rsrc(a.W), rs_w2 = make_rsrc(a.W2 ? a.W2 : a.W), rs_x = make_rsrc(a.X);
+    (void)rs_w2;
     auto tile_origin = [&](int j, int& n0, int& m0) {
         const int tile = xcd_remap((int)blockIdx.x + j * (int)gridDim.x, total);
         n0 = (tile % a.n_tiles_w) * NPT; m0 = (tile / a.n_tiles_w) * TX;      // W tiles fastest: the X tile is shared in L2
@@ -86,35 +92,41 @@ __global__ __launch_bounds__(512) void gemm_nt_flat_kernel(NTArgs a) {
     auto set_sources = [&](int j) {
         int n0, m0;
         tile_origin(j, n0, m0);
+        rs_w = make_rsrc(a.W + (size_t)n0 * a.ldw);
+        if constexpr (EPI == EPI_SWIGLU) rs_w2 = make_rsrc(a.W2 + (size_t)n0 * a.ldw);
+        rs_x = make_rsrc(a.X + (size_t)m0 * a.ldx);
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int t = (p * NWAVES + wave) * RPP + lane / CPR;
             const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
-            if constexpr (EPI == EPI_SWIGLU) {
-                int n = n0 + (t >> 6) * 32 + (t & 31);
-                n = n < N ? n : N - 1;
-                wsrc[p] = (((t >> 5) & 1) ? a.W2 : a.W) + (size_t)n * a.ldw + lc * 8;
-            } else {
-                int n = n0 + t;
-                n = n < N ? n : N - 1;
-                wsrc[p] = a.W + (size_t)n * a.ldw + lc * 8;
-            }
+            int r;                                               // row of this tile's W block
+            if constexpr (EPI == EPI_SWIGLU) r = (t >> 6) * 32 + (t & 31);     // rows [0,32) of a 64-row group: g (W), [32,64): u (W2)
+            else r = t;
+            r = n0 + r < N ? r : N - 1 - n0;
+            woff[p] = (uint32_t)r * (uint32_t)a.ldw * 2u + (uint32_t)lc * 16u;
         }
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             const int t = (p * NWAVES + wave) * RPP + lane / CPR;
             const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
-            int m = m0 + t;
-            m = m < a.M ? m : a.M - 1;
-            xsrc[p] = a.X + (size_t)m * a.ldx + lc * 8;
+            const int r = m0 + t < a.M ? t : a.M - 1 - m0;
+            xoff[p] = (uint32_t)r * (uint32_t)a.ldx * 2u + (uint32_t)lc * 16u;
         }
     };
     int s_g = 0, s_kt = 0, s_j = 0, s_buf = 0;
     auto stage_piece = [&](int q) {            // piece q of stage s_g (q < PW: W rows, else X rows)
-        if (q < PW)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[q < PW ? q : 0] + s_kt * KB), LDS_PTR(smem + s_buf * STAGE + (q * NWAVES + wave) * 1024), 16, 0, 0);
-        else
-            __builtin_amdgcn_global_load_lds(GLB_PTR(xsrc[q >= PW ? q - PW : 0] + s_kt * KB), LDS_PTR(smem + s_buf * STAGE + TW * RB + ((q - PW) * NWAVES + wave) * 1024), 16, 0, 0);
+        const int soff = s_kt * (KB * 2);
+        if (q < PW) {
+            const int pi = q < PW ? q : 0;
+            const int t0 = (pi * NWAVES + wave) * RPP;           // first tile row of the piece (wave uniform): picks W or W2
+            if (EPI == EPI_SWIGLU && ((t0 >> 5) & 1))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, LDS_PTR(smem + s_buf * STAGE + (pi * NWAVES + wave) * 1024), 16, woff[pi], soff, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(smem + s_buf * STAGE + (pi * NWAVES + wave) * 1024), 16, woff[pi], soff, 0, 0);
+        } else {
+            const int pi = q >= PW ? q - PW : 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(smem + s_buf * STAGE + TW * RB + (pi * NWAVES + wave) * 1024), 16, xoff[pi], soff, 0, 0);
+        }
     };
     auto stage_advance = [&]() {               // after the last piece of stage s_g
         ++s_g; ++s_kt;
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(512) void gemm_nt_flat_kernel(NTArgs a) {
     }
     // the last tile's outputs
     for (; pend < NST; ++pend) store_switch(pend);
+#endif
 }
 
 template <int TW, int TX, int KB, int EPI>
@@ -358,7 +371,7 @@ int launch_flat(NTArgs a, hipStream_t s) {
 
 }  // namespace
 
-int g_nt_flat = 1;      // FOURM_NT_FLAT=0 / fm_set_gemm_nt_config(bit 28) selects the tile-at-a-time kernels everywhere (A/B)
+int g_nt_flat = 0;      // experimental (measured equal to the tile-at-a-time kernels, profiles/r02_lab_nt_flat.txt): fm_set_gemm_nt_config bit 29 turns it on
 
 int fm_launch_nt_flat(const fmk::NTArgs& a, int epilogue, hipStream_t s) {
     using namespace fmk;

@@ -77,6 +77,11 @@ class ShadowDesc(C.Structure):
                 ("transpose", i32), ("tile_start", i32)]
 
 
+class AdamWJob(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("dst_plain", vp), ("dst_t", vp),
+                ("rows", i32), ("cols", i32), ("ld_plain", i32), ("ld_t", i32), ("tile_start", i32), ("pad_", i32)]
+
+
 class SelectDesc(C.Structure):
     _fields_ = [("mods", ModDesc * FM_MAX_MODS),
                 ("n_mods", i32), ("batch", i32), ("dim", i32), ("n_keep", i32), ("n_reg", i32), ("total_len", i32),
@@ -128,6 +133,7 @@ headnorm_fwd = _sig("fm_headnorm_fwd", vp, i32, vp, vp, vp, i32, vp, i32, i32, C
 headnorm_bwd = _sig("fm_headnorm_bwd", vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp)
 f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
 adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp)
+adamw_shadow = _sig("fm_adamw_shadow", vp, i32, i32, f32, f32, f32, f32, f32, i64, vp, vp)
 sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
 clip_coef = _sig("fm_clip_coef", vp, f32, vp, vp, vp)
 vq_patchify = _sig("fm_vq_patchify", vp, vp, i32, i32, i32, i32, i32, i32, vp)
@@ -142,7 +148,7 @@ EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_conf
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
-           "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_colsum", "fm_f32_to_bf16", "fm_adamw",
+           "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_colsum", "fm_f32_to_bf16", "fm_adamw", "fm_adamw_shadow",
            "fm_sumsq", "fm_clip_coef", "fm_vq_patchify", "fm_l2norm_rows", "fm_vq_assign"]
 
 

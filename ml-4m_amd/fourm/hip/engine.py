@@ -17,6 +17,7 @@ stream, fp32 master weights and gradients.
 import math
 import os
 import random
+import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -294,6 +295,11 @@ class FourMEngine:
         s = self.shadows.get(key)
         if s is None:
             s = self.shadows[key] = make()
+            for p in s.params:       # FusedAdamW rewrites these copies while it updates the master (fm_adamw_shadow)
+                regs = getattr(p, "_fourm_shadows", None)
+                if regs is None:
+                    regs = p._fourm_shadows = []
+                regs.append((weakref.ref(self), key))
         if s.stamp != self._stamp(s.params):
             self._refresh_shadows()
         return s.buf
@@ -313,6 +319,14 @@ class FourMEngine:
         ops.shadow_refresh(table, n, tiles)
         for s in stale:
             s.stamp = self._stamp(s.params)
+
+    def mark_shadows_fresh(self, keys, written):
+        """Called by FusedAdamW after a fused update: shadow ``key`` is current when every one of its (master, destination)
+        jobs is in ``written`` = {(id(param), destination data_ptr)}."""
+        for key in keys:
+            s = self.shadows.get(key)
+            if s is not None and all((id(p), dst.data_ptr()) in written for (p, dst, _) in s.jobs):
+                s.stamp = self._stamp(s.params)
 
     def w(self, p):
         """(out, in_p) bf16, pad columns zero: the W operand of y = x W^T."""

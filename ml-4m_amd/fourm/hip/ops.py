@@ -284,6 +284,37 @@ def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None):
     L.check(L.adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _stream()))
 
 
+ADAMW_CHUNK = 8192   # FM_ADAMW_CHUNK
+
+
+def adamw_jobs_table(jobs, device):
+    """jobs: list of dicts(p, g, m, v: fp32 tensors of one (rows, cols) matrix; plain / t: bf16 2-D destinations or None)
+    -> (device byte tensor of fm_adamw_job, total tiles)."""
+    arr = (L.AdamWJob * len(jobs))()
+    tiles = 0
+    for i, j in enumerate(jobs):
+        p = j["p"]
+        rows, cols = p.shape[0], p[0].numel()
+        d = arr[i]
+        for k in ("p", "g", "m", "v"):
+            t = j[k]
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == rows * cols, (k, t.dtype, tuple(t.shape))
+            setattr(d, k, t.data_ptr())
+        pl, tr = j.get("plain"), j.get("t")
+        if pl is not None:
+            assert pl.dtype == torch.bfloat16 and pl.stride(1) == 1 and pl.shape[0] >= rows and pl.shape[1] >= cols
+            d.dst_plain, d.ld_plain = pl.data_ptr(), pl.stride(0)
+        assert tr is None, "transposed shadows are refreshed by fm_shadow_refresh"
+        d.rows, d.cols, d.tile_start = rows, cols, tiles
+        tiles += (rows * cols + ADAMW_CHUNK - 1) // ADAMW_CHUNK
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return raw, tiles
+
+
+def adamw_shadow(table, n_jobs, tiles, lr, beta1, beta2, eps, wd, step, grad_mult=None):
+    L.check(L.adamw_shadow(_p(table), n_jobs, tiles, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _stream()))
+
+
 def sumsq(x, out):
     L.check(L.sumsq(_p(x), x.numel(), _p(out), _stream()))
 

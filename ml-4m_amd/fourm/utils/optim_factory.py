@@ -63,6 +63,7 @@ class FusedAdamW(optim.AdamW):
                                     f"{'contiguous' if p.is_contiguous() else 'strided'}, {p.device}); use torch.optim.AdamW")
         self._clip_coef = None        # device scalar set by fused_grad_norm(clip=...)
         self._runs = None
+        self._shadow_tables = {}      # (group index, step) signature -> cached device job table of fm_adamw_shadow
 
     @staticmethod
     def _check_grad(p):
@@ -72,12 +73,73 @@ class FusedAdamW(optim.AdamW):
                             f"{'contiguous' if g.is_contiguous() else 'strided'} on {g.device}; fp32 contiguous expected")
 
     # -- contiguous runs ------------------------------------------------------------------------
-    def _build_runs(self):
+    def _shadowed(self):
+        """Weight matrices whose bf16 GEMM-operand copies (engine shadows) can be rewritten by the update itself:
+        {group index: [(param, plain dst | None, transposed dst | None, [(engine, shadow key)])]}."""
+        out = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                regs = getattr(p, "_fourm_shadows", None)
+                if p.grad is None or not regs or p.dim() < 2:
+                    continue
+                plain = tr = None
+                keys = []
+                for ref, key in regs:
+                    eng = ref()
+                    sh = eng.shadows.get(key) if eng is not None else None
+                    if sh is None:
+                        continue
+                    for (pp, dst, transposed) in sh.jobs:
+                        # (transposed copies keep going through the engine's lazy fm_shadow_refresh: a transposing walk cannot
+                        # stream, and this kernel must)
+                        if pp is p and not transposed and plain is None:
+                            plain = dst; keys.append((eng, key))
+                if plain is not None or tr is not None:
+                    out.setdefault(gi, []).append((p, plain, tr, keys))
+        return out
+
+    def _step_shadowed(self, shadowed):
+        """One fm_adamw_shadow launch per (group, step count): master update + bf16 copies in one pass."""
+        from fourm.hip import ops
+        done, touched, written = set(), [], set()
+        for gi, items in shadowed.items():
+            g = self.param_groups[gi]
+            by_step = {}
+            for it in items:
+                p = it[0]
+                self._check_grad(p)
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous() and st["exp_avg"].dtype == torch.float32):
+                    continue                      # odd state (foreign checkpoint): the plain path handles it
+                st["step"] += 1
+                by_step.setdefault(int(st["step"]), []).append(it)
+                done.add(id(p))
+            for step, its in by_step.items():
+                sig = (gi,) + tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                                     pl.data_ptr() if pl is not None else 0, tr.data_ptr() if tr is not None else 0) for p, pl, tr, _ in its)
+                cached = self._shadow_tables.get(gi)
+                if cached is None or cached[0] != sig:       # rebuilt only when a buffer moved: no per-step host-to-device upload
+                    jobs = [dict(p=p, g=p.grad, m=self.state[p]["exp_avg"], v=self.state[p]["exp_avg_sq"], plain=pl, t=tr) for p, pl, tr, _ in its]
+                    table, tiles = ops.adamw_jobs_table(jobs, its[0][0].device)
+                    cached = self._shadow_tables[gi] = (sig, table, len(jobs), tiles)
+                _, table, n, tiles = cached
+                ops.adamw_shadow(table, n, tiles, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], step, self._clip_coef)
+                for p, pl, tr, keys in its:
+                    touched += keys
+                    for dst in (pl, tr):
+                        if dst is not None:
+                            written.add((id(p), dst.data_ptr()))
+        return done, touched, written
+
+    def _build_runs(self, skip=()):
         """Per group: maximal runs of parameters adjacent in memory (flat parameter store) whose gradients
         are adjacent with the same spacing.  State tensors of a run are carved from one flat buffer."""
         runs = []
         for gi, g in enumerate(self.param_groups):
-            ps = [p for p in g["params"] if p.grad is not None]
+            ps = [p for p in g["params"] if p.grad is not None and id(p) not in skip]
             for p in ps:
                 self._check_grad(p)
             ps.sort(key=lambda p: p.data_ptr())
@@ -163,7 +225,8 @@ class FusedAdamW(optim.AdamW):
     def step(self, closure=None):
         from fourm.hip import engine, ops
         loss = closure() if closure is not None else None
-        for gi, run in self._build_runs():
+        done, touched, written = self._step_shadowed(self._shadowed())
+        for gi, run in self._build_runs(skip=done):
             g = self.param_groups[gi]
             self._init_state(run)
             st0 = self.state[run[0]]
@@ -181,6 +244,8 @@ class FusedAdamW(optim.AdamW):
                       g["weight_decay"], step, self._clip_coef)
         self._clip_coef = None
         engine.bump_weight_epoch()
+        for eng in {id(e): e for e, _ in touched}.values():          # the copies written above are current again
+            eng.mark_shadows_fresh([k for e, k in touched if e is eng], written)
         return loss
 
     def _state_adjacent_all(self, run):

@@ -66,7 +66,8 @@ def test_gemm_nt_tile_configs(cfg):
         L.lib.fm_set_gemm_nt_config(9 + 256)
 
 
-NT_TILED = 9 + 256 + (1 << 28)       # automatic configuration, tile-at-a-time kernels only (no flattened persistent kernel)
+NT_TILED = 9 + 256                   # automatic configuration, tile-at-a-time kernels
+NT_FLAT = 9 + 256 + (1 << 29)        # + the flattened persistent kernel where it applies
 
 
 @pytest.mark.parametrize("M,N,K", [(32768, 768, 768), (6000, 2304, 768), (2048, 128, 512), (4100, 768, 4096), (33000, 1536, 1024)])
@@ -78,17 +79,18 @@ def test_gemm_nt_flat_bit_identical(M, N, K):
     x = bf(randn(M, K, seed=21) * 0.7)
     w = bf(randn(N, K, seed=22) * 0.05)
     L.lib.fm_set_gemm_nt_config(NT_TILED)
-    try:
-        ref = torch.full((M, N), 5.0, device=DEV, dtype=torch.bfloat16)
-        ops.gemm_nt(x, w, ref)
-    finally:
-        L.lib.fm_set_gemm_nt_config(9 + 256)
+    ref = torch.full((M, N), 5.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(x, w, ref)
     rows = torch.randperm(M, device=DEV)[:512]
     assert rel_err(ref[rows], x[rows].float() @ w.float().t()) < 4e-3
-    for rep in range(6):
-        out = torch.full((M, N), -3.0, device=DEV, dtype=torch.bfloat16)
-        ops.gemm_nt(x, w, out)
-        assert torch.equal(out, ref), (rep, int((out != ref).sum()))
+    L.lib.fm_set_gemm_nt_config(NT_FLAT)
+    try:
+        for rep in range(6):
+            out = torch.full((M, N), -3.0, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt(x, w, out)
+            assert torch.equal(out, ref), (rep, int((out != ref).sum()))
+    finally:
+        L.lib.fm_set_gemm_nt_config(NT_TILED)
 
 
 @pytest.mark.parametrize("M,H,K,save", [(32768, 2048, 768, True), (5000, 448, 768, True), (4096, 2048, 768, False)])
@@ -102,18 +104,19 @@ def test_gemm_nt_flat_swiglu_bit_identical(M, H, K, save):
         ops.gemm_nt(x, w1, act, epilogue=L.EPI_SWIGLU, w2=w3, out2=gu, Hp=H, N=H)
         return act, gu
     L.lib.fm_set_gemm_nt_config(NT_TILED)
-    try:
-        act0, gu0 = run()
-    finally:
-        L.lib.fm_set_gemm_nt_config(9 + 256)
+    act0, gu0 = run()
     rows = torch.randperm(M, device=DEV)[:256]
     g, u = bf(x[rows].float() @ w1.float().t()).float(), bf(x[rows].float() @ w3.float().t()).float()
     assert rel_err(act0[rows], bf(torch.nn.functional.silu(g)).float() * u) < 8e-3
-    for rep in range(4):
-        act, gu = run()
-        assert torch.equal(act, act0), rep
-        if save:
-            assert torch.equal(gu, gu0), rep
+    L.lib.fm_set_gemm_nt_config(NT_FLAT)
+    try:
+        for rep in range(4):
+            act, gu = run()
+            assert torch.equal(act, act0), rep
+            if save:
+                assert torch.equal(gu, gu0), rep
+    finally:
+        L.lib.fm_set_gemm_nt_config(NT_TILED)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 260, 192), (1024, 768, 768), (70, 2304, 768)])

@@ -245,3 +245,41 @@ def test_fused_adamw_step_matches_torch():
         assert float((p - q).abs().max()) < 2e-6, n
     sd = opt.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 2.0
+
+
+def test_fused_adamw_rewrites_weight_shadows():
+    """FusedAdamW.step() updates the weight matrices and rewrites their plain bf16 GEMM-operand copies in the same streaming
+    kernel (fm_adamw_shadow): after a step those shadows are marked current AND equal the cast of their fp32 master; the
+    transposed copies (dX operands) are left stale for the engine's single refresh launch at the next forward."""
+    from fourm.utils.optim_factory import FusedAdamW
+    g, case, model = setup("micro_swiglu")
+    md = to_device(case["mod_dict"])
+    opt = FusedAdamW([{"params": [p for n, p in model.named_parameters() if p.dim() > 1], "weight_decay": 0.05},
+                      {"params": [p for n, p in model.named_parameters() if p.dim() <= 1], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.95))
+    eng = model.engine
+
+    def check(only_plain):
+        n = 0
+        for key, sh in eng.shadows.items():
+            plain = all(not t for (_, _, t) in sh.jobs)
+            if only_plain and not plain:
+                assert sh.stamp != eng._stamp(sh.params), key          # stale: refreshed lazily, never used as is
+                continue
+            for (p, dst, transposed) in sh.jobs:
+                want = p.detach().reshape(p.shape[0], -1).to(torch.bfloat16)
+                want = want.t() if transposed else want
+                assert torch.equal(dst[: want.shape[0], : want.shape[1]], want), (key, transposed)
+            assert sh.stamp == eng._stamp(sh.params), key
+            n += 1
+        return n
+    for step in range(2):
+        random.seed(step); loss, _ = model(md, case["N"], case["M"]); loss.backward()
+        assert check(only_plain=False) > 30                            # after a forward every copy is current
+        before = {k: s.buf.clone() for k, s in eng.shadows.items()}
+        opt.step(); opt.zero_grad()
+        torch.cuda.synchronize()
+        assert check(only_plain=True) > 15
+        assert sum(int(not torch.equal(before[k], s.buf)) for k, s in eng.shadows.items()) > 15      # the weights did move
+    random.seed(5); l2, _ = model(md, case["N"], case["M"])
+    assert check(only_plain=False) > 30
+    assert float(l2) < float(loss)                                      # and the forward sees them

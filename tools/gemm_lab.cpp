@@ -91,6 +91,32 @@ int main(int argc, char** argv) {
         printf("sum over a 4M-B step (ms):");
         for (size_t k = 0; k < cfgs.size(); ++k) printf("  c%d: %.2f", cfgs[k], tot[k] / 1e3);
         printf("\n");
+    } else if (mode == "ksweep") {
+        // T(K) = fixed + slope * K at fixed M, N: separates per-tile costs from the main-loop rate
+        std::vector<int> cfgs = {265, 266, 267};
+        if (argc > 2) { cfgs.clear(); char* t = strtok(argv[2], ","); while (t) { cfgs.push_back(atoi(t)); t = strtok(nullptr, ","); } }
+        const int Ks[] = {512, 768, 1536, 3072, 6144};
+        for (int N : {2304, 768}) {
+            void* W = dev_rand_bf16((size_t)N * 6144, 1), *X = dev_rand_bf16((size_t)R * 6144, 3), *out = dev_zero((size_t)R * N * 2);
+            std::vector<std::vector<double>> t(cfgs.size(), std::vector<double>(5, 1e30));
+            for (int rep = 0; rep < 3; ++rep)
+                for (int ki = 0; ki < 5; ++ki)
+                    for (size_t c = 0; c < cfgs.size(); ++c) {
+                        fm_gemm_nt_args a{};
+                        a.W = W; a.X = X; a.out = out; a.M = R; a.N = N; a.K = Ks[ki]; a.ldw = 6144; a.ldx = 6144; a.ldo = N; a.epilogue = FM_EPI_BF16;
+                        fm_set_gemm_nt_config(cfgs[c]);
+                        if (fm_gemm_nt(&a, 0) != 0) { printf("cfg%d: %s\n", cfgs[c], fm_last_error()); continue; }
+                        double us = time_us([&] { fm_gemm_nt(&a, 0); }, 20, 2);
+                        if (us < t[c][ki]) t[c][ki] = us;
+                    }
+            for (size_t c = 0; c < cfgs.size(); ++c) {
+                printf("N=%d c%d:", N, cfgs[c]);
+                for (int ki = 0; ki < 5; ++ki) printf("  K%d: %7.1f us", Ks[ki], t[c][ki]);
+                const double slope = (t[c][4] - t[c][1]) / (Ks[4] - Ks[1]), fixed = t[c][1] - slope * Ks[1];
+                printf(" | fixed %6.1f us, main loop %5.0f TF\n", fixed, 2.0 * R * N / slope / 1e6);
+            }
+            CK(hipFree(W)); CK(hipFree(X)); CK(hipFree(out));
+        }
     } else if (mode == "tn") {
         struct { const char* name; int N, K; double per_step; } cases[] = {{"dW fc1/3 N2048 K768 ", 2048, 768, 48}, {"dW proj  N768  K768 ", 768, 768, 50},
             {"dW qkv   N2304 K768 ", 2304, 768, 24}, {"dW fc2   N768  K2048", 768, 2048, 24}, {"dW kv    N1536 K768 ", 1536, 768, 12}};
