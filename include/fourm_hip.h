@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 1
+#define FM_ABI_VERSION 2
 int fm_abi_version(void);
 const char* fm_last_error(void);
 
@@ -198,6 +198,8 @@ typedef struct fm_select_desc {
     void* patch_rows;   /* bf16 (B*Nt, patch_ld)  optional: pixels of the kept PATCH slots, zero elsewhere  */
     void* seqemb_rows;  /* bf16 (B*Nt, seqemb_ld) optional: embeddings of the kept SEQ_EMB slots            */
     int32_t patch_ld, seqemb_ld;
+    int32_t rows_f32;   /* 1: patch_rows / seqemb_rows are f32 (fp32 verification path)                     */
+    int32_t pad2_;
 } fm_select_desc;
 int fm_select_embed(const fm_select_desc* desc, void* stream);
 
@@ -285,6 +287,40 @@ int fm_adamw_shadow(const fm_adamw_job* jobs, int n_jobs, int total_tiles, float
                     float weight_decay, int64_t step, const void* grad_mult, void* stream);
 int fm_sumsq(const void* x, int64_t n, void* out, void* stream);                         /* out[0] += sum x^2 */
 int fm_clip_coef(const void* sumsq, float max_norm, void* norm_out, void* coef_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp32 VERIFICATION path (csrc/fp32_verify.hip): the floating-point kernels above once more with fp32 activations and weights
+ * and no bf16 rounding, so that the launch sequence of the engine can be checked against the upstream fp32 model at fp32
+ * tolerances.  Plain kernels, not the hot path.  Same conventions; every activation pointer is f32.
+ * ---------------------------------------------------------------------------------------------- */
+/* out[m][n] (+)= sum_k X[m*sxm + k*sxk] * W[n*swn + k*swk]  + epilogue (fm_epilogue without the *_BWD forms; no rounding).
+ * Fully strided operands: NT (sxk = swk = 1), dX = dY W (swn = 1, swk = ldw) and dW = dY^T X (sxm = swn = 1, accumulate = 1)
+ * are one kernel.  Grouped NT: groups + tile_group + seg_rows as in fm_gemm_nt (groups[g].W f32).  Grouped TN: groups[g].out /
+ * .N with seg_start / seg_count (device), max_N = largest group N, n_groups; reduces rows [seg_start[g], + seg_count[g]). */
+typedef struct fm_gemm_f32_args {
+    const void* X; const void* W; const void* W2; void* out; void* out2; const void* res; const void* bias; const void* bias2;
+    int64_t sxm, sxk, swn, swk;
+    int32_t M, N, K, ldo, ldo2, ldr, Hp, epilogue, accumulate, max_N, seg_rows, n_groups;
+    const fm_gemm_group* groups; const int32_t* tile_group; const int32_t* seg_start; const int32_t* seg_count;
+} fm_gemm_f32_args;
+int fm_gemm_f32(const fm_gemm_f32_args* args, void* stream);
+/* fm_attn_args with f32 Q / K / V / O (/ dO, dQ, dK, dV); blocked scores are replaced by -finfo(float32).max; stat_m / stat_l
+ * unused.  The backward ACCUMULATES into dK and dV (the caller zeroes them). */
+int fm_attn_f32_fwd(const fm_attn_args* args, void* stream);
+int fm_attn_f32_bwd(const fm_attn_args* args, void* stream);
+int fm_layernorm_bwd_f32(const void* dy, int lddy, const int32_t* dy_row_map, const void* x, int ldx, const void* w, const void* mean,
+                         const void* rstd, const void* dres, void* dx, int lddx, void* dx2, int lddx2, void* dw, void* db, int R, int D,
+                         void* stream);
+int fm_headnorm_f32_fwd(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, void* stats, int R, int H, float eps, void* stream);
+int fm_headnorm_f32_bwd(const void* dy, int lddy, const void* x, int ldx, const void* w, const void* stats, void* dx, int lddx, void* dw, void* db,
+                        int R, int H, void* stream);
+int fm_swiglu_bwd_f32(const void* da, int ldda, const void* gu, int ldgu, void* dgu, int lddgu, int R, int H, int Hp, void* stream);
+int fm_gelu_bwd_f32(const void* dh, int lddh, const void* pre, int ldp, void* dpre, int lddp, int R, int H, void* stream);
+int fm_colsum_f32(const void* dy, int ldy, void* db, int R, int N, void* stream);
+int fm_cross_entropy_f32(void* logits, int ldl, const int32_t* perm, const int32_t* tile_group, const int64_t* target_ids,
+                         const int32_t* vocab, const int32_t* seg_start, const int32_t* seg_count, const void* grad_scale, int loss_type,
+                         int n_heads, int padded_rows, int max_vocab, void* row_loss, void* row_lse, void* head_loss, void* total_loss,
+                         int write_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * VQ tokenizer front end (fourm/vq/vqvae.py:302-331)

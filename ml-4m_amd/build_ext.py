@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "fourm", "_lib", "libfourm_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "gemm_nt_flat.hip", "layernorm.hip", "attention.hip", "select_embed.hip", "loss.hip", "elementwise.hip", "vq.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "gemm_nt_flat.hip", "layernorm.hip", "attention.hip", "select_embed.hip", "loss.hip", "elementwise.hip", "vq.hip", "fp32_verify.hip"]
 
 
 def hipcc() -> str:

@@ -198,6 +198,57 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     }
 }
 
+// cross-entropy over fp32 logits in the segmented (per-head) row layout of loss.hip: one workgroup per padded row.
+// write_grad == 0: row_loss / row_lse;  write_grad == 1: logits <- d(loss)/d(logits) in place, scaled like ce_bwd_kernel.
+__global__ __launch_bounds__(256) void ce_f32_kernel(float* logits, int ld, const int* perm, const int* tile_group, const long long* target_ids,
+                                                     const int* vocab, const int* seg_count, const float* grad_scale, int loss_type, int n_heads,
+                                                     float* row_loss, float* row_lse, int write_grad, int seg_rows) {
+    __shared__ float red[4];
+    const int pr = blockIdx.x;
+    const int g = tile_group[pr / seg_rows];
+    if (g < 0) return;
+    const int src = perm[pr];
+    const int V = vocab[g];
+    float* row = logits + (size_t)pr * ld;
+    if (src < 0) {                                          // pad row of a live segment
+        if (!write_grad) { if (threadIdx.x == 0) { row_loss[pr] = 0.f; row_lse[pr] = 0.f; } }
+        else for (int c = threadIdx.x; c < V; c += 256) row[c] = 0.f;
+        return;
+    }
+    const int tgt = (int)target_ids[src];
+    if (!write_grad) {
+        float mx = -INFINITY;
+        for (int c = threadIdx.x; c < V; c += 256) mx = fmaxf(mx, row[c]);
+        mx = wave_max(mx);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float s = 0.f;
+        for (int c = threadIdx.x; c < V; c += 256) s += expf(row[c] - mx);
+        s = wave_sum(s);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        const float lse = mx + logf(s);
+        if (threadIdx.x == 0) { row_lse[pr] = lse; row_loss[pr] = lse - row[tgt]; }
+        return;
+    }
+    // d(total)/d(logit) = scale_g * (softmax - onehot); 'mod': scale_g = 1 / (n_heads * count_g); 'token': V_g / sum_h count_h * V_h
+    float coef;
+    if (loss_type == FM_LOSS_MOD) coef = 1.0f / ((float)n_heads * (float)seg_count[g]);
+    else {
+        double tot = 0.0;
+        for (int h = 0; h < n_heads; ++h) tot += (double)seg_count[h] * (double)vocab[h];
+        coef = (float)((double)V / tot);
+    }
+    coef *= grad_scale ? grad_scale[0] : 1.0f;
+    const float lse = row_lse[pr];
+    for (int c = threadIdx.x; c < V; c += 256) row[c] = coef * (expf(row[c] - lse) - (c == tgt ? 1.0f : 0.f));
+}
+
+
 // padded[pr] = src[perm[pr]] (bf16 rows of width D), zero rows where perm < 0
 __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, int lds_, const int32_t* __restrict__ perm,
                                                           bf16_t* __restrict__ dst, int ldd, int Rp, int D) {
@@ -255,5 +306,24 @@ extern "C" int fm_cross_entropy(void* logits, int ldl, const int32_t* perm, cons
                            (const long long*)target_ids, vocab, seg_count, (const float*)grad_scale, loss_type, n_heads, (const float*)row_lse);
     }
     FM_CHECK_LAUNCH("fm_cross_entropy");
+    return 0;
+}
+
+/* fp32 verification path (csrc/fp32_verify.hip): the same segmented cross-entropy over fp32 logits, exact expf / logf */
+extern "C" int fm_cross_entropy_f32(void* logits, int ldl, const int32_t* perm, const int32_t* tile_group, const int64_t* target_ids,
+                                    const int32_t* vocab, const int32_t* seg_start, const int32_t* seg_count, const void* grad_scale,
+                                    int loss_type, int n_heads, int Rp, int max_vocab, void* row_loss, void* row_lse, void* head_loss,
+                                    void* total_loss, int write_grad, void* stream) {
+    FM_CHECK_ARG(logits && perm && tile_group && target_ids && vocab && seg_start && seg_count && row_loss && row_lse && head_loss && total_loss,
+                 "fm_cross_entropy_f32: null pointer");
+    FM_CHECK_ARG(loss_type == FM_LOSS_MOD || loss_type == FM_LOSS_TOKEN, "fm_cross_entropy_f32: invalid loss type %d", loss_type);
+    FM_CHECK_ARG(ldl >= max_vocab, "fm_cross_entropy_f32: ldl=%d too small for vocab %d", ldl, max_vocab);
+    hipLaunchKernelGGL(ce_f32_kernel, dim3(Rp), dim3(256), 0, (hipStream_t)stream, (float*)logits, ldl, perm, tile_group,
+                       (const long long*)target_ids, vocab, seg_count, (const float*)grad_scale, loss_type, n_heads, (float*)row_loss,
+                       (float*)row_lse, write_grad, SEG_ALIGN);
+    if (!write_grad)
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)row_loss, seg_start, seg_count,
+                           vocab, n_heads, loss_type, (float*)head_loss, (float*)total_loss);
+    FM_CHECK_LAUNCH("fm_cross_entropy_f32");
     return 0;
 }

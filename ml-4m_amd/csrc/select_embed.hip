@@ -214,7 +214,21 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
             if (x0_o) *(float4*)(x0_o + c * 4) = make_float4(t.x + e.x, t.y + e.y, t.z + e.z, t.w + e.w);
         }
         // dense side inputs gathered for the projection GEMM (zero rows elsewhere)
-        if (d.patch_rows) {
+        if (d.patch_rows && d.rows_f32) {                // fp32 verification path: the same rows, unrounded
+            float* pr = (float*)d.patch_rows + orow * d.patch_ld;
+            const bool here = (!masked || raw) && md.kind == FM_KIND_PATCH;
+            const int ps = md.patch, C = md.channels, gw = md.grid_w;
+            const float* img = (const float*)md.ids + (size_t)b * md.id_stride;
+            for (int f = lane; f < d.patch_ld; f += 64) {
+                float v = 0.f;
+                if (here && f < ps * ps * C) {
+                    const int gy = j / gw, gx = j % gw, Wd = gw * ps, Hd = (md.L / gw) * ps;
+                    const int c = f % C, px = (f / C) % ps, py = f / (C * ps);
+                    v = img[((size_t)c * Hd + gy * ps + py) * Wd + gx * ps + px];
+                }
+                pr[f] = v;
+            }
+        } else if (d.patch_rows) {
             bf16_t* pr = (bf16_t*)d.patch_rows + orow * d.patch_ld;
             if ((!masked || raw) && md.kind == FM_KIND_PATCH) {
                 // feature f = (py*ps + px)*C + c  <-  img[b][c][gy*ps + py][gx*ps + px]   (encoder_embeddings.py:301)
@@ -234,7 +248,12 @@ __global__ __launch_bounds__(256) void select_embed_kernel(SelArgs A) {
                 for (int f = lane; f < d.patch_ld / 4; f += 64) *(uint2*)(pr + f * 4) = make_uint2(0u, 0u);
             }
         }
-        if (d.seqemb_rows) {
+        if (d.seqemb_rows && d.rows_f32) {
+            float* sr = (float*)d.seqemb_rows + orow * d.seqemb_ld;
+            const bool here = (!masked || raw) && md.kind == FM_KIND_SEQ_EMB;
+            const float* src = (const float*)md.ids + (size_t)b * md.id_stride + (size_t)j * md.orig_dim;
+            for (int f = lane; f < d.seqemb_ld; f += 64) sr[f] = (here && f < md.orig_dim) ? src[f] : 0.f;
+        } else if (d.seqemb_rows) {
             bf16_t* sr = (bf16_t*)d.seqemb_rows + orow * d.seqemb_ld;
             if ((!masked || raw) && md.kind == FM_KIND_SEQ_EMB) {
                 const float* src = (const float*)md.ids + (size_t)b * md.id_stride + (size_t)j * md.orig_dim;

@@ -26,7 +26,7 @@ def _load():
 lib = _load()
 lib.fm_last_error.restype = C.c_char_p
 lib.fm_abi_version.restype = C.c_int
-ABI_VERSION = 1
+ABI_VERSION = 2
 if lib.fm_abi_version() != ABI_VERSION:
     raise FourmHipUnavailable(f"libfourm_hip.so ABI {lib.fm_abi_version()} != expected {ABI_VERSION}; rebuild")
 
@@ -77,6 +77,14 @@ class ShadowDesc(C.Structure):
                 ("transpose", i32), ("tile_start", i32)]
 
 
+class GemmF32Args(C.Structure):
+    _fields_ = [("X", vp), ("W", vp), ("W2", vp), ("out", vp), ("out2", vp), ("res", vp), ("bias", vp), ("bias2", vp),
+                ("sxm", i64), ("sxk", i64), ("swn", i64), ("swk", i64),
+                ("M", i32), ("N", i32), ("K", i32), ("ldo", i32), ("ldo2", i32), ("ldr", i32), ("Hp", i32), ("epilogue", i32),
+                ("accumulate", i32), ("max_N", i32), ("seg_rows", i32), ("n_groups", i32),
+                ("groups", vp), ("tile_group", vp), ("seg_start", vp), ("seg_count", vp)]
+
+
 class AdamWJob(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("dst_plain", vp), ("dst_t", vp),
                 ("rows", i32), ("cols", i32), ("ld_plain", i32), ("ld_t", i32), ("tile_start", i32), ("pad_", i32)]
@@ -89,7 +97,8 @@ class SelectDesc(C.Structure):
                 ("reg_tokens", vp), ("mask_token", vp),
                 ("tokens", vp), ("emb", vp), ("x0", vp), ("out_mask", vp), ("out_mod", vp), ("slot_mod", vp),
                 ("slot_src", vp), ("slot_pos", vp), ("target_ids", vp), ("out_cs", vp), ("out_mod_pre", vp),
-                ("out_mod_index", vp), ("patch_rows", vp), ("seqemb_rows", vp), ("patch_ld", i32), ("seqemb_ld", i32)]
+                ("out_mod_index", vp), ("patch_rows", vp), ("seqemb_rows", vp), ("patch_ld", i32), ("seqemb_ld", i32),
+                ("rows_f32", i32), ("pad2_", i32)]
 
 
 class EmbedBwdMod(C.Structure):
@@ -136,6 +145,17 @@ adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, 
 adamw_shadow = _sig("fm_adamw_shadow", vp, i32, i32, f32, f32, f32, f32, f32, i64, vp, vp)
 sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
 clip_coef = _sig("fm_clip_coef", vp, f32, vp, vp, vp)
+# fp32 verification path
+gemm_f32 = _sig("fm_gemm_f32", P(GemmF32Args), vp)
+attn_f32_fwd = _sig("fm_attn_f32_fwd", P(AttnArgs), vp)
+attn_f32_bwd = _sig("fm_attn_f32_bwd", P(AttnArgs), vp)
+layernorm_bwd_f32 = _sig("fm_layernorm_bwd_f32", vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, vp)
+headnorm_f32_fwd = _sig("fm_headnorm_f32_fwd", vp, i32, vp, vp, vp, i32, vp, i32, i32, C.c_float, vp)
+headnorm_f32_bwd = _sig("fm_headnorm_f32_bwd", vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp)
+swiglu_bwd_f32 = _sig("fm_swiglu_bwd_f32", vp, i32, vp, i32, vp, i32, i32, i32, i32, vp)
+gelu_bwd_f32 = _sig("fm_gelu_bwd_f32", vp, i32, vp, i32, vp, i32, i32, i32, vp)
+colsum_f32 = _sig("fm_colsum_f32", vp, i32, vp, i32, i32, vp)
+cross_entropy_f32 = _sig("fm_cross_entropy_f32", vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp)
 vq_patchify = _sig("fm_vq_patchify", vp, vp, i32, i32, i32, i32, i32, i32, vp)
 l2norm_rows = _sig("fm_l2norm_rows", vp, i32, vp, i32, i32, i32, vp)
 vq_assign = _sig("fm_vq_assign", vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp)
@@ -149,7 +169,9 @@ EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_conf
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
            "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_colsum", "fm_f32_to_bf16", "fm_adamw", "fm_adamw_shadow",
-           "fm_sumsq", "fm_clip_coef", "fm_vq_patchify", "fm_l2norm_rows", "fm_vq_assign"]
+           "fm_sumsq", "fm_clip_coef", "fm_vq_patchify", "fm_l2norm_rows", "fm_vq_assign",
+           "fm_gemm_f32", "fm_attn_f32_fwd", "fm_attn_f32_bwd", "fm_layernorm_bwd_f32", "fm_headnorm_f32_fwd", "fm_headnorm_f32_bwd",
+           "fm_swiglu_bwd_f32", "fm_gelu_bwd_f32", "fm_colsum_f32", "fm_cross_entropy_f32"]
 
 
 def check(rc: int):

@@ -143,6 +143,13 @@ class FourMEngine:
         self.Hp = ru(self.Hd, 64)
         self.scale = 64 ** -0.5
         self.eps = blk.norm1.eps
+        # "bf16" = the hot path (autocast semantics); "fp32" = the verification path (csrc/fp32_verify.hip): fp32 activations and
+        # weights through plain kernels, no rounding anywhere - same launch sequence, checked against the upstream fp32 model
+        prec = getattr(model, "compute_precision", None) or os.environ.get("FOURM_PRECISION", "bf16")
+        if prec not in ("bf16", "fp32"):
+            raise ValueError(f"compute_precision {prec!r}: 'bf16' or 'fp32'")
+        self.fp32 = prec == "fp32"
+        self.adt = torch.float32 if self.fp32 else torch.bfloat16
         self.ws: Optional[Workspace] = None
         self.shadows: Dict[tuple, Shadow] = {}
         self._shadow_table = None
@@ -330,6 +337,8 @@ class FourMEngine:
 
     def w(self, p):
         """(out, in_p) bf16, pad columns zero: the W operand of y = x W^T."""
+        if self.fp32:
+            return p.detach().reshape(p.shape[0], -1)
         def make():
             out_f, in_f = p.shape[0], p[0].numel()
             buf = torch.zeros(out_f, ru(in_f, 64), dtype=torch.bfloat16, device=p.device)
@@ -338,6 +347,8 @@ class FourMEngine:
 
     def wt(self, p):
         """(in, out_p) bf16, pad columns zero: the W operand of dX = dY W."""
+        if self.fp32:
+            return p.detach().reshape(p.shape[0], -1).t()      # strided view: the fp32 GEMM takes any strides
         def make():
             out_f, in_f = p.shape[0], p[0].numel()
             buf = torch.zeros(in_f, ru(out_f, 64), dtype=torch.bfloat16, device=p.device)
@@ -420,11 +431,12 @@ class FourMEngine:
             desc.target_ids, desc.out_cs = out["target_ids"].data_ptr(), out["cs"].data_ptr()
             desc.out_mod_pre, desc.out_mod_index = out["mod_pre"].data_ptr(), out["head_of_row"].data_ptr()
         if patch_ld:
-            out["patch_rows"] = ws.get(prefix + "patch_rows", (Rp, patch_ld), torch.bfloat16)
+            out["patch_rows"] = ws.get(prefix + "patch_rows", (Rp, patch_ld), self.adt)
             desc.patch_rows, desc.patch_ld = out["patch_rows"].data_ptr(), patch_ld
         if seq_ld:
-            out["seqemb_rows"] = ws.get(prefix + "seqemb_rows", (Rp, seq_ld), torch.bfloat16)
+            out["seqemb_rows"] = ws.get(prefix + "seqemb_rows", (Rp, seq_ld), self.adt)
             desc.seqemb_rows, desc.seqemb_ld = out["seqemb_rows"].data_ptr(), seq_ld
+        desc.rows_f32 = 1 if self.fp32 else 0
         L.check(L.select_embed(ops.C.byref(desc), ops._stream()))
         out["_keep"] = keep
         # dense projections of pixel / embedding modalities, added onto the (zero) token rows
@@ -459,7 +471,7 @@ class FourMEngine:
         return t
 
     def _mlp_fwd(self, mlp, h, x_res, x_out, R, Rp, sv, tag):
-        bf = torch.bfloat16
+        bf = self.adt
         if self.gated:
             gu = self._buf(sv, tag, "gu", (Rp, 2 * self.Hp), bf) if sv is not None else None       # inference: nothing to save
             act = self._buf(sv, tag, "act", (Rp, self.Hp), bf)
@@ -473,7 +485,7 @@ class FourMEngine:
 
     def _qk_norm_fwd(self, attn, q, k, Rq, Rk, Rqp, Rkp, sv, tag, key):
         """q_norm / k_norm of NormAttention / NormCrossAttention: bf16 q, k -> normalised bf16 copies + (mean, rstd)."""
-        bf, f32, D, H = torch.bfloat16, torch.float32, self.D, self.H
+        bf, f32, D, H = self.adt, torch.float32, self.D, self.H
         qn = self._buf(sv, tag, key + ".q", (Rqp, D), bf)
         kn = self._buf(sv, tag, key + ".k", (Rkp, D), bf)
         sq = self._buf(sv, tag, key + ".sq", (Rqp * H, 2), f32)
@@ -489,7 +501,7 @@ class FourMEngine:
             ops.headnorm_bwd(d_n, x, norm.weight, st, d_x, self._g(norm.weight), db, R, self.H)
 
     def _self_attn_fwd(self, attn, h, x_res, x_out, B, N, R, Rp, mask, sv, tag):
-        bf, D = torch.bfloat16, self.D
+        bf, D = self.adt, self.D
         qkv = self._buf(sv, tag, "qkv", (Rp, 3 * D), bf)
         o = self._buf(sv, tag, "o", (Rp, D), bf)
         ops.gemm_nt(h, self.w(attn.qkv.weight), qkv, bias=attn.qkv.bias, M=R, N=3 * D, K=D)
@@ -504,7 +516,7 @@ class FourMEngine:
         ops.gemm_nt(o, self.w(attn.proj.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=attn.proj.bias, M=R, N=D, K=D)
 
     def _cross_attn_fwd(self, attn, hq, hc, x_res, x_out, B, M, N, Rq, Rqp, Rc, Rcp, mask, sv, tag):
-        bf, D = torch.bfloat16, self.D
+        bf, D = self.adt, self.D
         q = self._buf(sv, tag, "q", (Rqp, D), bf)
         kv = self._buf(sv, tag, "kv", (Rcp, 2 * D), bf)
         o = self._buf(sv, tag, "o2", (Rqp, D), bf)
@@ -523,7 +535,7 @@ class FourMEngine:
     def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag):
         """x_in (Rp, D) f32 -> new (Rp, D) f32 buffer.  [upstream Block.forward, fm_utils.py:331-334]"""
         R, Rp, D = B * N, x_in.shape[0], self.D
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = self.adt, torch.float32
         h1 = self._ln(blk.norm1, x_in, self._buf(sv, tag, "h1", (Rp, D), bf), R, sv, "n1", tag)
         x_mid = self._buf(sv, tag, "x_mid", (Rp, D), f32)
         self._self_attn_fwd(blk.attn, h1, x_in, x_mid, B, N, R, Rp, mask, sv, tag)
@@ -537,7 +549,7 @@ class FourMEngine:
     def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag):
         """[upstream DecoderBlock.forward, fm_utils.py:362-366]"""
         Rq, Rqp, Rc, Rcp, D = B * M, y_in.shape[0], B * N, ctx.shape[0], self.D
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = self.adt, torch.float32
         h1 = self._ln(blk.norm1, y_in, self._buf(sv, tag, "h1", (Rqp, D), bf), Rq, sv, "n1", tag)
         y1 = self._buf(sv, tag, "y1", (Rqp, D), f32)
         self._self_attn_fwd(blk.self_attn, h1, y_in, y1, B, M, Rq, Rqp, sa_mask, sv, tag)
@@ -583,7 +595,7 @@ class FourMEngine:
                 st["enc_layers"].append(sv)
         R, Rp, D = B * N, x.shape[0], self.D
         sv_top = {} if save else None
-        xn = self._ln(m.encoder_norm, x, self._buf(sv_top, "top", "xn", (Rp, D), torch.bfloat16), R, sv_top, "en", "top")
+        xn = self._ln(m.encoder_norm, x, self._buf(sv_top, "top", "xn", (Rp, D), self.adt), R, sv_top, "en", "top")
         ctx = self._buf(sv_top, "top", "ctx", (Rp, D), torch.float32)
         pc = m.decoder_proj_context
         ops.gemm_nt(xn, self.w(pc.weight), ctx, epilogue=L.EPI_RESIDUAL, res=enc["emb"], bias=pc.bias, M=R, N=D, K=D)
@@ -613,7 +625,7 @@ class FourMEngine:
         hs["tile_group"] = ws.get("heads.tile_group", (Rp // ops.SEG,), i32)
         ops.segment_rows(dec["head_of_row"].view(-1), nH, hs["seg_start"], hs["seg_count"], hs["perm"], hs["r2p"], hs["tile_group"])
         sv = {} if save else None
-        yp = ws.get("heads.yp", (Rp, D), torch.bfloat16)
+        yp = ws.get("heads.yp", (Rp, D), self.adt)
         # decoder_norm writes straight into the segmented layout; pad rows are cleared first
         yp.zero_()
         self._ln(m.decoder_norm, y_final, yp, R, sv, "dn", "heads", row_map=hs["r2p"])
@@ -626,11 +638,15 @@ class FourMEngine:
         cache = getattr(self, "_head_groups", None)
         if cache is None or cache[0] != key:       # device tables of raw pointers: rebuilt only when a buffer moved
             fwd = ops.make_groups([dict(W=t, N=v, K=D, ldw=D) for t, v in zip(w_fwd, vocabs)], dev)
-            bwd = ops.make_groups([dict(W=t, N=D, K=ru(v, 64), ldw=ru(v, 64)) for t, v in zip(w_bwd, vocabs)], dev) if save else None
+            if self.fp32:     # dY = d(logits) W reads the (V, D) master through strides: n = d (stride 1), k = v (stride D)
+                bwd = ops.make_groups([dict(W=m.decoder_embeddings[h].to_logits.weight, N=D, K=v, ldw=D, transposed=1)
+                                       for h, v in zip(heads, vocabs)], dev) if save else None
+            else:
+                bwd = ops.make_groups([dict(W=t, N=D, K=ru(v, 64), ldw=ru(v, 64)) for t, v in zip(w_bwd, vocabs)], dev) if save else None
             vt = torch.tensor(vocabs, dtype=i32, device=dev)
             self._head_groups = cache = (key, fwd, bwd, vt)
         hs["g_fwd"], hs["g_bwd"], hs["vocab_t"] = cache[1], cache[2], cache[3]
-        logits = ws.get("heads.logits", (Rp, ldl), torch.bfloat16)
+        logits = ws.get("heads.logits", (Rp, ldl), self.adt)
         ops.gemm_nt_grouped(yp, hs["g_fwd"], hs["tile_group"], logits, hs["maxV"], max_K=D)
         hs.update(yp=yp, logits=logits, sv=sv)
         hs["row_loss"] = ws.get("heads.row_loss", (Rp,), torch.float32)
@@ -692,7 +708,7 @@ class FourMEngine:
 
     def _mlp_bwd(self, mlp, sv, g_bf, R, Rp):
         """In: g_bf = d(out) bf16.  Out: dh (bf16 scratch) = gradient w.r.t. the norm2 output."""
-        bf, D, Hp, Hd = torch.bfloat16, self.D, self.Hp, self.Hd
+        bf, D, Hp, Hd = self.adt, self.D, self.Hp, self.Hd
         R64 = R           # the TN kernel masks the reduction past the live rows itself (no reliance on zeroed padding)
         ws = self.ws
         self._dW(g_bf, sv["act"], mlp.fc2, R64)
@@ -712,7 +728,11 @@ class FourMEngine:
                 ops.swiglu_bwd(da, sv["gu"], dgu, Hd, Hp, R=R)
             self._dW(dgu[:, :Hp], sv["h2"], mlp.fc1, R64, n_cols=Hd)
             self._dW(dgu[:, Hp:], sv["h2"], mlp.fc3, R64, n_cols=Hd)
-            ops.gemm_nt(dgu, self.w13t(mlp), dh, M=R, N=D, K=2 * Hp)
+            if self.fp32:     # d(h2) = dg fc1 + du fc3, straight from the two masters
+                ops.gemm_nt(dgu[:, :Hp], self.wt(mlp.fc1.weight), dh, M=R, N=D, K=Hd)
+                ops.gemm_nt(dgu[:, Hp:], self.wt(mlp.fc3.weight), dh, M=R, N=D, K=Hd, epilogue=L.EPI_F32, res=dh)
+            else:
+                ops.gemm_nt(dgu, self.w13t(mlp), dh, M=R, N=D, K=2 * Hp)
         else:
             dpre = ws.get("bwd.dpre", (Rp, Hp), bf)
             if fuse:
@@ -724,7 +744,7 @@ class FourMEngine:
         return dh
 
     def _self_attn_bwd(self, attn, sv, g_bf, B, N, R, Rp, mask):
-        bf, D = torch.bfloat16, self.D
+        bf, D = self.adt, self.D
         R64, ws = R, self.ws
         self._dW(g_bf, sv["o"], attn.proj, R64)
         do = ws.get("bwd.do", (Rp, D), bf)
@@ -752,7 +772,7 @@ class FourMEngine:
         self._ln_bwd(blk.norm1, dh, sv["x_in"], sv, "n1", g, g_bf, R, dres=g)
 
     def decoder_block_bwd(self, blk, sv, g, g_bf, dctx, dctx_bf, ctx, B, M, N, sa_mask, xa_mask):
-        bf, D = torch.bfloat16, self.D
+        bf, D = self.adt, self.D
         Rq, Rqp, Rc, Rcp = B * M, g.shape[0], B * N, ctx.shape[0]
         ws = self.ws
         dh = self._mlp_bwd(blk.mlp, sv, g_bf, Rq, Rqp)
@@ -835,7 +855,7 @@ class FourMEngine:
         m, ws = self.model, self.ws
         enc, dec, st, hs = c["enc"], c["dec"], c["st"], c["hs"]
         B, N, Mt, D = enc["B"], enc["Nt"], dec["Nt"], self.D
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = self.adt, torch.float32
         Rq, Rc = B * Mt, B * N
         Rqp, Rcp = st["y_final"].shape[0], st["x_final"].shape[0]
         # ---- heads: d(logits) in place, then dY (grouped NT) and dW_head (grouped TN) -----------------

@@ -61,7 +61,10 @@ def _ld(t: torch.Tensor) -> int:
 # GEMM
 # ---------------------------------------------------------------------------------------------
 def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bias2=None, out2=None, Hp=0, N=None, K=None, M=None):
-    """out[m][n] = sum_k x[m][k] w[n][k] (+ epilogue).  x: bf16 (M, >=K); w: bf16 (N, >=K)."""
+    """out[m][n] = sum_k x[m][k] w[n][k] (+ epilogue).  x: bf16 (M, >=K); w: bf16 (N, >=K).
+    fp32 operands select the verification kernel (any strides for w)."""
+    if x.dtype == torch.float32:
+        return _gemm_f32(x, w, out, epilogue=epilogue, bias=bias, res=res, w2=w2, bias2=bias2, out2=out2, Hp=Hp, N=N, K=K, M=M)
     a = L.GemmNTArgs()
     a.W, a.W2, a.X, a.out, a.out2 = _p(w), _p(w2), _p(x), _p(out), _p(out2)
     a.res, a.bias, a.bias2 = _p(res), _p(bias), _p(bias2)
@@ -80,7 +83,31 @@ def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bia
     return out
 
 
+def _gemm_f32(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bias2=None, out2=None, Hp=0, N=None, K=None, M=None,
+              accumulate=False):
+    assert w.dtype == torch.float32 and out.dtype == torch.float32 and x.stride(1) == 1 and out.stride(1) == 1
+    a = L.GemmF32Args()
+    a.X, a.W, a.W2, a.out, a.out2, a.res, a.bias, a.bias2 = _p(x), _p(w), _p(w2), _p(out), _p(out2), _p(res), _p(bias), _p(bias2)
+    a.M = x.shape[0] if M is None else M
+    a.N = w.shape[0] if N is None else N
+    a.K = min(w.shape[1] if K is None else K, w.shape[1])          # padded reduction widths (Hp) stop at the weight's own width
+    a.sxm, a.sxk, a.swn, a.swk = x.stride(0), 1, w.stride(0), w.stride(1)
+    if w2 is not None:
+        assert w2.stride() == w.stride()
+    a.ldo, a.ldo2, a.ldr = out.stride(0), out2.stride(0) if out2 is not None else 0, res.stride(0) if res is not None else 0
+    a.Hp, a.epilogue, a.accumulate = Hp, epilogue, 1 if accumulate else 0
+    L.check(L.gemm_f32(C.byref(a), _stream()))
+    return out
+
+
 def gemm_nt_grouped(x, groups, tile_group, out, max_N, M=None, max_K=0):
+    if x.dtype == torch.float32:
+        a = L.GemmF32Args()
+        a.X, a.out, a.groups, a.tile_group = _p(x), _p(out), _p(groups), _p(tile_group)
+        a.M, a.N, a.max_N, a.seg_rows = (x.shape[0] if M is None else M), max_N, max_N, SEG
+        a.sxm, a.sxk, a.ldo, a.epilogue = x.stride(0), 1, out.stride(0), L.EPI_BF16
+        L.check(L.gemm_f32(C.byref(a), _stream()))
+        return out
     a = L.GemmNTArgs()
     a.X, a.out = _p(x), _p(out)
     a.M = x.shape[0] if M is None else M
@@ -94,6 +121,16 @@ def gemm_nt_grouped(x, groups, tile_group, out, max_N, M=None, max_K=0):
 
 def gemm_tn(a_mat, b_mat, out, *, N=None, K=None, R=None, splits=0, force_tr=-1, a_cols=0, b_cols=0):
     """out[n][k] += sum_r a[r][n] b[r][k]; out fp32 (N, >=K)."""
+    if a_mat.dtype == torch.float32:        # verification kernel: X := a^T, W := b^T through strides, accumulate
+        g = L.GemmF32Args()
+        g.X, g.W, g.out = _p(a_mat), _p(b_mat), _p(out)
+        g.M = a_mat.shape[1] if N is None else N
+        g.N = b_mat.shape[1] if K is None else K
+        g.K = a_mat.shape[0] if R is None else R
+        g.sxm, g.sxk, g.swn, g.swk = 1, a_mat.stride(0), 1, b_mat.stride(0)
+        g.ldo, g.epilogue, g.accumulate = _ld(out), L.EPI_BF16, 1
+        L.check(L.gemm_f32(C.byref(g), _stream()))
+        return out
     a = L.GemmTNArgs()
     a.A, a.B, a.out = _p(a_mat), _p(b_mat), _p(out)
     a.R = a_mat.shape[0] if R is None else R
@@ -109,6 +146,14 @@ def gemm_tn(a_mat, b_mat, out, *, N=None, K=None, R=None, splits=0, force_tr=-1,
 
 
 def gemm_tn_grouped(a_mat, b_mat, groups, seg_start, seg_count, n_groups, max_N, max_R, K, *, splits=0, force_tr=-1):
+    if a_mat.dtype == torch.float32:
+        g = L.GemmF32Args()
+        g.X, g.W, g.groups, g.seg_start, g.seg_count = _p(a_mat), _p(b_mat), _p(groups), _p(seg_start), _p(seg_count)
+        g.N, g.max_N, g.n_groups = K, max_N, n_groups
+        g.sxm, g.sxk, g.swn, g.swk = 1, a_mat.stride(0), 1, b_mat.stride(0)
+        g.ldo, g.epilogue, g.accumulate = K, L.EPI_BF16, 1
+        L.check(L.gemm_f32(C.byref(g), _stream()))
+        return
     a = L.GemmTNArgs()
     a.A, a.B = _p(a_mat), _p(b_mat)
     a.K = K
@@ -127,6 +172,7 @@ def make_groups(entries, device):
         arr[i].W = e["W"].data_ptr() if e.get("W") is not None else None
         arr[i].out = e["out"].data_ptr() if e.get("out") is not None else None
         arr[i].N, arr[i].K, arr[i].ldw = e["N"], e.get("K", 0), e.get("ldw", 0)
+        arr[i].pad_ = e.get("transposed", 0)         # fp32 path: W is read as W[k][n] (stride ldw along k)
     host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
     return host.to(device)
 
@@ -153,6 +199,10 @@ def layernorm_bwd(dy, x, w, mean, rstd, dx, *, dres=None, dx_bf16=None, dw=None,
 
 
 def _ln_bwd(dy, x, w, mean, rstd, dx, dres, dx_bf16, dw, db, dy_row_map, R):
+    if dy.dtype == torch.float32:
+        L.check(L.layernorm_bwd_f32(_p(dy), _ld(dy), _p(dy_row_map), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _ld(dx),
+                                    _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0, _p(dw), _p(db), R, w.numel(), _stream()))
+        return dx
     L.check(L.layernorm_bwd(_p(dy), _ld(dy), _p(dy_row_map), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _ld(dx),
                             _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0, _p(dw), _p(db), R, w.numel(), _stream()))
     return dx
@@ -160,10 +210,14 @@ def _ln_bwd(dy, x, w, mean, rstd, dx, dres, dx_bf16, dw, db, dy_row_map, R):
 
 def headnorm_fwd(x, w, b, y, stats, R, H, eps):
     """Per-head (64 features) LayerNorm of the q / k column block ``x`` -> ``y`` (both bf16 2-D views)."""
+    if x.dtype == torch.float32:
+        return L.check(L.headnorm_f32_fwd(_p(x), _ld(x), _p(w), _p(b), _p(y), _ld(y), _p(stats), R, H, eps, _stream()))
     L.check(L.headnorm_fwd(_p(x), _ld(x), _p(w), _p(b), _p(y), _ld(y), _p(stats), R, H, eps, _stream()))
 
 
 def headnorm_bwd(dy, x, w, stats, dx, dw, db, R, H):
+    if x.dtype == torch.float32:
+        return L.check(L.headnorm_f32_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(stats), _p(dx), _ld(dx), _p(dw), _p(db), R, H, _stream()))
     L.check(L.headnorm_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(stats), _p(dx), _ld(dx), _p(dw), _p(db), R, H, _stream()))
 
 
@@ -186,6 +240,9 @@ def attn_fwd(q, k, v, o, B, H, Nq, Nk, scale, *, mask_kind=L.MASK_NONE, kpad=Non
              causal=False, stat_m=None, stat_l=None, force_tr=-1):
     """q/k/v/o: 2-D bf16 views whose row t of sample b is row b*N + t; head h occupies columns [64h, 64h+64)."""
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
+    if q.dtype == torch.float32:
+        L.check(L.attn_f32_fwd(C.byref(a), _stream()))
+        return o
     with _prof("attn_fwd", 4.0 * B * H * Nq * Nk * 64):
         L.check(L.attn_fwd(C.byref(a), _stream()))
     return o
@@ -196,6 +253,10 @@ def attn_bwd(q, k, v, o, do, dq, dk, dv, B, H, Nq, Nk, scale, stat_m, stat_l, *,
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
     a.dO, a.dQ, a.dK, a.dV = _p(do), _p(dq), _p(dk), _p(dv)
     a.lddo, a.lddq, a.lddk, a.lddv = do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
+    if q.dtype == torch.float32:
+        dk.zero_(); dv.zero_()                      # the verification kernel accumulates dK / dV with atomics
+        L.check(L.attn_f32_bwd(C.byref(a), _stream()))
+        return
     with _prof("attn_bwd", 10.0 * B * H * Nq * Nk * 64):
         L.check(L.attn_bwd(C.byref(a), _stream()))
 
@@ -219,7 +280,8 @@ def gather_rows(src, perm, dst, D):
 def cross_entropy(logits, perm, tile_group, target_ids, vocab, seg_start, seg_count, n_heads, max_vocab, row_loss, row_lse, head_loss,
                   total_loss, *, loss_type=L.LOSS_MOD, grad_scale=None, write_grad=False):
     """write_grad=False: forward (losses + row_lse); write_grad=True: in-place d(logits) from the saved row_lse."""
-    L.check(L.cross_entropy(_p(logits), _ld(logits), _p(perm), _p(tile_group), _p(target_ids), _p(vocab), _p(seg_start),
+    fn = L.cross_entropy_f32 if logits.dtype == torch.float32 else L.cross_entropy
+    L.check(fn(_p(logits), _ld(logits), _p(perm), _p(tile_group), _p(target_ids), _p(vocab), _p(seg_start),
                             _p(seg_count), _p(grad_scale), loss_type, n_heads, perm.numel(), max_vocab, _p(row_loss), _p(row_lse),
                             _p(head_loss), _p(total_loss), 1 if write_grad else 0, _stream()))
 
@@ -228,10 +290,14 @@ def cross_entropy(logits, perm, tile_group, target_ids, vocab, seg_start, seg_co
 # element-wise
 # ---------------------------------------------------------------------------------------------
 def swiglu_bwd(da, gu, dgu, H, Hp, R=None):
+    if da.dtype == torch.float32:
+        return L.check(L.swiglu_bwd_f32(_p(da), _ld(da), _p(gu), _ld(gu), _p(dgu), _ld(dgu), da.shape[0] if R is None else R, H, Hp, _stream()))
     L.check(L.swiglu_bwd(_p(da), _ld(da), _p(gu), _ld(gu), _p(dgu), _ld(dgu), da.shape[0] if R is None else R, H, Hp, _stream()))
 
 
 def gelu_bwd(dh, pre, dpre, H, Hp, R=None):
+    if dh.dtype == torch.float32:
+        return L.check(L.gelu_bwd_f32(_p(dh), _ld(dh), _p(pre), _ld(pre), _p(dpre), _ld(dpre), dh.shape[0] if R is None else R, H, _stream()))
     L.check(L.gelu_bwd(_p(dh), _ld(dh), _p(pre), _ld(pre), _p(dpre), _ld(dpre), dh.shape[0] if R is None else R, H, Hp, _stream()))
 
 
@@ -272,10 +338,14 @@ def shadow_refresh(table, n_jobs, tiles):
 
 
 def colsum(dy, db, N, R=None):
+    if dy.dtype == torch.float32:
+        return L.check(L.colsum_f32(_p(dy), _ld(dy), _p(db), dy.shape[0] if R is None else R, N, _stream()))
     L.check(L.colsum(_p(dy), _ld(dy), _p(db), dy.shape[0] if R is None else R, N, _stream()))
 
 
 def f32_to_bf16(src, dst):
+    if dst.dtype == torch.float32:
+        return dst.copy_(src)
     L.check(L.f32_to_bf16(_p(src), _p(dst), src.numel(), _stream()))
     return dst
 

@@ -83,6 +83,9 @@ class FourM(nn.Module):
         self.init_std = 0.02
         self.use_act_checkpoint = use_act_checkpoint
         self.num_register_tokens = num_register_tokens
+        # "bf16": the hot path (upstream's autocast arithmetic); "fp32": verification kernels without any rounding (set before the
+        # first forward, or afterwards followed by ``model._engine = None``)
+        self.compute_precision = "bf16"
 
         self.encoder_modalities = set(encoder_embeddings.keys())
         self.decoder_modalities = set(decoder_embeddings.keys())
@@ -341,7 +344,7 @@ class FourM(nn.Module):
         y, _ = eng.trunk_forward(enc, dec, save=False)
         B, Mt, D = dec["B"], dec["Nt"], self.dim
         R = B * Mt
-        yn = eng.ws.get("api.yn", (y.shape[0], D), torch.bfloat16)
+        yn = eng.ws.get("api.yn", (y.shape[0], D), eng.adt)
         ops.layernorm_fwd(y, self.decoder_norm.weight, self.decoder_norm.bias, yn, eps=self.decoder_norm.eps, R=R)
         out = {}
         for mod in mod_dict:
@@ -349,7 +352,7 @@ class FourM(nn.Module):
                 continue
             w = self.decoder_embeddings[mod].to_logits.weight
             V = w.shape[0]
-            lg = torch.empty(R, ops.ru(V, 4), dtype=torch.bfloat16, device=y.device)
+            lg = torch.empty(R, ops.ru(V, 4), dtype=eng.adt, device=y.device)
             ops.gemm_nt(yn, eng.w(w), lg, M=R, N=V, K=D)
             out[mod] = lg[:, :V].reshape(B, Mt, V)
         return out

@@ -141,6 +141,56 @@ def test_logits(name):
     assert worst_f32 < b_f32, errs
 
 
+@pytest.mark.parametrize("name", ["micro_swiglu", "micro_pad", "micro_gelu", "micro_qknorm", "ti_mod7", "l_like", "b_mod7"])
+def test_fp32_verification_mode(name):
+    """compute_precision = "fp32": the SAME engine (selection, launch sequence, hand-written backward, segmented heads) on the
+    fp32 verification kernels (csrc/fp32_verify.hip), no bf16 rounding anywhere, against the upstream fp32 model (the oracle in
+    fp32 == upstream, pinned by make_golden.py; the fixture's loss / logit norms / gradient norms are re-checked here).
+    north_star asks for logits within 1e-3 relative.  Measured r02 (profiles/r02_parity.jsonl): logits 4.8e-7 ... 8.1e-7, worst
+    gradient tensor 1.1e-6 ... 4.7e-6, loss <= 2e-7; held to 1e-5 / 5e-5 / 2e-6 (fp32 summation-order noise only)."""
+    g, case, model = setup(name)
+    model.compute_precision = "fp32"
+    cfg, md = case["cfg"], case["mod_dict"]
+    order = g["meta/order"].tolist()
+    P = tie({k: v.clone().requires_grad_(v.is_floating_point()) for k, v in case["sd"].items()}, cfg, case["share_embedding"])
+    o_loss, o_mod = O.fourm_forward(P, cfg, md, case["N"], case["M"], order, loss_type=case["loss_type"])
+    o_loss.sum().backward()
+    random.seed(case["order_seed"])
+    loss, mod_loss = model(to_device(md), case["N"], case["M"], loss_type=case["loss_type"])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert model.engine.fp32 and model.engine.adt == torch.float32
+    e_loss = abs(float(loss) - float(g["loss"][0])) / abs(float(g["loss"][0]))          # vs the UPSTREAM fixture
+    for k, v in mod_loss.items():
+        assert abs(float(v) - float(g[f"mod_loss/{k}"][0])) < 2e-5 * max(1.0, abs(float(g[f"mod_loss/{k}"][0]))), k
+    worst = []
+    for n, p in model.named_parameters():
+        og = P[n].grad
+        if og is None or float(og.norm()) < 1e-9:
+            assert p.grad is None or float(p.grad.norm()) < 1e-6, n
+            continue
+        worst.append((rel(p.grad, og), n))
+        key = f"grad_l2/{n}"
+        if key in g.files:                                                               # upstream's own gradient norm
+            assert abs(float(p.grad.double().norm()) - float(g[key])) < 1e-3 * float(g[key]) + 1e-7, n
+    worst.sort(reverse=True)
+    # logits
+    model.eval()
+    random.seed(case["order_seed"])
+    with torch.no_grad():
+        logits = model(to_device(md), case["N"], case["M"], return_logits=True)
+        f32 = O.fourm_forward(P, cfg, md, case["N"], case["M"], order, return_logits=True)
+    e_logits = {k: rel(v, f32[k]) for k, v in logits.items()}
+    for k, v in logits.items():
+        assert v.dtype == torch.float32
+        assert abs(float(v.double().norm()) - float(g[f"logits_fro/{k}"])) < 1e-4 * float(g[f"logits_fro/{k}"]), k
+    record("model.fp32_mode", case=name, loss_rel=e_loss, logits_rel_worst=max(e_logits.values()), grad_rel_worst=worst[0][0],
+           grad_rel_worst_name=worst[0][1], grad_rel_median=float(np.median([w[0] for w in worst])))
+    assert e_loss < 2e-6, e_loss
+    assert max(e_logits.values()) < 1e-5, e_logits
+    assert worst[0][0] < 5e-5, worst[:6]
+
+
 def test_eval_forward_and_accumulation():
     g, case, model = setup("micro_swiglu")
     md = to_device(case["mod_dict"])
