@@ -26,25 +26,36 @@ import torch.distributed as dist  # noqa: E402
 
 MOD7_IN = ["caption", "det", "rgb@224", "tok_clip@224", "tok_depth@224", "tok_normal@224", "tok_rgb@224", "tok_semseg@224"]
 MOD7_OUT = [m for m in MOD7_IN if m != "rgb@224"]
+# BASELINE.json configs[3]: cfgs/default/4m/data/cc12m+coyo+c4/main/mix_mod21_all2allmix_rgb2all_capT5bias_C4.yaml:7-8
+MOD21_IN = ("caption-t5_caption-det-metadata-rgb@224-tok_rgb@224-tok_normal@224-tok_depth@224-tok_semseg@224-tok_clip@224-human_poses-"
+            "tok_dinov2@224-tok_dinov2_global-tok_imagebind@224-tok_imagebind_global-tok_sam_edge@224-tok_canny_edge@224-color_palette-"
+            "sam_instance").split("-")
+MOD21_OUT = [m for m in MOD21_IN if m not in ("rgb@224", "t5_caption")]
+MODS = {"mod7": (MOD7_IN, MOD7_OUT), "mod21": (MOD21_IN, MOD21_OUT)}
 BF16_PEAK_TFLOPS = 2500.0          # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def build_model(name, device):
+def build_model(name, device, mods="mod7"):
+    """The way the trainer builds it (run_training_4m.py:242-253 setup_modality_info, :354-387 get_model)."""
     from fourm.data.modality_info import MODALITY_INFO
     from fourm.utils import create_model
-    info = {m: dict(MODALITY_INFO[m]) for m in MOD7_IN}
+    mods_in, mods_out = MODS[mods]
+    info = {m: dict(MODALITY_INFO[m]) for m in sorted(set(mods_in) | set(mods_out))}
+    geom = {m: (info[m].get("input_size", 224), info[m].get("patch_size", 16)) for m in info}
     for m in info:
         if info[m]["type"] == "img":
-            info[m]["max_tokens"] = (224 // 16) ** 2
+            info[m]["max_tokens"] = (geom[m][0] // geom[m][1]) ** 2
 
-    def embs(mods, key):
+    def embs(names, key):
         out = {}
-        for m in mods:
-            kw = dict(patch_size=16, image_size=224) if info[m]["type"] == "img" else {}
+        for m in names:
+            if info[m].get(key) is None:
+                continue
+            kw = dict(patch_size=geom[m][1], image_size=geom[m][0]) if info[m]["type"] == "img" else {}
             out[m] = info[m][key](**kw)
         return out
-    model = create_model(name, encoder_embeddings=embs(MOD7_IN, "encoder_embedding"), decoder_embeddings=embs(MOD7_OUT, "decoder_embedding"),
+    model = create_model(name, encoder_embeddings=embs(mods_in, "encoder_embedding"), decoder_embeddings=embs(mods_out, "decoder_embedding"),
                          modality_info=info)
     return model.to(device)
 
@@ -59,7 +70,12 @@ def train_flops_per_sample(model, n_in, n_out, head_vocabs):
     f_enc = N * (6 * D * D + 2 * D * D + mlp) + 4 * N * N * D
     f_dec = M * (6 * D * D + 2 * D * D + mlp) + 4 * M * M * D + M * 4 * D * D + N * 4 * D * D + 4 * M * N * D
     f = Le * f_enc + Ld * f_dec + 2 * N * D * D
-    f += 2 * (N / 8) * 768 * D                                   # pixel patches actually selected (uniform split over 8 inputs)
+    n_enc = len(model.encoder_embeddings)
+    for e in model.encoder_embeddings.values():                   # dense input projections on the rows actually selected (uniform split)
+        if hasattr(e, "proj"):
+            f += 2 * (N / n_enc) * e.proj.weight.shape[1] * D
+        if hasattr(e, "emb_proj"):
+            f += 2 * (N / n_enc) * e.emb_proj.weight.shape[1] * D
     f += sum(2 * D * v * (M / len(head_vocabs)) for v in head_vocabs)
     return 3.0 * f
 
@@ -145,22 +161,87 @@ def pmc_traffic(kernel_regex, timeout_s=240, worker_args=()):
                     "launches_counted": n_launch["FETCH_SIZE"], "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 B, separate --pmc passes"}
 
 
-def cpu_baseline(timeout_s=240):
-    """Run the CPU-oracle leg in a child process (bounded wall time, its own thread pool)."""
+REFERENCE_TREE = "/root/reference"
+
+
+def cpu_baseline(timeout_s=300, workload="train"):
+    """Run the CPU leg in a child process (bounded wall time, its own thread pool): the UNMODIFIED upstream model through
+    tests/golden/ref_stubs.py when /root/reference exists (the build container), else the oracle port (the GPU box)."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True, text=True,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", workload], capture_output=True, text=True,
                            timeout=timeout_s, env={**os.environ, "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:
-        return {"value": None, "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
-                "sample": f"CPU oracle leg did not finish within {timeout_s}s ({type(e).__name__})"}
+        return {"value": None, "unit": "tokens/s" if workload == "train" else "images/s", "cores": os.cpu_count(), "kind": "port",
+                "reference_available": os.path.isdir(REFERENCE_TREE),
+                "sample": f"CPU leg did not finish within {timeout_s}s ({type(e).__name__})"}
 
 
-def cpu_baseline_worker(batch=8, steps=2):
+def _cpu_model_name():
+    try:
+        return [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return ""
+
+
+def cpu_baseline_reference_worker(batch=8, steps=3):
+    """The UNMODIFIED upstream FourM (imported from /root/reference through the inert stubs of tests/golden/ref_stubs.py), fp32,
+    forward + backward + torch.optim.AdamW on the 4M-B mod7 shapes: SURVEY §8d's CPU baseline.  Only where the tree exists."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import ref_stubs
+    ref_stubs.install()
+    sys.path.insert(0, REFERENCE_TREE)
+    from tests.golden.make_golden import upstream_model, clone_mod_dict
+    from oracle import fourm_oracle as O
+    threads = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = O.named_cfg("base", O.mod7_specs())
+    model = upstream_model(cfg, True, False, ())
+    model.load_state_dict(O.seeded_state_dict(cfg, seed=0), strict=True)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+    md = O.synthetic_mod_dict(cfg, batch, 128, 128, seed=0)
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        loss, _ = model(clone_mod_dict(md), 128, 128)
+        loss.sum().backward()
+        opt.step(); opt.zero_grad()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": batch * 256 / t, "unit": "tokens/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "reference",
+            "reference_available": True,
+            "sample": f"unmodified upstream fourm.models.fm.FourM (fp32), 4M-B mod7, batch {batch}, 128+128 tokens, fwd+bwd+AdamW, median of "
+                      f"{steps} steps after 1 warm-up, {t:.2f} s/step", "cpu": _cpu_model_name()}
+
+
+def cpu_baseline_vq_worker(batch=8, steps=3):
+    """The VQ oracle port (fp32 restatement of VQ.encode, pinned to upstream by tests/golden/make_golden_vq.py) on the host cores."""
+    from oracle import vq_oracle as V
+    threads = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = V.vq_cfg("vit_b_enc", image=224, patch=16, codebook=16384, post_mlp=True)
+    sd = V.seeded_vq_state_dict(cfg, seed=0)
+    x = V.synthetic_images(cfg, batch, seed=0)
+    times = []
+    with torch.no_grad():
+        for it in range(steps + 1):
+            t0 = time.perf_counter()
+            V.vq_encode(sd, cfg, x)
+            times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": batch / t, "unit": "images/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "reference_available": os.path.isdir(REFERENCE_TREE),
+            "sample": f"oracle fp32 PyTorch port of VQ.encode (ViT-B/16 + 16384 x 32 cosine codebook), batch {batch} 224^2 images, median of "
+                      f"{steps} passes after 1 warm-up, {t:.2f} s/batch", "cpu": _cpu_model_name()}
+
+
+def cpu_baseline_worker(batch=8, steps=3):
     """The oracle port (plain fp32 PyTorch restatement of the upstream model) timed on the host cores:
-    forward + backward + AdamW on the same 4M-B mod7 shapes, small batch.  A reported baseline only."""
+    forward + backward + AdamW on the same 4M-B mod7 shapes, small batch.  A reported baseline only.
+    (Used where /root/reference does not exist: the GPU box.  The port is pinned to upstream by tests/golden/make_golden.py.)"""
     from oracle import fourm_oracle as O
     threads = min(64, os.cpu_count() or 1)        # more threads than this only adds contention at batch 8
     torch.set_num_threads(threads)
@@ -186,14 +267,91 @@ def cpu_baseline_worker(batch=8, steps=2):
         opt.step(); opt.zero_grad()
         times.append(time.perf_counter() - t0)
     t = sorted(times[1:])[len(times[1:]) // 2]
-    model = ""
-    try:
-        model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        pass
     return {"value": batch * 256 / t, "unit": "tokens/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle fp32 PyTorch port, 4M-B mod7, batch {batch}, 128+128 tokens, fwd+bwd+AdamW, median of {steps} steps "
-                      f"after 1 warm-up, {t:.2f} s/step", "cpu": model}
+            "reference_available": False,
+            "sample": f"oracle fp32 PyTorch port (the reference tree is not on this machine), 4M-B mod7, batch {batch}, 128+128 tokens, "
+                      f"fwd+bwd+AdamW, median of {steps} steps after 1 warm-up, {t:.2f} s/step", "cpu": _cpu_model_name()}
+
+
+def main_vq(a):
+    """BASELINE.json configs[4]: images/s of VQ.encode (patchify -> ViT-B/16 -> fp32 post-MLP -> 1x1 projection -> cosine code
+    search) at the reference's sub-batch of 64 (save_vq_tokens.py:387-388).  Replicas only across GPUs (no collective)."""
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible: the tokenizer has no CPU implementation"}))
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from fourm.hip import ops
+    from fourm.vq import VQ
+    torch.manual_seed(rank)
+    batch = a.user_batch or 64
+    model = VQ(image_size=224, enc_type="vit_b_enc", patch_size=16, post_mlp=True, codebook_size=16384, latent_dim=32, norm_codes=True,
+               sync_codebook=False).to(dev).eval()
+    xs = [torch.rand(batch, 3, 224, 224, device=dev) * 2 - 1 for _ in range(2)]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    if a.pmc_worker:
+        for i in range(2):
+            model.tokenize(xs[i % 2])
+        fence()
+        return
+    for i in range(a.warmup):
+        model.tokenize(xs[i % 2])
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        tok = model.tokenize(xs[i % 2])
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    flops_img = 37.0e9                      # SURVEY §8d: 36.8 GFLOP ViT + 0.21 GFLOP code search per image
+    value = world * batch * a.steps / dt
+    out = {"metric": "images/sec (RGB VQ tokenizer encode+quantize, whole job)", "value": value, "unit": "images/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "RGB VQ tokenizer (ViT-B/16 encoder 90.5M params, 224^2 -> 14x14 codes, 16384 x 32 cosine codebook): "
+                                  "VQ.tokenize on uniform [-1,1] images", "per_gpu_batch": batch, "global_batch": batch * world,
+                      "parallelism": f"replicas x{world}"},
+           "codes_per_sec": value * 196, "mfu": flops_img * value / world / (BF16_PEAK_TFLOPS * 1e12),
+           "arithmetic": "ViT blocks bf16 operands / fp32 accumulate; post-MLP, 1x1 projection and code search fp32"}
+    if not a.no_kernel_profile and rank == 0:
+        prof = LaunchProfiler()
+        ops.set_profiler(prof)
+        for i in range(2):
+            model.tokenize(xs[i % 2])
+        ops.set_profiler(None)
+        agg = prof.summary()
+        tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
+        name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["flops"] else 0.0
+        fam, _, epi = name.partition("/epi")
+        traffic, detail = (None, None)
+        if world == 1 and not a.no_traffic and fam in KERNEL_REGEX:
+            traffic, detail = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0"), worker_args=["--workload", "vq", "--batch", str(batch)])
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
+                           "kernel": f"{name} (csrc/gemm.hip)", "traffic": traffic, "traffic_detail": detail, "launches_per_step": d["n"] // 2,
+                           "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms,
+                           "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
+        out["kernel_breakdown_ms_per_step"] = {k: round(v["ms"] / 2, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        print(json.dumps(out), file=sys.stderr)
+        out["cpu_baseline"] = cpu_baseline(workload="vq")
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -201,10 +359,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
-    ap.add_argument("--model", default="fm_base_12e_12d_swiglu_nobias")
-    ap.add_argument("--n-in", type=int, default=128)
-    ap.add_argument("--n-out", type=int, default=128)
+    ap.add_argument("--workload", default="train", choices=["train", "vq"], help="train = the headline 4M train step; vq = BASELINE "
+                    "configs[4]: RGB VQ tokenizer (ViT-B/16, 224^2 -> 14 x 14 codes, 16384 x 32 codebook) encode + quantize, batch 64")
+    ap.add_argument("--mods", default="mod7", choices=sorted(MODS), help="mod7 = BASELINE configs[1] (4M-B, batch 256, 128+128 tokens); "
+                    "mod21 = configs[3] (4M-L, 19 / 17 modalities, batch 64, 256+256 tokens)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 for mod7, 64 for mod21)")
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--n-in", type=int, default=None)
+    ap.add_argument("--n-out", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test hook: several ranks on one GPU)")
@@ -212,9 +374,21 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    a.user_batch = a.batch
+    dflt = {"mod7": ("fm_base_12e_12d_swiglu_nobias", 256, 128), "mod21": ("fm_large_24e_24d_swiglu_nobias", 64, 256)}[a.mods]
+    a.model = a.model or dflt[0]
+    a.batch = a.batch or dflt[1]
+    a.n_in, a.n_out = a.n_in or dflt[2], a.n_out or dflt[2]
     if a.cpu_baseline_worker:
-        print(json.dumps(cpu_baseline_worker()))
+        if a.workload == "vq":
+            print(json.dumps(cpu_baseline_vq_worker()))
+        elif os.path.isdir(REFERENCE_TREE):
+            print(json.dumps(cpu_baseline_reference_worker()))
+        else:
+            print(json.dumps(cpu_baseline_worker()))
         return
+    if a.workload == "vq":
+        return main_vq(a)
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
@@ -240,7 +414,7 @@ def main():
     from fourm.utils.optim_factory import FusedAdamW, get_parameter_groups
 
     torch.manual_seed(0)
-    model = build_model(a.model, dev).train()
+    model = build_model(a.model, dev, a.mods).train()
     dp = DataParallel(model) if world > 1 else None
     fwd = dp if dp is not None else model
     import contextlib, io
@@ -285,7 +459,7 @@ def main():
 
     tokens_per_step = world * a.batch * (a.n_in + a.n_out)
     value = tokens_per_step * a.steps / dt
-    head_vocabs = [model.decoder_embeddings[m].vocab_size for m in MOD7_OUT]
+    head_vocabs = [e.vocab_size for e in model.decoder_embeddings.values()]
     flops_step = train_flops_per_sample(model, a.n_in, a.n_out, head_vocabs) * a.batch
     n_params = sum(p.numel() for p in {id(p): p for p in model.parameters()}.values())
     family = {"fm_tiny": "4M-Ti", "fm_small": "4M-S", "fm_base": "4M-B", "fm_large": "4M-L", "fm_xlarge": "4M-XL"}.get(a.model.rsplit("_", 4)[0], a.model)
@@ -293,7 +467,8 @@ def main():
         "metric": f"multimodal tokens/sec ({family} train step, whole job)", "value": value, "unit": "tokens/s", "n_gpus": world,
         "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{family} mod7 ({a.model}, {n_params / 1e6:.1f}M params) masked-modeling train step, 224^2 token grids, "
+        "config": {"workload": f"{family} {a.mods} ({a.model}, {n_params / 1e6:.1f}M params, {len(model.encoder_embeddings)} input / "
+                               f"{len(model.decoder_embeddings)} target modalities) masked-modeling train step, 224^2 token grids, "
                                f"{a.n_in} input + {a.n_out} target tokens/sample, AdamW", "model": a.model, "per_gpu_batch": a.batch,
                    "global_batch": a.batch * world, "seq_len": a.n_in + a.n_out, "parallelism": f"dp{world}"},
         "tokens_per_sec_per_gpu": value / world,
@@ -324,7 +499,7 @@ def main():
                   "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms,
                   "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
         if world == 1 and not a.no_traffic and fam in KERNEL_REGEX:
-            same_job = ["--model", a.model, "--batch", str(a.batch), "--n-in", str(a.n_in), "--n-out", str(a.n_out)]
+            same_job = ["--mods", a.mods, "--model", a.model, "--batch", str(a.batch), "--n-in", str(a.n_in), "--n-out", str(a.n_out)]
             common["traffic"], common["traffic_detail"] = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0"), worker_args=same_job)
         if d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -339,7 +514,7 @@ def main():
                 f.write("\n".join(prof.shape_table(2)) + "\n")
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mods == "mod7":
         print(json.dumps(out), file=sys.stderr)      # the GPU result is safe on stderr before the CPU leg starts
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -289,6 +289,22 @@ int fm_sumsq(const void* x, int64_t n, void* out, void* stream);                
 int fm_clip_coef(const void* sumsq, float max_norm, void* norm_out, void* coef_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Generation step: token sampling + MaskGIT commit (csrc/sample.hip) — GenerationSampler.top_k_top_p_filtering / sample_tokens /
+ * select_tokens_batched and the scatter updates of maskgit_step_batched, fourm/models/generate.py:332-420,650-661.
+ * One workgroup per logits row: temperature (0 = argmax), top_k (0 = off; entries strictly below the k-th largest logit are
+ * dropped), top_p (0 or 1 = off; an entry survives iff the temperature-1 probability mass of strictly larger logits is <= top_p),
+ * then one multinomial draw by inverse CDF in index order from uniforms[row] in [0, 1).  Deterministic: fixed-polynomial exp with
+ * separately rounded fp32 operations, integer radix selects, a fixed summation tree (oracle/sample_oracle.py is bit-identical).
+ * out_ids: int64 (R); out_prob: f32 (R) = probability of the drawn token after filtering at the sampling temperature. */
+int fm_sample_tokens(const void* logits, int ld, int logits_are_f32, int R, int V, float temperature, int top_k, float top_p,
+                     const void* uniforms, void* out_ids, void* out_prob, void* stream);
+/* Per sample b: the num_select entries of prob (B, N) with the largest value (ties: lower index first), in that order, go to
+ * top_idx (B, num_select) and are committed: tensor[b][mod_pos[b][i]] = samples[b][i] (int64 or int32 tensor of row length L),
+ * input_mask[b][pos] = 0, target_mask[b][pos] = 1 (bool / uint8). */
+int fm_maskgit_commit(const void* prob, const void* samples, const int32_t* mod_pos, int B, int N, int num_select, void* tensor,
+                      int tensor_is_i64, int L, void* input_mask, void* target_mask, int32_t* top_idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * fp32 VERIFICATION path (csrc/fp32_verify.hip): the floating-point kernels above once more with fp32 activations and weights
  * and no bf16 rounding, so that the launch sequence of the engine can be checked against the upstream fp32 model at fp32
  * tolerances.  Plain kernels, not the hot path.  Same conventions; every activation pointer is f32.

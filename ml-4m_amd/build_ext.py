@@ -10,7 +10,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "fourm", "_lib", "libfourm_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "gemm_nt_flat.hip", "layernorm.hip", "attention.hip", "select_embed.hip", "loss.hip", "elementwise.hip", "vq.hip", "fp32_verify.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "gemm_nt_flat.hip", "layernorm.hip", "attention.hip", "select_embed.hip", "loss.hip", "elementwise.hip", "vq.hip", "fp32_verify.hip", "sample.hip"]
+
+
+# sample.hip: the sampler's determinism contract needs separately rounded fp32 multiplies and adds (no fused multiply-add)
+EXTRA_FLAGS = {"sample.hip": ["-ffp-contract=off"]}
 
 
 def hipcc() -> str:
@@ -45,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 os.path.getmtime(os.path.join(ROOT, "include", "fourm_hip.h"))):
             continue
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
-               "-x", "hip", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o]
+               "-x", "hip", "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o] + EXTRA_FLAGS.get(os.path.basename(s), [])
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

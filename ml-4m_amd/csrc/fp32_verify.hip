@@ -106,6 +106,99 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(fm_gemm_f32_args a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// The NT case (both operands reduction-contiguous) on the fp32 matrix cores: v_mfma_f32_32x32x2_f32 is exact fp32 (one fmaf chain
+// per output, bitwise) at the fp32 vector rate.  128(feature) x 128(row) tile, 4 waves of 64 x 64, K-step 32 through LDS
+// (row stride 33 floats: the 32 lanes of a half-wave hit 32 banks).  Weight-like operand on the MFMA row side, like gemm.hip:
+// a lane ends up with 4 consecutive features of one token row -> float4 epilogue.  Used by the verification path and by the
+// tokenizer's post-MLP / 1x1 projection, which upstream computes with autocast disabled (vq/models/vit_models.py:494-496).
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(fm_gemm_f32_args a) {
+    constexpr int T = 128, KS = 32, LDT = KS + 1;
+    __shared__ float Ws[T * LDT], Xs[T * LDT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ww = wave >> 1, wx = wave & 1;
+    const int n0 = blockIdx.x * T, m0 = blockIdx.y * T;
+    const float* X = (const float*)a.X; const float* W = (const float*)a.W;
+    const int M = a.M, N = a.N, K = a.K;
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // staging: thread -> (row = tid / 8 + 32 p, 4 floats at column (tid % 8) * 4)
+    const int lr = threadIdx.x >> 3, lc = (threadIdx.x & 7) * 4;
+    float4 wreg[4], xreg[4];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = lr + 32 * p;
+            const int n = n0 + r < N ? n0 + r : N - 1, m = m0 + r < M ? m0 + r : M - 1;
+            const int k = k0 + lc;
+            if (k + 3 < K) {
+                wreg[p] = *(const float4*)(W + (long long)n * a.swn + k);
+                xreg[p] = *(const float4*)(X + (long long)m * a.sxm + k);
+            } else {
+                float w4[4], x4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w4[e] = k + e < K ? W[(long long)n * a.swn + k + e] : 0.f; x4[e] = k + e < K ? X[(long long)m * a.sxm + k + e] : 0.f; }
+                wreg[p] = make_float4(w4[0], w4[1], w4[2], w4[3]); xreg[p] = make_float4(x4[0], x4[1], x4[2], x4[3]);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            float* wd = Ws + (lr + 32 * p) * LDT + lc; float* xd = Xs + (lr + 32 * p) * LDT + lc;
+            wd[0] = wreg[p].x; wd[1] = wreg[p].y; wd[2] = wreg[p].z; wd[3] = wreg[p].w;
+            xd[0] = xreg[p].x; xd[1] = xreg[p].y; xd[2] = xreg[p].z; xd[3] = xreg[p].w;
+        }
+    };
+    load(0);
+    for (int k0 = 0; k0 < K; k0 += KS) {
+        __syncthreads();                       // the previous step's readers are done
+        stash();
+        __syncthreads();
+        if (k0 + KS < K) load(k0 + KS);        // next K-step in flight under the MFMAs
+        const float* wb = Ws + (ww * 64 + (lane & 31)) * LDT + (lane >> 5);
+        const float* xb = Xs + (wx * 64 + (lane & 31)) * LDT + (lane >> 5);
+#pragma unroll
+        for (int kk = 0; kk < KS; kk += 2) {
+            const float a0 = wb[kk], a1 = wb[32 * LDT + kk], b0 = xb[kk], b1 = xb[32 * LDT + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    const float* bias = (const float*)a.bias; const float* res = (const float*)a.res;
+    float* out = (float*)a.out;
+    const int fhi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wx * 64 + j * 32 + (lane & 31);
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + ww * 64 + i * 32 + 8 * g + 4 * fhi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e >= N) continue;
+                    float v = acc[i][j][4 * g + e] + (bias ? bias[n + e] : 0.f);
+                    float* o = out + (size_t)m * a.ldo + n + e;
+                    if (a.epilogue == FM_EPI_TANH) v = tanhf(v);
+                    else if (a.epilogue == FM_EPI_GELU) { if (a.out2) ((float*)a.out2)[(size_t)m * a.ldo2 + n + e] = v; v = gelu32(v); }
+                    else if (a.epilogue == FM_EPI_RESIDUAL || (a.epilogue == FM_EPI_F32 && res)) v += res[(size_t)m * a.ldr + n + e];
+                    *o = a.accumulate ? *o + v : v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // attention: one workgroup (64 threads) per (b, h, query).  Scores in LDS, softmax in fp32, blocked scores REPLACED by NEG_FILL32.
 // ------------------------------------------------------------------------------------------------------------------------------
 struct Attn32 {
@@ -279,6 +372,14 @@ extern "C" int fm_gemm_f32(const fm_gemm_f32_args* p, void* stream) {
     const int maxN = p->groups && p->tile_group ? p->max_N : p->N;
     const int maxM = p->seg_start ? p->max_N : p->M;
     dim3 grid((maxN + 63) / 64, (maxM + 63) / 64, p->seg_start ? p->n_groups : 1);
+    // plain NT with reduction-contiguous, 16-byte aligned operands: the fp32 matrix cores
+    const bool nt = p->sxk == 1 && p->swk == 1 && !p->groups && !p->seg_start && p->epilogue != FM_EPI_SWIGLU && p->sxm % 4 == 0 &&
+                    p->swn % 4 == 0 && ((((uintptr_t)p->X | (uintptr_t)p->W)) & 15) == 0;
+    if (nt) {
+        hipLaunchKernelGGL(gemm_f32_mfma_kernel, dim3((p->N + 127) / 128, (p->M + 127) / 128), dim3(256), 0, (hipStream_t)stream, *p);
+        FM_CHECK_LAUNCH("fm_gemm_f32");
+        return 0;
+    }
     if (p->epilogue == FM_EPI_SWIGLU) {
         FM_CHECK_ARG(p->W2, "fm_gemm_f32: SwiGLU needs W2");
         hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *p);

@@ -145,6 +145,8 @@ adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, 
 adamw_shadow = _sig("fm_adamw_shadow", vp, i32, i32, f32, f32, f32, f32, f32, i64, vp, vp)
 sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
 clip_coef = _sig("fm_clip_coef", vp, f32, vp, vp, vp)
+sample_tokens = _sig("fm_sample_tokens", vp, i32, i32, i32, i32, f32, i32, f32, vp, vp, vp, vp)
+maskgit_commit = _sig("fm_maskgit_commit", vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp)
 # fp32 verification path
 gemm_f32 = _sig("fm_gemm_f32", P(GemmF32Args), vp)
 attn_f32_fwd = _sig("fm_attn_f32_fwd", P(AttnArgs), vp)
@@ -170,7 +172,7 @@ EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_conf
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
            "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_colsum", "fm_f32_to_bf16", "fm_adamw", "fm_adamw_shadow",
            "fm_sumsq", "fm_clip_coef", "fm_vq_patchify", "fm_l2norm_rows", "fm_vq_assign",
-           "fm_gemm_f32", "fm_attn_f32_fwd", "fm_attn_f32_bwd", "fm_layernorm_bwd_f32", "fm_headnorm_f32_fwd", "fm_headnorm_f32_bwd",
+           "fm_sample_tokens", "fm_maskgit_commit", "fm_gemm_f32", "fm_attn_f32_fwd", "fm_attn_f32_bwd", "fm_layernorm_bwd_f32", "fm_headnorm_f32_fwd", "fm_headnorm_f32_bwd",
            "fm_swiglu_bwd_f32", "fm_gelu_bwd_f32", "fm_colsum_f32", "fm_cross_entropy_f32"]
 
 

@@ -96,7 +96,8 @@ def _gemm_f32(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, b
         assert w2.stride() == w.stride()
     a.ldo, a.ldo2, a.ldr = out.stride(0), out2.stride(0) if out2 is not None else 0, res.stride(0) if res is not None else 0
     a.Hp, a.epilogue, a.accumulate = Hp, epilogue, 1 if accumulate else 0
-    L.check(L.gemm_f32(C.byref(a), _stream()))
+    with _prof("gemm_f32", 2.0 * a.M * a.N * a.K * (2 if epilogue == L.EPI_SWIGLU else 1), 4.0 * (a.K * (a.M + a.N) + a.M * a.N), tag=f"M{a.M} N{a.N} K{a.K}"):
+        L.check(L.gemm_f32(C.byref(a), _stream()))
     return out
 
 

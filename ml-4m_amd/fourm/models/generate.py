@@ -1,0 +1,154 @@
+"""Generation step of 4M on MI355X: the MaskGIT decoding step of upstream ``GenerationSampler`` (fourm/models/generate.py:323-661).
+
+One call of ``maskgit_step_batched`` = select + embed the conditioning tokens -> encoder -> context projection -> decoder over the
+still-masked positions of the target modality (no self-attention mask, generate.py:642) -> logits -> temperature / top-k / top-p
+sampling of every position -> keep the ``num_select`` most confident samples and write them into ``mod_dict``.  Everything runs on
+the engine's HIP kernels; the sampling + commit are two launches of csrc/sample.hip instead of upstream's topk / sort / softmax /
+cumsum / argsort / gather / multinomial / topk / scatter chain.
+
+Scope (first slice): the MaskGIT scheme, batched, for grid-token target modalities.  ROAR and the autoregressive
+scheme (which upstream runs WITHOUT a K/V cache, generate.py:850-914), guidance and chained schedules are not implemented yet and
+raise; nothing falls back to eager PyTorch.
+
+Determinism: the only randomness is one uniform per decoded position drawn with ``torch.rand`` from the generator passed in (or the
+device default): same logits + same uniforms -> same tokens (csrc/sample.hip, bit-exact against oracle/sample_oracle.py).
+Upstream draws through ``torch.multinomial``; the sampled DISTRIBUTION is the same, the random stream is not.
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+__all__ = ["GenerationSampler"]
+
+
+class GenerationSampler(nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    # sampling  (generate.py:332-420)
+    # ------------------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _top_k_int(top_k, vocab):
+        if not top_k:
+            return 0
+        if isinstance(top_k, int):
+            return min(top_k, vocab)
+        if isinstance(top_k, float):
+            return min(int(top_k * vocab), vocab)
+        raise ValueError(f"Invalid value for top_k: {top_k}")
+
+    def sample_tokens(self, logits, temperature=1.0, top_k=0.0, top_p=0.0, generator=None, uniforms=None):
+        """logits (R, V) bf16 / f32 -> (samples int64 (R), sampled_probs f32 (R)).  temperature ~ 0: argmax, probabilities 1."""
+        from fourm.hip import _lib as L, ops
+        if logits.dim() != 2 or logits.stride(1) != 1:
+            raise ValueError("sample_tokens expects row-major (rows, vocab) logits")
+        if logits.dtype not in (torch.bfloat16, torch.float32):
+            logits = logits.float()
+        R, V = logits.shape
+        dev = logits.device
+        greedy = abs(temperature) < 1e-10
+        if uniforms is None and not greedy:
+            uniforms = torch.rand(R, device=dev, generator=generator, dtype=torch.float32)
+        ids = torch.empty(R, dtype=torch.int64, device=dev)
+        probs = torch.empty(R, dtype=torch.float32, device=dev)
+        L.check(L.sample_tokens(ops._p(logits), logits.stride(0), 1 if logits.dtype == torch.float32 else 0, R, V, float(temperature),
+                                self._top_k_int(top_k, V), float(top_p or 0.0), ops._p(uniforms), ops._p(ids), ops._p(probs), ops._stream()))
+        return ids, probs
+
+    def sample_tokens_batched(self, logits, temperature=1.0, top_k=0.0, top_p=0.0, generator=None, uniforms=None):
+        if logits.ndim > 2:
+            B, N = logits.shape[:2]
+            flat = logits.reshape(B * N, logits.shape[-1])
+            s, p = self.sample_tokens(flat, temperature, top_k, top_p, generator, None if uniforms is None else uniforms.reshape(-1))
+            return s.view(B, N), p.view(B, N)
+        return self.sample_tokens(logits, temperature, top_k, top_p, generator, uniforms)
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    # one MaskGIT forward  (generate.py:407-480, :628-647)
+    # ------------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_enc_dec_maskgit_batched(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], target_mod: str, seed: Optional[int] = None):
+        """-> (logits (B, N, V) for the N still-masked positions of ``target_mod`` in position order, mod_pos (B, N) int32)."""
+        from fourm.hip import _lib as L, ops
+        m = self.model
+        eng = m.engine
+        eng.prepare()
+        if target_mod not in m.decoder_embeddings:
+            raise KeyError(f"{target_mod} has no decoder embedding")
+        demb = m.decoder_embeddings[target_mod]
+        if demb.kind != L.KIND_TOK:
+            raise NotImplementedError("MaskGIT decoding is implemented for grid-token modalities (sequences use ROAR / autoregressive "
+                                      "decoding upstream, which are not implemented here yet)")
+        enc_names = [n for n in mod_dict if n in m.encoder_embeddings]
+        B = mod_dict[enc_names[0]]["tensor"].shape[0]
+        # budget = the largest number of visible tokens of a sample (generate.py:413, one host read like upstream's .max())
+        vis = sum((~mod_dict[n]["input_mask"].reshape(B, -1).bool()).sum(1) for n in enc_names)
+        n_enc = int(vis.max())
+        tm = mod_dict[target_mod]["target_mask"].reshape(B, -1).bool()
+        n_dec = int((~tm[0]).sum())                                  # "assumes num_decoder_tokens is the same across the batch" (:460)
+        if n_enc == 0 or n_dec == 0:
+            raise ValueError("nothing to condition on / nothing left to decode")
+        enc = eng.select(mod_dict, n_enc, False, enc_names, "gen.enc.")
+        dd = dict(mod_dict[target_mod])
+        if "decoder_attention_mask" not in dd:                        # generation dicts need none (no decoder self-attention mask)
+            dd["decoder_attention_mask"] = torch.zeros_like(tm, dtype=torch.int32)
+        dec = eng.select({target_mod: dd}, n_dec, True, [target_mod], "gen.dec.", heads=[target_mod])
+        dec["sa_mask"] = dict(mask_kind=L.MASK_NONE)
+        dec.pop("cs")                                                 # trunk_forward: use the explicit (absent) self-attention mask
+        y, _ = eng.trunk_forward(enc, dec, save=False)
+        D, R = m.dim, B * n_dec
+        yn = eng.ws.get("gen.yn", (y.shape[0], D), eng.adt)
+        ops.layernorm_fwd(y, m.decoder_norm.weight, m.decoder_norm.bias, yn, eps=m.decoder_norm.eps, R=R)
+        w = demb.to_logits.weight
+        V = w.shape[0]
+        lg = eng.ws.get("gen.logits", (y.shape[0], ops.ru(V, 8)), eng.adt)
+        ops.gemm_nt(yn, eng.w(w), lg, M=R, N=V, K=D)
+        return lg[:R, :V].view(B, n_dec, V) if lg.shape[1] == V else lg[:R].view(B, n_dec, -1)[..., :V], dec["slot_pos"].view(B, n_dec)
+
+    @torch.no_grad()
+    def maskgit_step_batched(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, seed=None, generator=None, uniforms=None):
+        """One MaskGIT step: mod_dict[target_mod]['tensor' | 'input_mask' | 'target_mask'] are updated in place (and returned)."""
+        from fourm.hip import _lib as L, ops
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        logits, mod_pos = self.forward_enc_dec_maskgit_batched(mod_dict, target_mod)
+        B, N, V = logits.shape
+        rows = logits.reshape(B * N, V) if logits.is_contiguous() else logits.as_strided((B * N, V), (logits.stride(1), 1))
+        samples, probs = self.sample_tokens(rows, temperature, top_k, top_p, generator, uniforms)
+        d = mod_dict[target_mod]
+        t = d["tensor"]
+        flat = t.reshape(B, -1)
+        if not flat.is_contiguous() or flat.data_ptr() != t.data_ptr():
+            raise ValueError("mod_dict tensors must be contiguous (they are updated in place)")
+        for k in ("input_mask", "target_mask"):
+            if d[k].dtype != torch.bool or not d[k].is_contiguous():
+                d[k] = d[k].bool().contiguous()
+        num_select = min(int(num_select), N)
+        top_idx = torch.empty(B, num_select, dtype=torch.int32, device=t.device)
+        L.check(L.maskgit_commit(ops._p(probs), ops._p(samples), ops._p(mod_pos.contiguous()), B, N, num_select, ops._p(flat),
+                                 1 if t.dtype == torch.int64 else 0, flat.shape[1], ops._p(d["input_mask"]), ops._p(d["target_mask"]),
+                                 ops._p(top_idx), ops._stream()))
+        self.last_step = dict(samples=samples.view(B, N), probs=probs.view(B, N), top_indices=top_idx, mod_pos=mod_pos)
+        return mod_dict
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    def generate_maskgit(self, mod_dict, target_mod, num_steps, temperature=1.0, top_k=0.0, top_p=0.0, generator=None):
+        """A constant-rate MaskGIT schedule: ``num_steps`` steps, each committing an equal share of the remaining positions."""
+        B = mod_dict[target_mod]["tensor"].shape[0]
+        remaining = int((~mod_dict[target_mod]["target_mask"].reshape(B, -1)[0].bool()).sum())
+        for step in range(num_steps):
+            if remaining <= 0:
+                break
+            k = remaining if step == num_steps - 1 else max(1, remaining // (num_steps - step))
+            self.maskgit_step_batched(mod_dict, target_mod, k, temperature, top_k, top_p, generator=generator)
+            remaining -= k
+        return mod_dict
+
+    def guided_maskgit_step_batched(self, *a, **k):
+        raise NotImplementedError("classifier-free guidance is not implemented yet (SURVEY §8 f2)")
+
+    def autoregressive_step_batched(self, *a, **k):
+        raise NotImplementedError("autoregressive decoding (with a K/V cache) is not implemented yet (SURVEY §8 f2)")

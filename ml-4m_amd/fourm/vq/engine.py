@@ -23,6 +23,7 @@ class _VitEngine(FourMEngine):
         if self.D // self.H != 64:
             raise NotImplementedError("the HIP attention kernels are built for head_dim 64")
         self.gated, self.act, self.qk_norm = False, "gelu", False
+        self.fp32, self.adt = False, torch.bfloat16       # the 12 blocks follow autocast; the post-MLP / projection call the fp32 GEMM
         self.Hd = blk.mlp.hidden_features
         self.Hp = ru(self.Hd, 64)
         self.scale, self.eps = 64 ** -0.5, blk.norm1.eps
@@ -76,15 +77,16 @@ def _tokens(enc, x):
     for i, blk in enumerate(enc.blocks):
         stream = eng.encoder_block_fwd(blk, stream, B, G, none, None, f"vit{i % 2}")
     if hasattr(enc, "post_mlp"):
-        # x + fc2(tanh(fc1(norm(x))))   (vit_models.py:494-496; fp32 upstream, bf16 GEMM operands here)
-        n = ws.get("vq.n", (Rp, D), torch.bfloat16)
+        # x.float() + fc2(tanh(fc1(norm_mlp(x.float()))))  with autocast DISABLED upstream (vit_models.py:494-496): fp32 operands
+        # on the fp32 matrix cores (fm_gemm_f32: v_mfma_f32_32x32x2_f32, exact fp32) - no bf16 rounding in this tail
+        f32 = torch.float32
+        n = ws.get("vq.n", (Rp, D), f32)
         ops.layernorm_fwd(stream, enc.norm_mlp.weight, enc.norm_mlp.bias, n, eps=enc.norm_mlp.eps, R=R)
         hid = enc.post_mlp.fc1.weight.shape[0]
-        t = ws.get("vq.t", (Rp, ru(hid, 64)), torch.bfloat16)
-        ops.gemm_nt(n, eng.w(enc.post_mlp.fc1.weight), t, epilogue=L.EPI_TANH, bias=enc.post_mlp.fc1.bias, M=R, N=hid, K=D)
-        out = ws.get("vq.post", (Rp, D), torch.float32)
-        ops.gemm_nt(t, eng.w(enc.post_mlp.fc2.weight), out, epilogue=L.EPI_RESIDUAL, res=stream, bias=enc.post_mlp.fc2.bias, M=R, N=D,
-                    K=ru(hid, 64))
+        t = ws.get("vq.t", (Rp, hid), f32)
+        ops.gemm_nt(n, enc.post_mlp.fc1.weight.detach(), t, epilogue=L.EPI_TANH, bias=enc.post_mlp.fc1.bias, M=R, N=hid, K=D)
+        out = ws.get("vq.post", (Rp, D), f32)
+        ops.gemm_nt(t, enc.post_mlp.fc2.weight.detach(), out, epilogue=L.EPI_RESIDUAL, res=stream, bias=enc.post_mlp.fc2.bias, M=R, N=D, K=hid)
         stream = out
     return eng, stream, (B, nh, nw)
 
@@ -101,10 +103,10 @@ def vq_encode(vq, x):
     eng, stream, (B, nh, nw) = _tokens(enc, x)
     ws, D, Ld = eng.ws, eng.D, vq.latent_dim
     G, R = nh * nw, B * nh * nw
-    xb = ws.get("vq.xb", (stream.shape[0], D), torch.bfloat16)
-    ops.f32_to_bf16(stream, xb)
+    # 1x1 convolution to the latent dimension: fp32 like the codebook search that follows (the tokenization script runs without
+    # autocast, save_vq_tokens.py; 0.2 % of the FLOPs)
     z = ws.get("vq.z", (stream.shape[0], Ld), torch.float32)
-    ops.gemm_nt(xb, eng.w(vq.quant_proj.weight), z, epilogue=L.EPI_F32, bias=vq.quant_proj.bias, M=R, N=Ld, K=D)
+    ops.gemm_nt(stream, vq.quant_proj.weight.detach().reshape(Ld, D), z, epilogue=L.EPI_F32, bias=vq.quant_proj.bias, M=R, N=Ld, K=D)
     cb = vq.quantize._codebook
     K = cb.embed.shape[0]
     key = ("codes", cb.embed._version, cb.embed.data_ptr())

@@ -2,10 +2,10 @@
 ``fourm/vq/vqvae.py`` (``VQ`` :39-331: constructor arguments, ``encode`` / ``tokenize`` / ``tokens_to_embedding``,
 state_dict keys).  Inference only; decoders, diffusion and tokenizer training are out of scope.
 
-Precision: the ViT runs with bf16 GEMM operands (fp32 accumulate, fp32 residual / LayerNorm / softmax),
-the codebook search in exact fp32.  Upstream's tokenization script runs everything in fp32; code
-assignment given identical latents is bit-identical (tests), end-to-end token agreement is reported by
-the tests against the fp32 oracle."""
+Precision = upstream's autocast arithmetic: the 12 ViT blocks with bf16 GEMM operands (fp32 accumulate, fp32 residual /
+LayerNorm / softmax); the tanh post-MLP, the 1x1 projection and the codebook search in exact fp32 (upstream disables
+autocast there, vit_models.py:494-496, quantize_lucid.py:388-390).  Code assignment given identical latents is bit-identical
+(tests); end-to-end token agreement against the all-fp32 upstream run is measured and asserted by the tests."""
 import copy
 from typing import Any, Dict, List, Optional, Tuple, Union
 

@@ -601,6 +601,27 @@ def mod7_specs(image: int = 224, patch: int = 16) -> List[ModSpec]:
     ]
 
 
+def mod21_specs() -> List[ModSpec]:
+    """The 19 input / 17 target modalities of the 4M-21 mixture (cfgs/default/4m/data/cc12m+coyo+c4/main/
+    mix_mod21_all2allmix_rgb2all_capT5bias_C4.yaml:7-8) with the registry's vocabularies and lengths
+    (fourm/data/modality_info.py:32-383): ViT-B/14 feature tokenizers give 16 x 16 grids, the two global-feature modalities 16
+    tokens with a learned position table (patch 56 over 224)."""
+    tok = lambda n, v, p=16: ModSpec(n, "tok", vocab=v, n_pos=(224 // p) ** 2, patch=p)
+    seq = lambda n, L: ModSpec(n, "seq", vocab=30000, n_pos=L)
+    return [
+        seq("caption", 256), ModSpec("t5_caption", "seq_emb", n_pos=77, orig_dim=4096, in_dec=False), seq("det", 256), seq("metadata", 40),
+        ModSpec("rgb@224", "patch", n_pos=196, patch=16, in_dec=False),
+        tok("tok_rgb@224", 16384), tok("tok_normal@224", 8192), tok("tok_depth@224", 8192), tok("tok_semseg@224", 4096),
+        tok("tok_clip@224", 8192), ModSpec("human_poses", "seq", vocab=30000, n_pos=263, tensor_len=2 * (275 + 1)),   # max_tokens 275
+        tok("tok_dinov2@224", 8192, 14), tok("tok_dinov2_global", 8192, 56),
+        tok("tok_imagebind@224", 8192, 14), tok("tok_imagebind_global", 8192, 56), tok("tok_sam_edge@224", 8192),
+        tok("tok_canny_edge@224", 8192), seq("color_palette", 23), seq("sam_instance", 290),
+    ]
+
+
+MOD21_LEARNED_POS = ("tok_dinov2_global", "tok_imagebind_global")
+
+
 def named_cfg(size: str, mods: List[ModSpec]) -> TrunkCfg:
     table = {"tiny": (384, 6, 6), "small": (512, 8, 8), "base": (768, 12, 12), "large": (1024, 24, 16),
              "xlarge": (2048, 24, 32)}

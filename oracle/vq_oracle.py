@@ -80,11 +80,11 @@ def synthetic_images(cfg: VQCfg, batch: int, seed: int = 0) -> Tensor:
     return torch.rand(batch, cfg.channels, cfg.image, cfg.image, generator=g) * 2 - 1
 
 
-def vq_encode(P: Dict[str, Tensor], cfg: VQCfg, x: Tensor, emulate_bf16: bool = False, emulate_tail: bool = False):
+def vq_encode(P: Dict[str, Tensor], cfg: VQCfg, x: Tensor, emulate_bf16: bool = False):
     """Returns (quant (B, L, h, w), tokens (B, h, w) int64, latents z (B, h*w, L) before normalisation).
-    ``emulate_bf16`` rounds at the autocast points of the 12 blocks and the patch projection (the HIP
-    pipeline); ``emulate_tail`` also rounds the operands of the post-MLP and the 1x1 projection."""
-    num, tail = _Num(emulate_bf16), _Num(emulate_bf16 and emulate_tail)
+    ``emulate_bf16`` rounds at upstream's autocast points: the patch projection and the 12 blocks.  The post-MLP (autocast
+    disabled, vit_models.py:494-496), the 1x1 projection and the codebook search (quantize_lucid.py:388-390) stay fp32."""
+    num, tail = _Num(emulate_bf16), _Num(False)
     B, C, H, W = x.shape
     p, g = cfg.patch, H // cfg.patch
     # Conv2d(k = s = p): patches ordered (c, py, px) against weight.view(D, -1)

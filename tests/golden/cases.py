@@ -57,6 +57,10 @@ CASES = {
     # BASELINE.json configs[1]: the benched model (4M-B mod7, 12+12 blocks, D=768, hidden 2048), batch 2 of the same
     # 128+128-token batches (the fixture keeps summaries only)
     "b_mod7": dict(cfg=lambda: O.named_cfg("base", O.mod7_specs()), B=2, N=128, M=128, bud=(128, 128), seed=4),
+    # BASELINE.json configs[3]: 4M-L mod21 at FULL depth (24 + 24 blocks, D = 1024, hidden 2730, 19 input / 17 target modalities,
+    # 256 + 256 tokens), batch 1 (the fixture keeps summaries only; 1.27 G parameters are regenerated from seeds)
+    "l_mod21": dict(cfg=lambda: O.named_cfg("large", O.mod21_specs()), B=1, N=256, M=256, bud=(256, 256), seed=6,
+                    learned=O.MOD21_LEARNED_POS),
 }
 
 
@@ -64,7 +68,7 @@ def build_case(name: str):
     c = CASES[name]
     cfg = c["cfg"]()
     seed = c.get("seed", 1)
-    learned = ("tok_g",) if any(m.name == "tok_g" for m in cfg.mods) else ()
+    learned = c.get("learned", ("tok_g",) if any(m.name == "tok_g" for m in cfg.mods) else ())
     share = c.get("share_embedding", True)
     nb = c.get("norm_bias", False)
     sd = O.seeded_state_dict(cfg, seed=seed, share_embedding=share, learned_pos=learned, norm_bias=nb)

@@ -1,0 +1,95 @@
+"""BASELINE.json configs[3] at full size: 4M-L (24 + 24 blocks, D = 1024, hidden 2730 -> 2752) on the 21-modality mixture (19 input /
+17 target modalities incl. the T5-embedded caption (77 x 4096), ViT-B/14 16 x 16 token grids and the 16-token global modalities),
+per-GPU batch 64, 256 + 256 tokens (cfgs/default/4m/models/main/4m-l_mod21_500b.yaml:6-11,32) - through properties that need no
+CPU oracle (the B = 1 oracle / upstream comparison at full depth is the `l_mod21` case of tests/test_model_gpu.py):
+  * selection = stable partition of the 4481 concatenated positions, every modality id present;
+  * deterministic forward, loss at random init ~ mean log-vocabulary over the 17 heads;
+  * backward linear in the upstream gradient; every trainable tensor receives a finite gradient, none is identically zero;
+  * the workspace of the step stays inside the 288 GB of one MI355X (reported)."""
+import math
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N_TOK = 256
+
+
+@pytest.fixture(scope="module")
+def job():
+    import bench
+    from fourm.data.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    dev = torch.device("cuda", 0)
+    model = bench.build_model("fm_large_24e_24d_swiglu_nobias", dev, "mod21").train()
+    batch = synthetic_batch(model, 64, N_TOK, N_TOK, device=dev, seed=11)
+    yield model, batch
+    del model, batch
+    torch.cuda.empty_cache()
+
+
+def test_model_is_the_named_config(job):
+    model, batch = job
+    assert len(model.encoder_embeddings) == 19 and len(model.decoder_embeddings) == 17
+    assert model.dim == 1024 and len(model.encoder) == 24 and len(model.decoder) == 24
+    assert model.encoder[0].mlp.hidden_features == 2730
+    n = sum(p.numel() for p in {id(p): p for p in model.parameters()}.values())
+    assert abs(n - 1272.4e6) < 1e6, n                                   # 1272.4 M parameters
+    assert sum(d["tensor"].shape[1:].numel() if d["tensor"].dtype != torch.float32 else 0 for d in batch.values()) > 0
+    assert batch["t5_caption"]["tensor"].shape == (64, 77, 4096)
+    assert batch["tok_dinov2@224"]["tensor"].shape == (64, 16, 16) and batch["tok_dinov2_global"]["tensor"].shape == (64, 4, 4)
+
+
+def test_selection_is_a_stable_partition(job):
+    model, batch = job
+    with torch.no_grad():
+        tok, emb, mask, mod = model.forward_mask_encoder(batch, N_TOK)
+        cat_tok, cat_emb, cat_mask, cat_mod = model.cat_encoder_tensors(batch)
+    B = tok.shape[0]
+    assert cat_mask.shape[1] == 4481                                     # O = 4481 concatenated input positions
+    valid = ~cat_mask
+    order = torch.argsort((~valid).int(), dim=1, stable=True)[:, :N_TOK]
+    want_emb = torch.gather(cat_emb, 1, order[..., None].expand(-1, -1, 1024)).masked_fill(mask[:, 0, :, None], 0.0)
+    assert torch.equal(emb, want_emb)
+    want_mod = torch.gather(cat_mod, 1, order).masked_fill(mask[:, 0], -1)
+    assert torch.equal(mod, want_mod)
+    ids = {int(v["id"]) for k, v in model.modality_info.items() if k in model.encoder_embeddings}
+    assert set(mod.unique().tolist()) - {-1} == ids                     # every input modality contributes tokens
+    # gathered token rows: exact except the two dense projections (pixels, T5 rows: bf16 GEMMs on the gathered rows)
+    dense = torch.zeros_like(mod, dtype=torch.bool)
+    for name in ("rgb@224", "t5_caption"):
+        dense |= mod == int(model.modality_info[name]["id"])
+    want_tok = torch.gather(cat_tok, 1, order[..., None].expand(-1, -1, 1024)).masked_fill(mask[:, 0, :, None], 0.0)
+    assert torch.equal(tok[~dense], want_tok[~dense])
+    assert float((tok[dense] - want_tok[dense]).norm() / want_tok[dense].norm()) < 1e-2
+
+
+def test_forward_deterministic_backward_linear(job):
+    model, batch = job
+    with torch.no_grad():
+        random.seed(3); l1, m1 = model(batch, N_TOK, N_TOK)
+        random.seed(3); l2, m2 = model(batch, N_TOK, N_TOK)
+    assert torch.equal(l1, l2) and all(torch.equal(m1[k], m2[k]) for k in m1)
+    assert len(m1) == 17
+    for name, v in m1.items():
+        assert abs(float(v) - math.log(model.decoder_embeddings[name].vocab_size)) < 0.5, (name, float(v))
+    model.zero_grad(set_to_none=True)
+    random.seed(3); loss, _ = model(batch, N_TOK, N_TOK); loss.backward()
+    eng = model.engine
+    g1 = eng.flat_grads.detach().clone()
+    assert torch.isfinite(g1).all()
+    for n, p in model.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) > 0, n      # no parameter is left without gradient
+    model.zero_grad(set_to_none=True)
+    random.seed(3); loss, _ = model(batch, N_TOK, N_TOK); (0.25 * loss).backward()
+    err = float((eng.flat_grads - 0.25 * g1).norm() / (0.25 * g1).norm())
+    assert err < 3e-3, err
+    gb = eng.ws.nbytes() / 2 ** 30
+    from tests.parity_log import record
+    record("fullsize.l_mod21", workspace_GiB=gb, params_GiB=eng.flat_params.numel() * 4 / 2 ** 30, loss=float(l1))
+    assert gb < 200, gb

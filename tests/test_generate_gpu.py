@@ -1,0 +1,116 @@
+"""Generation step: the sampling kernels bit-exact against the numpy oracle, and one MaskGIT step of
+``GenerationSampler`` (upstream generate.py:628-661) against the CPU oracle pipeline."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fourm_oracle as O
+from oracle import sample_oracle as S
+from tests.golden.cases import build_case
+from tests.parity_log import record
+from tests.util_model import build_hip_model, tie
+
+pytestmark = pytest.mark.gpu
+
+
+def sampler(model=None):
+    from fourm.models.generate import GenerationSampler
+    return GenerationSampler(model)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("V", [64, 1000, 16384, 30000])
+def test_sample_tokens_bit_exact(V, dtype):
+    """Same logits + same uniforms -> the same token ids as oracle/sample_oracle.py, bit for bit, for every filter combination."""
+    g = torch.Generator().manual_seed(V)
+    R = 48
+    logits = (torch.randn(R, V, generator=g) * 2.5).to(dtype)
+    logits[3] = logits[3, 0]                                   # a constant row: everything ties
+    logits[5, 17] = 40.0                                       # a row dominated by one entry
+    u = torch.rand(R, generator=g)
+    u[0], u[1] = 0.0, 0.99999994                               # the ends of the CDF
+    smp = sampler()
+    lf = logits.float().numpy()
+    bad = []
+    for temperature, top_k, top_p in [(1.0, 0, 0.0), (0.7, 50, 0.0), (1.0, 0, 0.9), (0.5, 100, 0.8), (1.3, 0.01, 0.95), (0.0, 0, 0.0), (1.0, 1, 0.0)]:
+        ids, probs = smp.sample_tokens(logits.cuda(), temperature, top_k, top_p, uniforms=u.cuda())
+        k = smp._top_k_int(top_k, V)
+        want_ids, want_p = S.sample_tokens(lf, temperature, k, top_p, u.numpy())
+        if not np.array_equal(ids.cpu().numpy(), want_ids):
+            bad.append(("ids", temperature, top_k, top_p, np.nonzero(ids.cpu().numpy() != want_ids)[0][:5].tolist()))
+        if not np.array_equal(probs.cpu().numpy(), want_p):
+            bad.append(("probs", temperature, top_k, top_p, float(np.abs(probs.cpu().numpy() - want_p).max())))
+    assert not bad, bad
+    # statistics: frequencies follow softmax(logits / T) restricted to the nucleus
+    row = logits[7:8].float()
+    rep = row.repeat(8192, 1).cuda()
+    ids, _ = smp.sample_tokens(rep, 1.0, 20, 0.0, generator=torch.Generator(device="cuda").manual_seed(1))
+    keep = S.survivors(row[0].numpy(), 20, 0.0)
+    p = torch.softmax(row[0].masked_fill(~torch.from_numpy(keep), float("-inf")), -1)
+    freq = torch.bincount(ids.cpu(), minlength=V).float() / 8192
+    assert float((freq - p).abs().max()) < 0.03 and float(freq[~torch.from_numpy(keep)].sum()) == 0.0
+
+
+def gen_mod_dict(cfg, B, target, seed=0, cond_tokens=24):
+    """Conditioning: ``cond_tokens`` visible inputs spread over the other modalities; target modality fully masked, to be decoded."""
+    md = O.synthetic_mod_dict(cfg, B, cond_tokens, 0, seed=seed, no_target=tuple(m.name for m in cfg.mods))
+    for name, d in md.items():
+        d["target_mask"][:] = True
+    t = md[target]
+    t["input_mask"][:] = True
+    t["target_mask"][:] = False
+    return md
+
+
+@pytest.mark.parametrize("case_name,target", [("micro_swiglu", "tok_a@32"), ("ti_mod7", "tok_depth@224")])
+def test_maskgit_step(case_name, target):
+    case = build_case(case_name)
+    cfg = case["cfg"]
+    model = build_hip_model(cfg, case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    model.load_state_dict(case["sd"], strict=True)
+    model = model.cuda().eval()
+    P = tie({k: v.clone() for k, v in case["sd"].items()}, cfg, case["share_embedding"])
+    B = 3
+    md = gen_mod_dict(cfg, B, target)
+    dev_md = {k: {a: b.cuda() for a, b in v.items()} for k, v in md.items()}
+    smp = sampler(model)
+    logits, mod_pos = smp.forward_enc_dec_maskgit_batched(dev_md, target)
+    spec = cfg.mod(target)
+    Npos = spec.n_pos
+    assert tuple(logits.shape) == (B, Npos, spec.vocab) and torch.equal(mod_pos.cpu(), torch.arange(Npos, dtype=torch.int32)[None].expand(B, -1))
+    # ---- oracle: the same forward from the restated pieces (bf16 rounding at the autocast points) ----
+    num = O._Num(True)
+    with torch.no_grad():
+        n_enc = max(int(sum((~md[m.name]["input_mask"].reshape(B, -1)[b]).sum() for m in cfg.mods if m.in_enc)) for b in range(B))
+        enc = O.select_encoder(P, cfg, md, n_enc, num)
+        x = O.encoder_forward(P, cfg, enc["tokens"] + enc["emb"], enc["mask"], num)
+        ctx = num.linear(x, P["decoder_proj_context.weight"], P["decoder_proj_context.bias"]) + enc["emb"]
+        _, e, _ = O.embed_decoder_modality(P, spec, md[target])
+        y0 = P["mask_token"].expand(B, Npos, -1) + e.float()
+        y = O.decoder_forward(P, cfg, y0, ctx, enc["mask"], None, num)
+        want = num.linear(y, P[f"decoder_embeddings.{target}.to_logits.weight"], None)
+    err = float((logits.float().cpu() - want).norm() / want.norm())
+    record("generate.maskgit_logits", case=case_name, rel=err)
+    assert err < 1.2e-2, err                                     # two bf16 pipelines (see test_model_gpu.LOGIT_BOUNDS)
+    # ---- sampling + commit: bit-exact given the kernel's own logits and the same uniforms ----
+    u = torch.rand(B * Npos, generator=torch.Generator().manual_seed(5))
+    num_select = max(1, Npos // 4)
+    lf = logits.float().cpu().numpy().reshape(B * Npos, -1).copy()
+    before = {k: v.clone() for k, v in dev_md[target].items()}
+    smp.maskgit_step_batched(dev_md, target, num_select, 0.8, 30, 0.9, uniforms=u.cuda())
+    ids, probs = S.sample_tokens(lf, 0.8, 30, 0.9, u.numpy())
+    st = smp.last_step
+    assert np.array_equal(st["samples"].cpu().numpy().reshape(-1), ids)
+    t = before["tensor"].cpu().numpy().reshape(B, -1).copy()
+    im, tmk = before["input_mask"].cpu().numpy().reshape(B, -1).copy(), before["target_mask"].cpu().numpy().reshape(B, -1).copy()
+    top = S.maskgit_commit(probs.reshape(B, Npos), ids.reshape(B, Npos), mod_pos.cpu().numpy(), num_select, t, im, tmk)
+    assert np.array_equal(st["top_indices"].cpu().numpy(), top)
+    assert np.array_equal(dev_md[target]["tensor"].cpu().numpy().reshape(B, -1), t)
+    assert np.array_equal(dev_md[target]["input_mask"].cpu().numpy().reshape(B, -1), im)
+    assert np.array_equal(dev_md[target]["target_mask"].cpu().numpy().reshape(B, -1), tmk)
+    assert int(tmk.sum()) == B * num_select and int((~im).sum()) == B * num_select
+    # ---- the whole schedule: every position decoded after the last step, ids inside the vocabulary ----
+    smp.generate_maskgit(dev_md, target, num_steps=3, temperature=1.0, top_k=0, top_p=0.0, generator=torch.Generator(device="cuda").manual_seed(2))
+    assert bool(dev_md[target]["target_mask"].all()) and not bool(dev_md[target]["input_mask"].any())
+    tk = dev_md[target]["tensor"]
+    assert int(tk.min()) >= 0 and int(tk.max()) < spec.vocab

@@ -17,7 +17,7 @@ from tests.util_model import build_hip_model, tie, to_device
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "micro_qknorm", "ti_mod7", "l_like", "b_mod7"]
+HIP_CASES = ["micro_swiglu", "micro_pad", "micro_gelu", "micro_qknorm", "ti_mod7", "l_like", "b_mod7", "l_mod21"]
 
 
 def setup(name):
@@ -111,10 +111,10 @@ def test_loss_and_gradients(name):
 #   micro_swiglu                    7.2e-3               7.6e-3        7.6e-3
 #   ti_mod7  (4M-Ti, 6+6)           5.6e-3               7.4e-3        7.5e-3
 #   b_mod7   (4M-B, 12+12, benched) 5.9e-3               9.7e-3        9.6e-3
-LOGIT_BOUNDS = {"micro_swiglu": (1.4e-2, 1.5e-2), "ti_mod7": (1.1e-2, 1.5e-2), "b_mod7": (1.2e-2, 1.9e-2)}
+LOGIT_BOUNDS = {"micro_swiglu": (1.4e-2, 1.5e-2), "ti_mod7": (1.1e-2, 1.5e-2), "b_mod7": (1.2e-2, 1.9e-2), "l_mod21": (3e-2, 3e-2)}
 
 
-@pytest.mark.parametrize("name", ["micro_swiglu", "ti_mod7", "b_mod7"])
+@pytest.mark.parametrize("name", ["micro_swiglu", "ti_mod7", "b_mod7", "l_mod21"])
 def test_logits(name):
     g, case, model = setup(name)
     cfg = case["cfg"]

@@ -93,14 +93,21 @@ def test_tokenize_end_to_end(name):
     z = model._last_latents.float().cpu()
     ref = torch.from_numpy(g["latents"])
     rel = float((z - ref).norm() / ref.norm())
-    assert rel < 3e-2, rel                                                   # bf16 ViT vs fp32 upstream latents
-    # against the oracle run with the same bf16 rounding points: tight
-    _, tok_bf, z_bf = V.vq_encode(sd, cfg, x, emulate_bf16=True, emulate_tail=True)
-    assert float((z - z_bf).norm() / z_bf.norm()) < 6e-3
+    assert rel < 3e-2, rel                                                   # bf16 ViT blocks vs the all-fp32 upstream latents
+    # against the oracle with upstream's autocast rounding points (bf16 in the 12 blocks, fp32 post-MLP / projection /
+    # search - no deviation switched into the checker any more)
+    _, tok_bf, z_bf = V.vq_encode(sd, cfg, x, emulate_bf16=True)
+    rel_bf = float((z - z_bf).norm() / z_bf.norm())
     agree_fp32 = float((tokens.cpu() == torch.from_numpy(g["tokens"]).long()).float().mean())
     agree_bf16 = float((tokens.cpu() == tok_bf).float().mean())
-    # upstream measured 97.1 % agreement between its own bf16-autocast and fp32 encoders
-    assert agree_fp32 > 0.85 and agree_bf16 > 0.93, (agree_fp32, agree_bf16)
+    oracle_self = float((tok_bf == torch.from_numpy(g["tokens"]).long()).float().mean())      # the reference's own autocast-vs-fp32 figure
+    from tests.parity_log import record
+    record("vq.tokenize", case=name, latent_rel_vs_fp32=rel, latent_rel_vs_autocast_oracle=rel_bf, token_agreement_vs_fp32=agree_fp32,
+           token_agreement_vs_autocast_oracle=agree_bf16, oracle_autocast_vs_fp32=oracle_self)
+    assert rel_bf < 8e-3, rel_bf
+    # upstream measured 97.1 % agreement between its own bf16-autocast and fp32 encoders on real images; with the
+    # seeded random weights of this fixture the autocast oracle agrees with fp32 at `oracle_self`
+    assert agree_fp32 > 0.95 * oracle_self and agree_fp32 > 0.9 and agree_bf16 > 0.93, (agree_fp32, agree_bf16, oracle_self)
     # every disagreement with the bf16-emulating oracle is a near tie in that oracle's similarities
     en = torch.nn.functional.normalize(sd["quantize._codebook.embed"], dim=-1)
     sims = torch.nn.functional.normalize(z_bf.reshape(-1, cfg.latent), dim=-1) @ en.t()
