@@ -2,7 +2,7 @@
 17 target modalities incl. the T5-embedded caption (77 x 4096), ViT-B/14 16 x 16 token grids and the 16-token global modalities),
 per-GPU batch 64, 256 + 256 tokens (cfgs/default/4m/models/main/4m-l_mod21_500b.yaml:6-11,32) - through properties that need no
 CPU oracle (the B = 1 oracle / upstream comparison at full depth is the `l_mod21` case of tests/test_model_gpu.py):
-  * selection = stable partition of the 4481 concatenated positions, every modality id present;
+  * selection = stable partition of the ~4.5 k concatenated input positions, every modality id present;
   * deterministic forward, loss at random init ~ mean log-vocabulary over the 17 heads;
   * backward linear in the upstream gradient; every trainable tensor receives a finite gradient, none is identically zero;
   * the workspace of the step stays inside the 288 GB of one MI355X (reported)."""
@@ -51,7 +51,9 @@ def test_selection_is_a_stable_partition(job):
         tok, emb, mask, mod = model.forward_mask_encoder(batch, N_TOK)
         cat_tok, cat_emb, cat_mask, cat_mod = model.cat_encoder_tensors(batch)
     B = tok.shape[0]
-    assert cat_mask.shape[1] == 4481                                     # O = 4481 concatenated input positions
+    # concatenated input positions: 7 x 196 + 2 x 256 + 2 x 16 grid cells, 77 T5 rows, six padded id sequences of 2 * (max_length + 1)
+    # (SURVEY §8 counts 4481 with the loader's max_tokens = 275 for human_poses; the synthetic batch uses max_length = 263)
+    assert cat_mask.shape[1] == 7 * 196 + 2 * 256 + 2 * 16 + 77 + 2 * (257 + 257 + 41 + 264 + 24 + 291)
     valid = ~cat_mask
     order = torch.argsort((~valid).int(), dim=1, stable=True)[:, :N_TOK]
     want_emb = torch.gather(cat_emb, 1, order[..., None].expand(-1, -1, 1024)).masked_fill(mask[:, 0, :, None], 0.0)
