@@ -51,9 +51,9 @@ def test_selection_is_a_stable_partition(job):
         tok, emb, mask, mod = model.forward_mask_encoder(batch, N_TOK)
         cat_tok, cat_emb, cat_mask, cat_mod = model.cat_encoder_tensors(batch)
     B = tok.shape[0]
-    # concatenated input positions: 7 x 196 + 2 x 256 + 2 x 16 grid cells, 77 T5 rows, six padded id sequences of 2 * (max_length + 1)
+    # concatenated input positions: 8 x 196 + 2 x 256 + 2 x 16 grid cells, 77 T5 rows, six padded id sequences of 2 * (max_length + 1)
     # (SURVEY §8 counts 4481 with the loader's max_tokens = 275 for human_poses; the synthetic batch uses max_length = 263)
-    assert cat_mask.shape[1] == 7 * 196 + 2 * 256 + 2 * 16 + 77 + 2 * (257 + 257 + 41 + 264 + 24 + 291)
+    assert cat_mask.shape[1] == 8 * 196 + 2 * 256 + 2 * 16 + 77 + 2 * (257 + 257 + 41 + 264 + 24 + 291)
     valid = ~cat_mask
     order = torch.argsort((~valid).int(), dim=1, stable=True)[:, :N_TOK]
     want_emb = torch.gather(cat_emb, 1, order[..., None].expand(-1, -1, 1024)).masked_fill(mask[:, 0, :, None], 0.0)
