@@ -68,6 +68,10 @@ int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
  * epilogues); bits 24-27 (when non-zero) = its choice for the SwiGLU epilogue. */
 void fm_set_gemm_nt_config(int cfg);
 int fm_get_gemm_nt_config(void);
+/* Compute units the persistent GEMM grids leave free (default 0; env FOURM_RESERVED_CUS): set by the data-parallel wrapper so that
+ * RCCL's kernels find CUs while a gradient bucket is exchanged under the backward GEMMs (upstream: DDP overlap, run_training_4m.py:512). */
+void fm_set_reserved_cus(int n);
+int fm_get_reserved_cus(void);
 
 /* out[n][k] += sum_r A[r][n] * B[r][k]   (fp32 atomic accumulation, reduction split over blocks).
  * Replaces the weight-gradient matmul autograd runs for nn.Linear (dW = dY^T X).
@@ -268,6 +272,8 @@ int fm_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int rows, in
 int fm_transpose_cast_pad(const void* src, int ld_src, void* dst, int ld_dst, int dst_cols, int rows, int cols, void* stream);
 int fm_colsum(const void* dy, int ldy, void* db, int R, int N, void* stream);            /* db[n] += sum_r dy[r][n] */
 int fm_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream);
+/* dst(f32)[i] = scale * src(bf16)[i]: unpacks a gradient bucket that travelled in bf16 (optional wire format of the exchange) */
+int fm_bf16_to_f32_scaled(const void* src, void* dst, int64_t n, float scale, void* stream);
 /* torch.optim.AdamW update on a contiguous fp32 range (fourm/utils/optim_factory.py:239-240);
  * grad_mult: optional device scalar multiplied into the gradient (clipping). */
 int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,

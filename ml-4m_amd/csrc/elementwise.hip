@@ -328,6 +328,18 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void bf16_to_f32_scaled_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n, float scale) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+        if (i + 4 <= n) {
+            const uint2 p = *(const uint2*)(src + i);
+            *(float4*)(dst + i) = make_float4(scale * bf2f((bf16_t)(p.x & 0xffff)), scale * bf2f((bf16_t)(p.x >> 16)),
+                                              scale * bf2f((bf16_t)(p.y & 0xffff)), scale * bf2f((bf16_t)(p.y >> 16)));
+        } else {
+            for (size_t j = i; j < n; ++j) dst[j] = scale * bf2f(src[j]);
+        }
+    }
+}
+
 inline int grid_for(size_t work_items) {
     size_t g = (work_items + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;
@@ -422,6 +434,14 @@ extern "C" int fm_clip_coef(const void* sumsq, float max_norm, void* norm_out, v
     FM_CHECK_ARG(sumsq && norm_out, "fm_clip_coef: null pointer");
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const float*)sumsq, max_norm, (float*)norm_out, (float*)coef_out);
     FM_CHECK_LAUNCH("fm_clip_coef");
+    return 0;
+}
+
+extern "C" int fm_bf16_to_f32_scaled(const void* src, void* dst, int64_t n, float scale, void* stream) {
+    FM_CHECK_ARG(src && dst && n > 0 && (((uintptr_t)dst) & 15) == 0 && (((uintptr_t)src) & 7) == 0, "fm_bf16_to_f32_scaled: bad argument");
+    hipLaunchKernelGGL(bf16_to_f32_scaled_kernel, dim3(grid_for((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       (float*)dst, (size_t)n, scale);
+    FM_CHECK_LAUNCH("fm_bf16_to_f32_scaled");
     return 0;
 }
 

@@ -791,13 +791,18 @@ int g_nt_config = 9, g_nt_prio = 1;
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
+// Compute units the persistent GEMM grids may occupy.  With a gradient exchange in flight (fourm.parallel.DataParallel) RCCL's own
+// kernels need CUs: a persistent grid that holds every CU for the whole launch would serialise the collective behind each GEMM
+// instead of overlapping it, so the data-parallel wrapper reserves a few (fm_set_reserved_cus; multiples of 8 = whole XCD slices).
+int g_reserved_cus = [] { const char* e = getenv("FOURM_RESERVED_CUS"); return e ? atoi(e) : 0; }();
 static int n_compute_units() {
     static int n = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         return cus;
     }();
-    return n;
+    const int avail = n - g_reserved_cus;
+    return avail >= 64 ? avail / 8 * 8 : n;
 }
 
 template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false, bool PERSIST = false>
@@ -937,6 +942,8 @@ extern "C" void fm_set_gemm_nt_config(int cfg) {
     if ((cfg >> 24) & 0xf) g_nt_swiglu = (cfg >> 24) & 0xf;                                             // bits 24-27: the SwiGLU choice
 }
 extern "C" int fm_get_gemm_nt_config(void) { return g_nt_config; }
+extern "C" void fm_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
+extern "C" int fm_get_reserved_cus(void) { return g_reserved_cus; }
 static int g_tn_config = 1;
 extern "C" void fm_set_gemm_tn_config(int cfg) { g_tn_config = cfg; }
 extern "C" int fm_get_gemm_tn_config(void) { return g_tn_config; }
@@ -963,7 +970,7 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     constexpr int TN_TA = 128, TN_TB = 256, TN_STAGES = 3;
     // (the grouped head GEMM keeps configuration 0: short, uneven reductions - 940 vs 1110 us at the 4M-B shapes)
     const bool pp = g_tn_config == 1 && !grouped && p->force_tr != 0;
-    const int kb = pp ? 64 : 32, slots = pp ? 256 : 512;
+    const int kb = pp ? 64 : 32, slots = (pp ? 1 : 2) * n_compute_units();
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
     if (splits <= 0) {

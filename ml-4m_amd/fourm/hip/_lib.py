@@ -141,6 +141,9 @@ shadow_refresh = _sig("fm_shadow_refresh", vp, i32, i32, vp)
 headnorm_fwd = _sig("fm_headnorm_fwd", vp, i32, vp, vp, vp, i32, vp, i32, i32, C.c_float, vp)
 headnorm_bwd = _sig("fm_headnorm_bwd", vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp)
 f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
+bf16_to_f32_scaled = _sig("fm_bf16_to_f32_scaled", vp, vp, i64, f32, vp)
+lib.fm_set_reserved_cus.argtypes = [C.c_int]
+lib.fm_get_reserved_cus.restype = C.c_int
 adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp)
 adamw_shadow = _sig("fm_adamw_shadow", vp, i32, i32, f32, f32, f32, f32, f32, i64, vp, vp)
 sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
@@ -166,7 +169,7 @@ lib.fm_set_gemm_tn_config.argtypes = [C.c_int]
 lib.fm_set_attn_transpose_read.argtypes = [C.c_int]
 
 lib.fm_set_gemm_nt_config.argtypes = [C.c_int]
-EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_gemm_tn", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
+EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_gemm_tn", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",

@@ -351,6 +351,11 @@ def f32_to_bf16(src, dst):
     return dst
 
 
+def bf16_to_f32_scaled(src, dst, scale=1.0):
+    L.check(L.bf16_to_f32_scaled(_p(src), _p(dst), src.numel(), float(scale), _stream()))
+    return dst
+
+
 def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None):
     L.check(L.adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _stream()))
 

@@ -22,16 +22,30 @@ import torch.nn as nn
 
 
 class GradReducer:
-    """All-reduce (mean) of slices of a flat gradient buffer, launched stage by stage.
+    """Mean of slices of a flat gradient buffer across the ranks, launched stage by stage.
 
     ranges_by_stage: {stage: [(offset, length), ...]} in elements of ``flat``.  Adjacent ranges are
-    merged; ranges larger than ``bucket_elems`` are split so that several collectives are in flight."""
+    merged; ranges larger than ``bucket_elems`` are split so that several collectives are in flight.
+
+    algorithm  "all_reduce" (default) | "reduce_scatter": reduce-scatter + all-gather of each bucket (the bucket's head of
+               length numel // world * world; the tail goes through all_reduce) - the same bytes as a ring all-reduce, issued as
+               the two collectives a sharded optimizer would split apart.
+    wire_dtype None (fp32 on the wire) | torch.bfloat16: the bucket is packed to bf16 on the compute stream, exchanged, and unpacked
+               (x 1/world) into the fp32 store; accumulation ACROSS ranks is then in bf16 (upstream's FSDP script reduces in bf16
+               too, run_training_4m_fsdp.py:528), half the xGMI bytes.
+    force      run the collectives even at world size 1 (tests of the RCCL code path on one GPU)."""
 
     def __init__(self, flat: torch.Tensor, ranges_by_stage: Dict[str, Sequence[Tuple[int, int]]], group=None,
-                 bucket_elems: int = 64 * 1024 * 1024):
+                 bucket_elems: int = 64 * 1024 * 1024, algorithm: str = "all_reduce", wire_dtype=None, force: bool = False):
+        if algorithm not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"algorithm {algorithm!r}")
+        if wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("wire_dtype: None / torch.float32 / torch.bfloat16")
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_elems = bucket_elems
+        self.algorithm, self.force = algorithm, force
+        self.wire = torch.bfloat16 if wire_dtype == torch.bfloat16 else None
         self.stages = {s: self._merge(r) for s, r in ranges_by_stage.items()}
         covered = sorted((o, n) for r in self.stages.values() for o, n in r)
         for (o1, n1), (o2, _) in zip(covered, covered[1:]):
@@ -41,6 +55,8 @@ class GradReducer:
         self._done = set()
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"          # RCCL averages in the collective; gloo has no AVG
+        self._wire_bufs = {}                   # (offset, length) -> bf16 staging buffer, allocated once
+        self._shards = {}
 
     def _merge(self, ranges):
         out = []
@@ -62,23 +78,50 @@ class GradReducer:
     def begin(self):
         self._pending, self._done = [], set()
 
+    def _exchange(self, t: torch.Tensor, op):
+        """Asynchronous collectives that leave the cross-rank reduction of ``t`` in ``t``; returns the work handles."""
+        if self.algorithm == "reduce_scatter" and t.numel() >= self.world:
+            head = t.numel() // self.world * self.world
+            key = (t.data_ptr(), head)
+            shard = self._shards.get(key)
+            if shard is None:
+                shard = self._shards[key] = torch.empty(head // self.world, dtype=t.dtype, device=t.device)
+            works = [dist.reduce_scatter_tensor(shard, t[:head], op=op, group=self.group, async_op=True)]
+            works.append(dist.all_gather_into_tensor(t[:head], shard, group=self.group, async_op=True))
+            if head < t.numel():
+                works.append(dist.all_reduce(t[head:], op=op, group=self.group, async_op=True))
+            return works
+        return [dist.all_reduce(t, op=op, group=self.group, async_op=True)]
+
     def stage_done(self, stage: str):
         """Gradients of ``stage`` are final on the compute stream: start their exchange."""
-        if self.world == 1 or stage in self._done or stage not in self.stages:
+        if (self.world == 1 and not self.force) or stage in self._done or stage not in self.stages:
             return
         self._done.add(stage)
         for o, n in self.stages[stage]:
             t = self.flat[o:o + n]
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            self._pending.append((dist.all_reduce(t, op=op, group=self.group, async_op=True), t))
+            if self.wire is not None:
+                from fourm.hip import ops
+                w = self._wire_bufs.get((o, n))
+                if w is None:
+                    w = self._wire_bufs[(o, n)] = torch.empty(n, dtype=self.wire, device=t.device)
+                ops.f32_to_bf16(t, w)                                   # pack on the compute stream, behind the gradient kernels
+                self._pending.append((self._exchange(w, dist.ReduceOp.SUM), t, w))
+            else:
+                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+                self._pending.append((self._exchange(t, op), t, None))
 
     def finish(self):
         """Launch whatever stage has not been reported, then wait for every collective."""
         for s in self.stages:
             self.stage_done(s)
-        for work, t in self._pending:
-            work.wait()
-            if not self._avg:
+        for works, t, w in self._pending:
+            for work in works:
+                work.wait()
+            if w is not None:
+                from fourm.hip import ops
+                ops.bf16_to_f32_scaled(w, t, 1.0 / self.world)          # unpack + mean into the fp32 gradient store
+            elif not self._avg:
                 t.div_(self.world)
         self._pending = []
 
@@ -91,12 +134,23 @@ class DataParallel(nn.Module):
     gradients only accumulate locally; the first backward outside it exchanges the accumulated mean."""
 
     def __init__(self, module: nn.Module, device_ids=None, find_unused_parameters: bool = False, process_group=None,
-                 bucket_mb: int = 256):
+                 bucket_mb: int = 256, algorithm: str = "all_reduce", wire_dtype=None, reserved_cus: Optional[int] = None,
+                 force_collectives: bool = False):
+        """``reserved_cus``: compute units the persistent GEMM grids leave to RCCL while gradients are exchanged under the backward
+        (env FOURM_DP_RESERVED_CUS).  Default 0: a persistent GEMM workgroup uses 512 of a CU's 2048 thread slots, <= 144 of 160 KB
+        of LDS and ~400 of 512 VGPRs per SIMD, so RCCL's small workgroups can be co-resident on the same CUs; reserving whole CUs
+        breaks the tile quantisation of the 4M-B shapes (768 tiles on 256 CUs = 3 rounds, on 248 CUs = 4): measured +5.5 % step
+        time at 8 reserved CUs, +6.4 % at 16 on one GPU (profiles/r02_reserved_cus.txt)."""
         super().__init__()
+        import os
         self.module = module
         self.process_group = process_group
         self._sync = True
         self._bucket_elems = bucket_mb * 1024 * 1024 // 4
+        self._algorithm, self._wire, self._force = algorithm, wire_dtype, force_collectives
+        if reserved_cus is None:
+            reserved_cus = int(os.environ.get("FOURM_DP_RESERVED_CUS", "0"))
+        self._reserved_cus = reserved_cus
         self._reducer: Optional[GradReducer] = None
         self._reducer_for = None
         if dist.is_initialized() and dist.get_world_size(process_group) > 1:
@@ -118,12 +172,16 @@ class DataParallel(nn.Module):
         eng = self.module.engine
         eng._ensure_flat()
         if self._reducer is None or self._reducer_for is not eng.flat_grads:
-            self._reducer = GradReducer(eng.flat_grads, eng.grad_stages(), self.process_group, self._bucket_elems)
+            self._reducer = GradReducer(eng.flat_grads, eng.grad_stages(), self.process_group, self._bucket_elems,
+                                        algorithm=self._algorithm, wire_dtype=self._wire, force=self._force)
             self._reducer_for = eng.flat_grads
+            if eng.flat_grads.is_cuda and dist.get_backend(self.process_group) == "nccl":
+                from fourm.hip import _lib
+                _lib.lib.fm_set_reserved_cus(self._reserved_cus)       # RCCL's kernels run beside the persistent GEMM grids
         eng.reducer = self._reducer if self._sync else None
 
     def forward(self, *args, **kwargs):
-        if torch.is_grad_enabled() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+        if torch.is_grad_enabled() and dist.is_initialized() and (dist.get_world_size(self.process_group) > 1 or self._force):
             self._attach()
         elif hasattr(self.module, "_engine") and self.module._engine is not None:
             self.module._engine.reducer = None

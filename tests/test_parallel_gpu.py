@@ -95,5 +95,48 @@ def test_data_parallel_two_processes_one_gpu(tmp_path):
         assert torch.equal(torch.load(tmp_path / f"params_r{r}.pt"), ref_params)
 
 
+def nccl_worker(port, out_dir):
+    """World size 1 on RCCL with the collectives FORCED: ReduceOp.AVG, the async hand-off to RCCL's stream, reduce-scatter +
+    all-gather, the bf16 wire format and the CU reservation all execute; with one rank every exchange is the identity."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from fourm.hip import _lib
+    from fourm.parallel import DataParallel
+    case = build_case(CASE)
+    res = {}
+    for name, kw in (("allreduce_fp32", {}), ("rs_ag_fp32", dict(algorithm="reduce_scatter")),
+                     ("allreduce_bf16", dict(wire_dtype=torch.bfloat16)), ("rs_ag_bf16", dict(algorithm="reduce_scatter", wire_dtype=torch.bfloat16))):
+        model = _model(case)
+        want = _local_grads(model, case, 0, [0]).cpu()
+        model.zero_grad(set_to_none=True)
+        dp = DataParallel(model, force_collectives=True, bucket_mb=1, reserved_cus=16, **kw)
+        random.seed(7)
+        dp(_batch(case, 0, 0), case["N"], case["M"])[0].backward()
+        torch.cuda.synchronize()
+        red = model.engine.reducer
+        assert red is not None and len(red._done) >= 1 and ("wire_dtype" not in kw or len(red._wire_bufs) >= 1)      # the stages did exchange
+        assert _lib.lib.fm_get_reserved_cus() == 16
+        got = model.engine.flat_grads.detach().cpu()
+        res[name] = float((got - want).norm() / want.norm())
+    torch.save(res, os.path.join(out_dir, "nccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_code_path_world_size_one(tmp_path):
+    """The backend 'nccl' (= RCCL) branch of the exchange on the one GPU a test box has (it had never executed)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {**os.environ, "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "ml-4m_amd"), os.environ.get("PYTHONPATH", "")])}
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "nccl", str(port), str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    res = torch.load(tmp_path / "nccl.pt")
+    assert res["allreduce_fp32"] < 1e-6 and res["rs_ag_fp32"] < 1e-6, res          # identity (atomic order noise of the backward only)
+    assert res["allreduce_bf16"] < 4e-3 and res["rs_ag_bf16"] < 4e-3, res          # one bf16 rounding of every gradient
+    assert res["allreduce_bf16"] > 1e-4                                             # ... which did happen
+
+
 if __name__ == "__main__":
-    worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    if sys.argv[1] == "nccl":
+        nccl_worker(int(sys.argv[2]), sys.argv[3])
+    else:
+        worker(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
