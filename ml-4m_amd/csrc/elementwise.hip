@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // grad_mult (device scalar, optional) = gradient clipping coefficient.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     size_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    const float* __restrict__ grad_mult) {
+                                                    const float* __restrict__ grad_mult, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; wd = hyper[1]; bc1 = hyper[2]; bc2_sqrt = hyper[3]; }      // captured launches: values live on the device
     const float gm = grad_mult ? grad_mult[0] : 1.0f;
     const float step = lr / bc1;
     auto update = [&](float& pe, float& me, float& ve, float ge) {
@@ -235,7 +236,8 @@ constexpr int ADAMW_CHUNK = 8192;           // elements per tile: 256 threads x 
 
 __global__ __launch_bounds__(256) void adamw_shadow_kernel(const fm_adamw_job* __restrict__ jobs, int n, int total_tiles, float lr, float beta1,
                                                            float beta2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                           const float* __restrict__ grad_mult) {
+                                                           const float* __restrict__ grad_mult, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; wd = hyper[1]; bc1 = hyper[2]; bc2_sqrt = hyper[3]; }
     const float gm = grad_mult ? grad_mult[0] : 1.0f;
     const float step = lr / bc1;
     auto update = [&](float& pe, float& me, float& ve, float ge) {
@@ -402,23 +404,24 @@ extern "C" int fm_colsum(const void* dy, int ldy, void* db, int R, int N, void* 
 }
 
 extern "C" int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int64_t step, const void* grad_mult, void* stream) {
+                        float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* stream) {
     FM_CHECK_ARG(p && g && m && v && n > 0 && step > 0, "fm_adamw: bad argument");
     FM_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "fm_adamw: buffers must be 16-byte aligned");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (float*)p, (const float*)g, (float*)m,
-                       (float*)v, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult);
+                       (float*)v, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult,
+                       (const float*)hyper);
     FM_CHECK_LAUNCH("fm_adamw");
     return 0;
 }
 
 extern "C" int fm_adamw_shadow(const fm_adamw_job* jobs, int n_jobs, int total_tiles, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int64_t step, const void* grad_mult, void* stream) {
+                               float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* stream) {
     FM_CHECK_ARG(jobs && n_jobs > 0 && total_tiles > 0 && step > 0, "fm_adamw_shadow: bad argument");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const int blocks = total_tiles < 8192 ? total_tiles : 8192;
     hipLaunchKernelGGL(adamw_shadow_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs, total_tiles, lr, beta1, beta2, eps,
-                       weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult);
+                       weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult, (const float*)hyper);
     FM_CHECK_LAUNCH("fm_adamw_shadow");
     return 0;
 }

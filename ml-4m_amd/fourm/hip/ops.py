@@ -356,8 +356,8 @@ def bf16_to_f32_scaled(src, dst, scale=1.0):
     return dst
 
 
-def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None):
-    L.check(L.adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _stream()))
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None):
+    L.check(L.adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _p(hyper), _stream()))
 
 
 ADAMW_CHUNK = 8192   # FM_ADAMW_CHUNK
@@ -387,8 +387,8 @@ def adamw_jobs_table(jobs, device):
     return raw, tiles
 
 
-def adamw_shadow(table, n_jobs, tiles, lr, beta1, beta2, eps, wd, step, grad_mult=None):
-    L.check(L.adamw_shadow(_p(table), n_jobs, tiles, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _stream()))
+def adamw_shadow(table, n_jobs, tiles, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None):
+    L.check(L.adamw_shadow(_p(table), n_jobs, tiles, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _p(hyper), _stream()))
 
 
 def sumsq(x, out):

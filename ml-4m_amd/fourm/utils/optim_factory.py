@@ -64,6 +64,11 @@ class FusedAdamW(optim.AdamW):
         self._clip_coef = None        # device scalar set by fused_grad_norm(clip=...)
         self._runs = None
         self._shadow_tables = {}      # (group index, step) signature -> cached device job table of fm_adamw_shadow
+        # hipGraph support (fourm.hip.graph.GraphedTrainStep): per-group device block {lr, wd, 1 - b1^t, sqrt(1 - b2^t)} that the
+        # kernels read instead of their scalar arguments; in captured mode step() launches only, the host bookkeeping (step counts,
+        # hyper upload) is done by advance_host_state() before each replay
+        self._hyper_dev = self._hyper_host = None
+        self._captured = False
 
     @staticmethod
     def _check_grad(p):
@@ -71,6 +76,35 @@ class FusedAdamW(optim.AdamW):
         if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
             raise TypeError(f"FusedAdamW: gradient of a {tuple(p.shape)} parameter is {g.dtype} / "
                             f"{'contiguous' if g.is_contiguous() else 'strided'} on {g.device}; fp32 contiguous expected")
+
+    # -- hipGraph support -----------------------------------------------------------------------
+    def enable_device_hyper(self, device):
+        n = len(self.param_groups)
+        self._hyper_dev = torch.zeros(n, 4, dtype=torch.float32, device=device)
+        self._hyper_host = torch.zeros(n, 4, dtype=torch.float32).pin_memory()
+
+    def advance_host_state(self):
+        """What step() does on the host, for a step whose launches are replayed from a graph: step counters + the hyper block
+        (one 16-byte-per-group asynchronous copy on the current stream)."""
+        if self._hyper_dev is None:
+            raise RuntimeError("enable_device_hyper() first")
+        for gi, g in enumerate(self.param_groups):
+            step = None
+            for p in g["params"]:
+                st = self.state.get(p)
+                if p.grad is not None and st:
+                    st["step"] += 1
+                    step = int(st["step"])
+            if step is None:
+                continue
+            b1, b2 = g["betas"]
+            self._hyper_host[gi, 0], self._hyper_host[gi, 1] = g["lr"], g["weight_decay"]
+            self._hyper_host[gi, 2], self._hyper_host[gi, 3] = 1.0 - b1 ** step, (1.0 - b2 ** step) ** 0.5
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def _hyper(self, gi):
+        """Device hyper block of group ``gi`` while a graph is being captured (eager steps pass the scalars themselves)."""
+        return self._hyper_dev[gi] if (self._captured and self._hyper_dev is not None) else None
 
     # -- contiguous runs ------------------------------------------------------------------------
     def _shadowed(self):
@@ -114,7 +148,8 @@ class FusedAdamW(optim.AdamW):
                     st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
                 if not (st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous() and st["exp_avg"].dtype == torch.float32):
                     continue                      # odd state (foreign checkpoint): the plain path handles it
-                st["step"] += 1
+                if not self._captured:
+                    st["step"] += 1
                 by_step.setdefault(int(st["step"]), []).append(it)
                 done.add(id(p))
             for step, its in by_step.items():
@@ -126,7 +161,8 @@ class FusedAdamW(optim.AdamW):
                     table, tiles = ops.adamw_jobs_table(jobs, its[0][0].device)
                     cached = self._shadow_tables[gi] = (sig, table, len(jobs), tiles)
                 _, table, n, tiles = cached
-                ops.adamw_shadow(table, n, tiles, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], step, self._clip_coef)
+                ops.adamw_shadow(table, n, tiles, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], max(step, 1), self._clip_coef,
+                                 hyper=self._hyper(gi))
                 for p, pl, tr, keys in its:
                     touched += keys
                     for dst in (pl, tr):
@@ -230,18 +266,19 @@ class FusedAdamW(optim.AdamW):
             g = self.param_groups[gi]
             self._init_state(run)
             st0 = self.state[run[0]]
-            for p in run:
-                self.state[p]["step"] += 1
-            step = int(st0["step"])
+            if not self._captured:
+                for p in run:
+                    self.state[p]["step"] += 1
+            step = max(int(st0["step"]), 1)
             n = sum(p.numel() for p in run)
             if not self._state_adjacent_all(run):
                 for p in run:       # state loaded from a checkpoint (separate tensors): per-tensor launches
                     st = self.state[p]
                     ops.adamw(p, p.grad, st["exp_avg"], st["exp_avg_sq"], p.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                              g["weight_decay"], int(st["step"]), self._clip_coef)
+                              g["weight_decay"], max(int(st["step"]), 1), self._clip_coef, hyper=self._hyper(gi))
                 continue
             ops.adamw(run[0], run[0].grad, st0["exp_avg"], st0["exp_avg_sq"], n, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                      g["weight_decay"], step, self._clip_coef)
+                      g["weight_decay"], step, self._clip_coef, hyper=self._hyper(gi))
         self._clip_coef = None
         engine.bump_weight_epoch()
         for eng in {id(e): e for e, _ in touched}.values():          # the copies written above are current again

@@ -333,3 +333,63 @@ def test_fused_adamw_rewrites_weight_shadows():
     random.seed(5); l2, _ = model(md, case["N"], case["M"])
     assert check(only_plain=False) > 30
     assert float(l2) < float(loss)                                      # and the forward sees them
+
+
+def test_graphed_train_step_matches_eager():
+    """GraphedTrainStep (fourm/hip/graph.py): the whole step captured in one hipGraph and replayed on new batches with a changing
+    learning rate follows the eager launch sequence: same losses, same weights (up to the summation order of the fp32 atomics in the
+    weight-gradient kernels, which differs run to run in the eager path as well)."""
+    from fourm.hip.graph import GraphedTrainStep
+    from fourm.utils.optim_factory import FusedAdamW
+    case = build_case("micro_swiglu")
+
+    def make():
+        m = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+        m.load_state_dict(case["sd"]); m = m.cuda().train()
+        o = FusedAdamW([{"params": [p for n, p in m.named_parameters() if p.dim() > 1], "weight_decay": 0.05},
+                        {"params": [p for n, p in m.named_parameters() if p.dim() <= 1], "weight_decay": 0.0}], lr=1e-3, betas=(0.9, 0.95))
+        return m, o
+    batches = [to_device(O.synthetic_mod_dict(case["cfg"], 3, 20, 18, seed=50 + i)) for i in range(5)]
+    lrs = [1e-3 * (1 + 0.3 * i) for i in range(5)]
+    # eager reference, run TWICE: the decoder order is re-drawn from the same RNG state before every forward (the graph freezes one
+    # order); the distance between the two identical eager runs is the noise floor of the fp32 atomics amplified by Adam
+    def run_eager():
+        m, o = make()
+        out = []
+        for i, b in enumerate(batches):
+            for g in o.param_groups:
+                g["lr"] = lrs[i]
+            random.seed(11); loss, _ = m(b, case["N"], case["M"]); loss.backward()
+            norm = o.fused_grad_norm(clip=1.0); o.step(); o.zero_grad(set_to_none=True)
+            out.append((float(loss), float(norm)))
+        return m, out
+    me, eager = run_eager()
+    me2, eager2 = run_eager()
+
+    def dist(ma, mb):
+        num = sum(float((p - q).double().pow(2).sum()) for p, q in zip(ma.parameters(), mb.parameters()))
+        den = sum(float((p.double() - torch.zeros_like(p, dtype=torch.float64)).pow(2).sum()) for p in ma.parameters())
+        return (num / den) ** 0.5
+    floor = dist(me, me2)
+    # graphed: warm-up steps of the constructor run on batch 0 with lr[0]; rebuild the starting point afterwards
+    mg, og = make()
+    gs = GraphedTrainStep(mg, og, batches[0], case["N"], case["M"], clip_grad=1.0, order_seed=11)
+    mg.load_state_dict(case["sd"])                       # back to the initial weights (in place: the flat store does not move)
+    for st in og.state.values():
+        st["step"].zero_(); st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+    gs.resync()                                          # weights changed outside the graph: rebuild the bf16 shadows
+    graphed = []
+    for i, b in enumerate(batches):
+        for g in og.param_groups:
+            g["lr"] = lrs[i]
+        loss, _, norm = gs.step(b)
+        graphed.append((float(loss), float(norm)))
+    # (Adam's first steps move every weight by ~lr * sign(g): a gradient entry whose sign hangs on the summation order of the fp32
+    # atomics lands 2 lr apart in two runs of the SAME eager code as well; hence a distribution check, not bit equality)
+    for (le, ne), (lg, ng) in zip(eager, graphed):
+        assert abs(le - lg) < 1e-4 * abs(le) and abs(ne - ng) < 1e-3 * abs(ne), (eager, graphed)
+    assert abs(eager[0][0] - eager[-1][0]) > 1e-3          # the weights did move
+    d_graph = dist(me, mg)
+    record("graph.vs_eager", eager_vs_eager=floor, graph_vs_eager=d_graph, losses_eager=[e[0] for e in eager], losses_graph=[g_[0] for g_ in graphed])
+    assert d_graph < 3 * floor + 1e-6, (d_graph, floor)
+    assert all(float(st["step"]) == 5.0 for st in og.state.values())

@@ -53,3 +53,21 @@ for i in range(a.steps):
 if a.cprofile:
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+
+# ---- the same step replayed from one hipGraph (fourm/hip/graph.py) ------------------------------------------------------------
+from fourm.hip.graph import GraphedTrainStep
+gs = GraphedTrainStep(model, opt, batches[0], 128, 128, warmup=1)
+for i in range(2):
+    gs.step(batches[i % 2])
+torch.cuda.synchronize()
+for i in range(a.steps):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    gs.step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize(); t2_ = time.perf_counter()
+    print(f"graph step {i}: enqueue {(t1-t0)*1e3:.2f} ms (static batch); finished after {(t2_-t0)*1e3:.1f} ms")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(10):
+    gs.step(batches[i % 2])
+torch.cuda.synchronize()
+print(f"graph: 10 steps with batch copies {(time.perf_counter()-t0)*100:.2f} ms/step; final loss {float(gs.loss):.4f}")
