@@ -123,7 +123,7 @@ class LaunchProfiler:
 
 KERNEL_REGEX = {   # profiler family -> regex on the demangled kernel name (7th template argument of gemm_nt = epilogue)
     "gemm_nt": r"gemm_nt_kernel<\d+, \d+, \d+, \d+, \d+, \d+, {epi}, false",
-    "gemm_tn": r"gemm_tn_kernel<\w+, false", "attn_fwd": r"attn_fwd_kernel", "attn_bwd": r"attn_bwd_kernel",
+    "gemm_tn": r"gemm_tn_kernel<\w+, false", "gemm_tn_multi": r"gemm_tn_multi_kernel", "attn_fwd": r"attn_fwd_kernel", "attn_bwd": r"attn_bwd_kernel",
     "layernorm_fwd": r"ln_fwd_kernel", "layernorm_bwd": r"ln_bwd_kernel",
 }
 
@@ -491,6 +491,7 @@ def main():
         symbol = {"gemm_nt": "gemm_nt_kernel<128,256,2,4,{{32|64}},3,EPI={epi},GROUPED=false,PP=true,PERSIST=true>  (csrc/gemm.hip; "
                              "K-step 32 for K < 1536, 64 above)",
                   "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,64,3,PP=true>  (csrc/gemm.hip)",
+                  "gemm_tn_multi": "gemm_tn_multi_kernel<MASKED=false>  (csrc/gemm.hip; all dW GEMMs of a layer per launch)",
                   "attn_fwd": "attn_fwd_kernel<true,MASK>", "attn_bwd": "attn_bwd_kernel<true,MASK>",
                   "layernorm_fwd": "ln_fwd_kernel<bf16,3>", "layernorm_bwd": "ln_bwd_kernel<3>"}
         name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])

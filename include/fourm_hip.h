@@ -87,6 +87,17 @@ typedef struct fm_gemm_tn_args {
     int32_t n_groups, max_N, max_R, pad_;
 } fm_gemm_tn_args;
 int fm_gemm_tn(const fm_gemm_tn_args* args, void* stream);
+/* A list of dense weight-gradient GEMMs in ONE launch (all dW of a transformer layer: fourm/models/fm_utils.py Block /
+ * DecoderBlock backward as autograd runs it, one addmm per nn.Linear): job i does out_i[n][k] += sum_{r<R_i} A_i[r][n] * B_i[r][k]
+ * with fm_gemm_tn's operand rules.  The tiles of all jobs share one grid of one workgroup per CU: whole-row reductions while a
+ * full round of tiles remains, one main + tail cut of the last partial round (csrc/gemm.hip, gemm_tn_multi_kernel).
+ * n_jobs <= FM_TN_MAX_JOBS; the job array is read on the host at call time. */
+#define FM_TN_MAX_JOBS 16
+typedef struct fm_gemm_tn_job {
+    const void* A; const void* B; void* out;
+    int32_t R, N, K, lda, ldb, ldo, a_cols, b_cols;
+} fm_gemm_tn_job;
+int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* stream);
 /* tile schedule of fm_gemm_tn (table in csrc/gemm.hip): 0 = K-step 32, two workgroups per CU; 1 = K-step 64,
  * one workgroup per CU, ping-pong schedule (half the workgroups -> half the atomic epilogue traffic). */
 void fm_set_gemm_tn_config(int cfg);

@@ -787,6 +787,241 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// TN job list: every weight-gradient GEMM of one transformer layer in ONE launch
+// ------------------------------------------------------------------------------------------------
+// The trunk's backward produces 5 (encoder) / 8 (decoder layer) weight gradients out[n][k] += sum_r dY[r][n] X[r][k] with a few
+// dozen 128 x 256 output tiles each and a 32k-row reduction.  Launched one by one, each must be split ~14 ways over the rows to
+// occupy 256 CUs: 14 x the output in fp32 atomics per GEMM and a ~36-step main loop per workgroup.  Here the jobs of a layer form
+// one tile list (216 tiles for a 4M-B encoder layer, 288 for a decoder layer) on a grid of one workgroup per CU:
+//   * while at least gridDim tiles remain, workgroup w reduces tile f * gridDim + w over ALL its rows (no split at all);
+//   * the last rem < gridDim tiles are cut once: workgroup i < rem ("main") takes the first q = KT * rem / gridDim k-tiles of
+//     tile i, the other gridDim - rem workgroups ("tail") share the remaining k-tiles evenly, each walking a contiguous run of them
+//     (a handful of tile tails); every workgroup ends up with ~ total k-tiles / gridDim.
+// Main workgroups of neighbouring tiles (same XCD: logical index = (blockIdx % 8) * gridDim / 8 + blockIdx / 8) run in lock step
+// over the same rows, so the operand panels they share come from that XCD's L2 once - a stream-K cut at arbitrary offsets would
+// have every workgroup at a different row and lose that.  Atomic traffic: (tiles + gridDim) x 128 KB per LAYER.
+// The main loop is gemm_tn_kernel's ping-pong schedule (K-step 64, 3-stage LDS-DMA ring, transpose reads), restarted per segment.
+struct TNJob {
+    const bf16_t* A; const bf16_t* B; float* out;
+    int R, N, K, lda, ldb, ldo, a_cols, b_cols;
+    int n_tiles_b, tiles, tile_start, kt;        // kt = reduction tiles (of 64 rows) of this job
+    int q;                                       // main share of a tile of the last partial round
+};
+struct TNMultiArgs {
+    TNJob job[FM_TN_MAX_JOBS];
+    int n_jobs, tiles, tail_rr;
+};
+
+template <bool MASKED>
+__global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
+    constexpr int TA = 128, TB = 256, WB = 4, KB = 64, STAGES = 3, NWAVES = 8;
+    constexpr int RBA = TA * 2, RBB = TB * 2;
+    constexpr int PA = KB * RBA / 1024, PB = KB * RBB / 1024;
+    constexpr int LOADS = (PA + PB) / NWAVES;
+    constexpr int STAGE = KB * (RBA + RBB);
+    constexpr int KS = KB / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wa = wave / WB, wb = wave % WB;
+    const bool lead = wa == 0;
+    const int fhi = lane >> 5;
+    const bf16_t* zsrc = (const bf16_t*)g_zero16;
+    const int G = gridDim.x;
+    const int w = (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
+
+    const int li = lane & 15;
+    const int frow0 = fhi * 8 + (li >> 2), fcol = ((lane >> 4) & 1) * 16 + (li & 3) * 4;
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    uint32_t baseA[2], baseB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        baseA[i] = (uint32_t)tn_off<RBA>(frow0, wa * 64 + i * 32 + fcol);
+        baseB[i] = (uint32_t)tn_off<RBB>(frow0, wb * 64 + i * 32 + fcol) + KB * RBA;
+    }
+
+    // one segment: k-tiles [t_begin, t_end) of global tile `tile`, accumulated into its job's output
+    auto run = [&](int tile, int t_begin, int t_end) {
+        if (t_begin >= t_end) return;
+        int j = 0;
+        while (j + 1 < a.n_jobs && tile >= a.job[j + 1].tile_start) ++j;
+        const TNJob& jb = a.job[j];
+        const int local = tile - jb.tile_start;
+        const int n0 = (local / jb.n_tiles_b) * TA, k0 = (local % jb.n_tiles_b) * TB;
+        const bf16_t* A = jb.A; const bf16_t* B = jb.B;
+        const int lda = jb.lda, ldb = jb.ldb, a_cols = jb.a_cols, b_cols = jb.b_cols, r_lim = jb.R;
+
+        auto stage_piece = [&](int t, int buf, int q) {
+            char* base = smem + buf * STAGE;
+            const int r0 = t * KB;
+            if (q < PA / NWAVES) {
+                constexpr int LPR = RBA / 16, RPP = 1024 / RBA;
+                const int piece = q * NWAVES + wave;
+                const int row = piece * RPP + lane / LPR;
+                const int lc = (lane % LPR) ^ ((row & 3) << 2);
+                int ca = n0 + lc * 8; ca = ca <= a_cols - 8 ? ca : a_cols - 8;
+                const bf16_t* src = A + (size_t)(r0 + row) * lda + ca;
+                if constexpr (MASKED) src = r0 + row < r_lim ? src : zsrc;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + piece * 1024), 16, 0, 0);
+            } else {
+                constexpr int LPR = RBB / 16, RPP = 1024 / RBB;
+                const int piece = (q - PA / NWAVES) * NWAVES + wave;
+                const int row = piece * RPP + lane / LPR;
+                const int lc = (lane % LPR) ^ ((row & 3) << 2);
+                int cb = k0 + lc * 8; cb = cb <= b_cols - 8 ? cb : b_cols - 8;
+                const bf16_t* src = B + (size_t)(r0 + row) * ldb + cb;
+                if constexpr (MASKED) src = r0 + row < r_lim ? src : zsrc;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base + KB * RBA + piece * 1024), 16, 0, 0);
+            }
+        };
+        constexpr int NP = PA / NWAVES + PB / NWAVES;
+        auto stage = [&](int t, int buf) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) stage_piece(t, buf, q);
+        };
+        auto stage_part = [&](int t, int buf, int part, int nparts) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                if (q >= part * NP / nparts && q < (part + 1) * NP / nparts) stage_piece(t, buf, q);
+        };
+
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+
+        const int NT_ = t_end - t_begin;
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p)
+            if (p < NT_) stage(t_begin + p, p);
+        if (NT_ > 1) wait_vmcnt<LOADS>(); else wait_vmcnt<0>();
+        block_barrier();
+        if (!lead) block_barrier();
+        int buf = 0;
+        for (int it = 0; it < NT_; ++it) {
+            const bool more = it + 2 < NT_;
+            const int nbuf = buf >= 1 ? buf - 1 : 2;
+            const uint32_t st = smem_lds + buf * STAGE;
+            union Frag { bf16x8_t v; s16x4_t h[2]; };
+            Frag af[KS][2], bfr[KS][2];
+            auto read_k = [&](auto kk_c) {
+                constexpr int kk = decltype(kk_c)::value;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[kk][i].h[0] = tr_read<kk * 16 * RBA>(st + baseA[i]);
+                    af[kk][i].h[1] = tr_read<kk * 16 * RBA + 4 * RBA>(st + baseA[i]);
+                }
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    bfr[kk][jj].h[0] = tr_read<kk * 16 * RBB>(st + baseB[jj]);
+                    bfr[kk][jj].h[1] = tr_read<kk * 16 * RBB + 4 * RBB>(st + baseB[jj]);
+                }
+            };
+            read_k(std::integral_constant<int, 0>{});
+            read_k(std::integral_constant<int, 1>{});
+            read_k(std::integral_constant<int, 2>{});
+            read_k(std::integral_constant<int, 3>{});
+            if (!lead) {
+                if (more) { stage(t_begin + it + 2, nbuf); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
+            }
+            wait_lgkmcnt<0>();
+            block_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i].v, bfr[kk][jj].v, acc[i][jj], 0, 0, 0);
+                if (lead && more) stage_part(t_begin + it + 2, nbuf, kk, KS);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (lead) { if (more) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (lead || it + 1 < NT_) block_barrier();
+            buf = buf + 1 == STAGES ? 0 : buf + 1;
+        }
+        // accumulator: rows <-> n (A columns), cols <-> k (B columns); lane = k, regs = n
+        float* out = jb.out;
+        const int N = jb.N, K = jb.K, ldo = jb.ldo;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int k = k0 + wb * 64 + jj * 32 + (lane & 31);
+            if (k >= K) continue;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wa * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                    if (n < N) unsafeAtomicAdd(out + (size_t)n * ldo + k, acc[i][jj][r]);
+                }
+        }
+    };
+    auto job_of = [&](int tile) {
+        int j = 0;
+        while (j + 1 < a.n_jobs && tile >= a.job[j + 1].tile_start) ++j;
+        return j;
+    };
+
+    // the segments of this workgroup, one call site for the main loop
+    const int full = a.tiles / G, T0 = full * G, rem = a.tiles - T0, ntail = G - rem;
+    auto q_of = [&](int j) { return a.job[j].q; };
+    long long u0 = 0, u1 = 0;
+    if (rem > 0 && w >= rem) {
+        long long Lsum = 0;
+        for (int j = 0; j < a.n_jobs; ++j) {
+            const int lo = max(a.job[j].tile_start, T0), hi = a.job[j].tile_start + a.job[j].tiles;
+            if (hi > lo) Lsum += (long long)(hi - lo) * (a.job[j].kt - q_of(j));
+        }
+        u0 = Lsum * (w - rem) / ntail; u1 = Lsum * (w - rem + 1) / ntail;
+    }
+    int phase = 0, f = 0, tj = 0, ci = -1;
+    long long P = 0;
+    for (;;) {
+        int tile = 0, t0 = 0, t1 = 0;
+        bool have = false;
+        if (phase == 0) {
+            if (f < full) { tile = f * G + w; t1 = a.job[job_of(tile)].kt; ++f; have = true; }
+            else { phase = rem == 0 ? 3 : (w < rem ? 1 : 2); f = 0; }
+        } else if (phase == 1) {
+            tile = T0 + w; t1 = q_of(job_of(tile)); phase = 3; have = true;
+        } else if (phase == 2 && a.tail_rr) {
+            const int sgm = (w - rem) + f * ntail;          // f counts this tail's segments here
+            if (sgm >= rem) phase = 3;
+            else { tile = T0 + sgm; const int j = job_of(tile); t0 = q_of(j); t1 = a.job[j].kt; ++f; have = true; }
+        } else if (phase == 2) {
+            if (tj >= a.n_jobs) phase = 3;
+            else {
+                const int lo = max(a.job[tj].tile_start, T0), hi = a.job[tj].tile_start + a.job[tj].tiles;
+                const int q = q_of(tj), left = a.job[tj].kt - q;
+                bool advance = true;
+                if (hi > lo && left > 0) {
+                    const long long Pn = P + (long long)(hi - lo) * left;
+                    if (u1 > P && u0 < Pn) {
+                        const long long s0 = max(u0, P) - P, s1 = min(u1, Pn) - P;       // leftover k-tiles of this job: [s0, s1)
+                        if (ci < 0) ci = (int)(s0 / left);
+                        const long long base = (long long)ci * left;
+                        if (base < s1) {
+                            tile = lo + ci; t0 = q + (int)(max(s0, base) - base); t1 = q + (int)(min(s1, base + left) - base);
+                            ++ci; have = true; advance = false;
+                        }
+                    }
+                    if (advance) P = Pn;
+                }
+                if (advance) { ++tj; ci = -1; }
+            }
+        } else break;
+        if (have) run(tile, t0, t1);
+    }
+}
+
 int g_nt_config = 9, g_nt_prio = 1;
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
@@ -1006,5 +1241,74 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
 #undef LAUNCH_TN
 #undef LAUNCH_TN2
     FM_CHECK_LAUNCH("fm_gemm_tn");
+    return 0;
+}
+
+extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* stream) {
+    FM_CHECK_ARG(jobs && n_jobs > 0 && n_jobs <= FM_TN_MAX_JOBS, "fm_gemm_tn_multi: 1..FM_TN_MAX_JOBS jobs");
+    TNMultiArgs a{};
+    bool masked = false;
+    int tiles = 0;
+    long long units = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const fm_gemm_tn_job& p = jobs[i];
+        FM_CHECK_ARG(p.A && p.B && p.out, "fm_gemm_tn_multi: null pointer");
+        FM_CHECK_ARG(p.K > 0 && p.N > 0 && p.R > 0, "fm_gemm_tn_multi: bad shape");
+        FM_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0, "fm_gemm_tn_multi: leading dims must be multiples of 8");
+        TNJob& j = a.job[i];
+        j.A = (const bf16_t*)p.A; j.B = (const bf16_t*)p.B; j.out = (float*)p.out;
+        j.R = p.R; j.N = p.N; j.K = p.K; j.lda = p.lda; j.ldb = p.ldb; j.ldo = p.ldo;
+        j.a_cols = p.a_cols > 0 ? p.a_cols : p.lda; j.b_cols = p.b_cols > 0 ? p.b_cols : p.ldb;
+        FM_CHECK_ARG(j.a_cols >= 8 && j.b_cols >= 8, "fm_gemm_tn_multi: operands need at least 8 readable columns");
+        j.n_tiles_b = (p.K + 255) / 256;
+        j.tiles = ((p.N + 127) / 128) * j.n_tiles_b;
+        j.tile_start = tiles;
+        j.kt = (p.R + 63) / 64;
+        tiles += j.tiles;
+        units += (long long)j.tiles * j.kt;
+        masked = masked || p.R % 64 != 0;
+    }
+    a.n_jobs = n_jobs; a.tiles = tiles;
+    int grid = n_compute_units();
+    // tiny lists: no more workgroups than 8-k-tile shares (a multiple of the 8 XCDs)
+    if (units / 8 < grid) grid = (int)((units / 8 + 7) / 8 * 8);
+    if (grid < 8) grid = 8;
+    {   // The cut of the last partial round.  A segment costs its k-tiles + c (ring fill + a 128 KB atomic epilogue; c ~ 8 k-tiles
+        // fits profiles/r02_lab_tn_multi.txt); main and the busiest tail are balanced on that.  With at least as many remaining
+        // tiles as tail workgroups, whole tails are dealt round-robin: the tails then walk neighbouring tiles over the SAME rows
+        // in lock step and share operand panels in L2 like the mains do (4M-B encoder layer, 216 tiles: 476 us against 512 us for
+        // contiguous runs).  Otherwise each tail is cut into contiguous runs, ~ ntail / rem per tile.
+        constexpr double c = 8.0;
+        const int rem = tiles % grid, ntail = grid - rem;
+        a.tail_rr = rem >= ntail;
+        for (int i = 0; i < n_jobs; ++i) {
+            TNJob& j = a.job[i];
+            if (rem == 0) { j.q = j.kt; continue; }
+            if (a.tail_rr) {      // the busiest tail workgroup has n = ceil(rem / ntail) tails:  q + c = n (kt - q + c)
+                const int n = (rem + ntail - 1) / ntail;
+                double left = (j.kt - (n - 1) * c) / (n + 1.0);
+                j.q = j.kt - (left > 0 ? (int)left : 0);
+            } else {              // r = rem / ntail tails per tail workgroup on average:  q + c = (kt - q) r + (r + 1) c
+                const double r = (double)rem / ntail;
+                j.q = (int)((j.kt * r + r * c) / (1.0 + r));
+            }
+            if (j.q > j.kt) j.q = j.kt;
+            if (j.q < 0) j.q = 0;
+        }
+    }
+    constexpr size_t lds = (size_t)3 * 64 * (128 + 256) * 2;
+    hipStream_t s = (hipStream_t)stream;
+    if (masked) {
+        auto k = gemm_tn_multi_kernel<true>;
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
+    } else {
+        auto k = gemm_tn_multi_kernel<false>;
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        (void)once;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
+    }
+    FM_CHECK_LAUNCH("fm_gemm_tn_multi");
     return 0;
 }

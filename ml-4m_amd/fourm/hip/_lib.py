@@ -55,6 +55,14 @@ class GemmTNArgs(C.Structure):
                 ("seg_start", vp), ("seg_count", vp), ("n_groups", i32), ("max_N", i32), ("max_R", i32), ("pad_", i32)]
 
 
+class GemmTNJob(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("out", vp), ("R", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32),
+                ("ldo", i32), ("a_cols", i32), ("b_cols", i32)]
+
+
+TN_MAX_JOBS = 16
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("V", vp), ("O", vp), ("stat_m", vp), ("stat_l", vp),
                 ("ldq", i32), ("ldk", i32), ("ldv", i32), ("ldo", i32),
@@ -122,6 +130,7 @@ def _sig(name, *argtypes):
 P = C.POINTER
 gemm_nt = _sig("fm_gemm_nt", P(GemmNTArgs), vp)
 gemm_tn = _sig("fm_gemm_tn", P(GemmTNArgs), vp)
+gemm_tn_multi = _sig("fm_gemm_tn_multi", P(GemmTNJob), C.c_int, vp)
 layernorm_fwd = _sig("fm_layernorm_fwd", vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, f32, vp)
 layernorm_bwd = _sig("fm_layernorm_bwd", vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, vp)
 attn_fwd = _sig("fm_attn_fwd", P(AttnArgs), vp)
@@ -169,7 +178,7 @@ lib.fm_set_gemm_tn_config.argtypes = [C.c_int]
 lib.fm_set_attn_transpose_read.argtypes = [C.c_int]
 
 lib.fm_set_gemm_nt_config.argtypes = [C.c_int]
-EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_gemm_tn", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
+EXPORTS = ["fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",

@@ -156,6 +156,7 @@ class FourMEngine:
         self.flat_params = self.flat_grads = None
         self._slices = {}
         self._ctx = None           # saved state of the last training forward
+        self._dw_jobs = None       # weight-gradient GEMMs queued by the running block backward (None: launch each at once)
         self.reducer = None        # fourm.parallel.GradReducer when gradients are exchanged (data parallel)
 
     # ------------------------------------------------------------------------------------------
@@ -696,9 +697,19 @@ class FourMEngine:
         g = self._g(lin.weight)
         N = lin.weight.shape[0] if n_cols is None else n_cols
         if g is not None:
-            ops.gemm_tn(dy, x, g.view(g.shape[0], -1), N=N, K=lin.weight[0].numel(), R=R64)
+            if self._dw_jobs is not None:      # inside a block backward: one launch for the layer (_flush_dW)
+                self._dw_jobs.append((dy, x, g.view(g.shape[0], -1), N, lin.weight[0].numel(), R64))
+            else:
+                ops.gemm_tn(dy, x, g.view(g.shape[0], -1), N=N, K=lin.weight[0].numel(), R=R64)
         if lin.bias is not None and lin.bias.requires_grad:
             ops.colsum(dy, self.grad_view(lin.bias), N, R=R64)
+
+    def _flush_dW(self):
+        """All weight gradients queued by the current block backward in ONE launch (fm_gemm_tn_multi).  Their operands - the
+        bf16 output gradients and the saved activations of this layer - must still hold what they held when queued: the block
+        backwards write each residual-stream gradient copy to its own buffer until this point."""
+        jobs, self._dw_jobs = self._dw_jobs, None
+        ops.gemm_tn_multi(jobs)
 
     def _ln_bwd(self, norm, dy, x, sv, key, g, g_bf, R, dres, dy_row_map=None):
         dw = self._g(norm.weight)
@@ -766,16 +777,22 @@ class FourMEngine:
 
     def encoder_block_bwd(self, blk, sv, g, g_bf, B, N, mask):
         R, Rp = B * N, g.shape[0]
+        self._dw_jobs = []
         dh = self._mlp_bwd(blk.mlp, sv, g_bf, R, Rp)
-        self._ln_bwd(blk.norm2, dh, sv["x_mid"], sv, "n2", g, g_bf, R, dres=g)
-        dh = self._self_attn_bwd(blk.attn, sv, g_bf, B, N, R, Rp, mask)
+        g1 = self.ws.get("bwd.enc.gbf1", tuple(g_bf.shape), g_bf.dtype)      # g_bf is still an operand of the queued fc2 dW
+        self._ln_bwd(blk.norm2, dh, sv["x_mid"], sv, "n2", g, g1, R, dres=g)
+        dh = self._self_attn_bwd(blk.attn, sv, g1, B, N, R, Rp, mask)
+        self._flush_dW()
         self._ln_bwd(blk.norm1, dh, sv["x_in"], sv, "n1", g, g_bf, R, dres=g)
 
     def decoder_block_bwd(self, blk, sv, g, g_bf, dctx, dctx_bf, ctx, B, M, N, sa_mask, xa_mask):
         bf, D = self.adt, self.D
         Rq, Rqp, Rc, Rcp = B * M, g.shape[0], B * N, ctx.shape[0]
         ws = self.ws
-        dh = self._mlp_bwd(blk.mlp, sv, g_bf, Rq, Rqp)
+        self._dw_jobs = []
+        g_in = g_bf
+        dh = self._mlp_bwd(blk.mlp, sv, g_in, Rq, Rqp)
+        g_bf = ws.get("bwd.dec.gbf1", tuple(g_in.shape), g_in.dtype)          # each copy stays an operand of a queued dW
         self._ln_bwd(blk.norm2, dh, sv["y2"], sv, "n2", g, g_bf, Rq, dres=g)
         # cross attention
         xa = blk.cross_attn
@@ -797,6 +814,7 @@ class FourMEngine:
         self._dW(dq, sv["hq"], xa.q, Rq)
         dhq = ws.get("bwd.dh", (Rqp, D), bf)
         ops.gemm_nt(dq, self.wt(xa.q.weight), dhq, M=Rq, N=D, K=D)
+        g_bf = ws.get("bwd.dec.gbf2", tuple(g_in.shape), g_in.dtype)
         self._ln_bwd(blk.query_norm, dhq, sv["y1"], sv, "nq", g, g_bf, Rq, dres=g)
         self._dW(dkv, sv["hc"], xa.kv, Rc)
         dhc = ws.get("bwd.dhc", (Rcp, D), bf)
@@ -804,7 +822,8 @@ class FourMEngine:
         self._ln_bwd(blk.context_norm, dhc, ctx, sv, "nc", dctx, dctx_bf, Rc, dres=dctx)     # accumulates over layers
         # self attention
         dh = self._self_attn_bwd(blk.self_attn, sv, g_bf, B, M, Rq, Rqp, sa_mask)
-        self._ln_bwd(blk.norm1, dh, sv["y_in"], sv, "n1", g, g_bf, Rq, dres=g)
+        self._flush_dW()
+        self._ln_bwd(blk.norm1, dh, sv["y_in"], sv, "n1", g, g_in, Rq, dres=g)
 
     def _embed_bwd(self, sel, dx, dx_extra, is_dec):
         m = self.model
@@ -849,7 +868,7 @@ class FourMEngine:
         c = self._ctx
         if c is None:
             raise RuntimeError("train_backward without a preceding training forward")
-        self._ctx = None
+        self._ctx, self._dw_jobs = None, None
         if self.reducer is not None:
             self.reducer.begin()
         m, ws = self.model, self.ws

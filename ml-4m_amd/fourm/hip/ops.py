@@ -146,6 +146,29 @@ def gemm_tn(a_mat, b_mat, out, *, N=None, K=None, R=None, splits=0, force_tr=-1,
     return out
 
 
+def gemm_tn_multi(jobs):
+    """One launch for a list of dense weight-gradient GEMMs: jobs = [(a_mat, b_mat, out, N, K, R), ...] with gemm_tn's meaning
+    per entry (all dW of a transformer layer; csrc/gemm.hip gemm_tn_multi_kernel)."""
+    if not jobs:
+        return
+    if jobs[0][0].dtype == torch.float32:
+        for a_mat, b_mat, out, N, K, R in jobs:
+            gemm_tn(a_mat, b_mat, out, N=N, K=K, R=R)
+        return
+    for lo in range(0, len(jobs), L.TN_MAX_JOBS):
+        part = jobs[lo:lo + L.TN_MAX_JOBS]
+        arr = (L.GemmTNJob * len(part))()
+        flops = 0.0
+        for j, (a_mat, b_mat, out, N, K, R) in zip(arr, part):
+            j.A, j.B, j.out = _p(a_mat), _p(b_mat), _p(out)
+            j.R, j.N, j.K = R, N, K
+            j.lda, j.ldb, j.ldo = _ld(a_mat), _ld(b_mat), _ld(out)
+            j.a_cols, j.b_cols = a_mat.shape[1], b_mat.shape[1]
+            flops += 2.0 * R * N * K
+        with _prof("gemm_tn_multi", flops, 0.0, tag=f"jobs{len(part)} R{part[0][5]}"):
+            L.check(L.gemm_tn_multi(arr, len(part), _stream()))
+
+
 def gemm_tn_grouped(a_mat, b_mat, groups, seg_start, seg_count, n_groups, max_N, max_R, K, *, splits=0, force_tr=-1):
     if a_mat.dtype == torch.float32:
         g = L.GemmF32Args()

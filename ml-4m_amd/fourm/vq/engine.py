@@ -29,7 +29,7 @@ class _VitEngine(FourMEngine):
         self.scale, self.eps = 64 ** -0.5, blk.norm1.eps
         self.ws, self.shadows, self._shadow_table, self._ctx, self.reducer = None, {}, None, None, None
         self.flat_params = self.flat_grads = None
-        self._cache = {}
+        self._cache, self._dw_jobs = {}, None
 
     @property
     def device(self):

@@ -240,6 +240,48 @@ def test_gemm_tn_masks_rows_past_R(cfg, R, Rbuf):
         L.lib.fm_set_gemm_tn_config(1)
 
 
+TN_MULTI_LISTS = {
+    # (R, N, K) per job
+    "one_small": [(64, 128, 128)],
+    "one_split": [(8192, 768, 768)],                                               # 18 tiles < grid: main + contiguous tails
+    "ragged": [(1000, 200, 264), (37, 136, 520), (4100, 768, 136), (300, 64, 64)],  # R % 64 != 0, different R per job
+    "rr_tails": [(4096, 2048, 768), (4096, 2048, 768), (4096, 768, 2048), (4096, 768, 768), (4096, 2304, 768)],   # 216 tiles: round-robin tails
+    "full_round": [(2048, 2048, 768)] * 5 + [(2048, 768, 2048), (2048, 1536, 768)] + [(2048, 768, 768)] * 3,      # 330 tiles: a full round + a cut
+}
+
+
+@pytest.mark.parametrize("name", sorted(TN_MULTI_LISTS))
+def test_gemm_tn_multi(name):
+    """fm_gemm_tn_multi: every job of the list accumulates dY^T X into its own output, whatever the cut of the tile list over the
+    grid (whole tiles, main + tails, round-robin or contiguous); rows past R never count; repeated to screen for races."""
+    ops, L = _ops()
+    jobs, refs = [], []
+    for i, (R, N, K) in enumerate(TN_MULTI_LISTS[name]):
+        Rbuf = ops.ru(R, 128)
+        a = bf(randn(Rbuf, N, seed=100 + 2 * i) + torch.arange(N, device=DEV)[None] * 0.01)
+        b = bf(randn(Rbuf, K, seed=101 + 2 * i))
+        a[R:] = 1e4; b[R:] = float("nan")
+        refs.append(1.0 + a[:R].float().t() @ b[:R].float())
+        jobs.append((a, b, None, N, K, R))
+    for _ in range(3):
+        outs = [torch.full((N, K), 1.0, device=DEV, dtype=torch.float32) for _, N, K in TN_MULTI_LISTS[name]]
+        ops.gemm_tn_multi([(a, b, o, N, K, R) for (a, b, _, N, K, R), o in zip(jobs, outs)])
+        for i, (o, ref) in enumerate(zip(outs, refs)):
+            assert rel_err(o, ref) < 1e-4, (name, i, rel_err(o, ref))
+
+
+def test_gemm_tn_multi_column_views():
+    """Jobs whose dY is a column block of a wider buffer (the SwiGLU (g | u) gradient) and whose output has a wider row stride."""
+    ops, L = _ops()
+    R, Hp, D = 1024, 256, 192
+    dgu = bf(randn(R, 2 * Hp, seed=120))
+    x = bf(randn(R, D, seed=121))
+    big = torch.zeros(2 * 200, D, device=DEV, dtype=torch.float32)
+    ops.gemm_tn_multi([(dgu[:, :Hp], x, big[:200], 200, D, R), (dgu[:, Hp:], x, big[200:], 200, D, R)])
+    ref = torch.cat([dgu[:, :200].float().t() @ x.float(), dgu[:, Hp:Hp + 200].float().t() @ x.float()])
+    assert rel_err(big, ref) < 1e-4, rel_err(big, ref)
+
+
 def test_gemm_tn_identity_layout():
     ops, L = _ops()
     R = 128

@@ -391,5 +391,8 @@ def test_graphed_train_step_matches_eager():
     assert abs(eager[0][0] - eager[-1][0]) > 1e-3          # the weights did move
     d_graph = dist(me, mg)
     record("graph.vs_eager", eager_vs_eager=floor, graph_vs_eager=d_graph, losses_eager=[e[0] for e in eager], losses_graph=[g_[0] for g_ in graphed])
-    assert d_graph < 3 * floor + 1e-6, (d_graph, floor)
+    # a frozen learning rate or a stale shadow would put the weights ~6e-2 apart (30 % of lr per step on weights of std 0.02); the
+    # atomics noise of two eager runs measured 2e-4 .. 6e-4 here, so the bound is a multiple of the measured floor with an absolute
+    # allowance for the run where the two eager samples happen to agree closely
+    assert d_graph < max(5 * floor, 2e-3), (d_graph, floor)
     assert all(float(st["step"]) == 5.0 for st in og.state.values())

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <algorithm>
 #include <vector>
 #include <string>
 #include "fourm_hip.h"
@@ -147,6 +149,45 @@ int main(int argc, char** argv) {
         printf("sum over a 4M-B step (ms):");
         for (size_t k = 0; k < cfgs.size(); ++k) printf("  c%d: %.2f", cfgs[k], tot[k] / 1e3);
         printf("\n");
+    } else if (mode == "tnmulti") {
+        // all weight-gradient GEMMs of one 4M-B layer: one fm_gemm_tn launch each  vs  ONE fm_gemm_tn_multi launch
+        struct Shape { int N, K; };
+        std::vector<Shape> enc = {{2048, 768}, {2048, 768}, {768, 2048}, {768, 768}, {2304, 768}};
+        std::vector<Shape> dec = enc; dec.push_back({768, 768}); dec.push_back({768, 768}); dec.push_back({1536, 768});
+        const int Rm = argc > 2 ? atoi(argv[2]) : R;
+        for (auto* layer : {&enc, &dec}) {
+            std::vector<fm_gemm_tn_job> jobs; std::vector<fm_gemm_tn_args> args; std::vector<void*> outs, outs2;
+            double flops = 0;
+            for (auto& sh : *layer) {
+                void* A = dev_rand_bf16((size_t)R * sh.N, 4 + (int)jobs.size()), *B = dev_rand_bf16((size_t)R * sh.K, 50 + (int)jobs.size());
+                void* o1 = dev_zero((size_t)sh.N * sh.K * 4), *o2 = dev_zero((size_t)sh.N * sh.K * 4);
+                fm_gemm_tn_job j{}; j.A = A; j.B = B; j.out = o2; j.R = Rm; j.N = sh.N; j.K = sh.K; j.lda = sh.N; j.ldb = sh.K; j.ldo = sh.K;
+                fm_gemm_tn_args a{}; a.A = A; a.B = B; a.out = o1; a.R = Rm; a.N = sh.N; a.K = sh.K; a.lda = sh.N; a.ldb = sh.K; a.ldo = sh.K; a.force_tr = -1;
+                jobs.push_back(j); args.push_back(a); outs.push_back(o1); outs2.push_back(o2);
+                flops += 2.0 * Rm * sh.N * sh.K;
+            }
+            // correctness: one pass each into zeroed outputs
+            for (auto& a : args) if (fm_gemm_tn(&a, 0) != 0) { printf("tn: %s\n", fm_last_error()); return 1; }
+            if (fm_gemm_tn_multi(jobs.data(), (int)jobs.size(), 0) != 0) { printf("multi: %s\n", fm_last_error()); return 1; }
+            CK(hipDeviceSynchronize());
+            double worst = 0;
+            for (size_t i = 0; i < jobs.size(); ++i) {
+                const size_t n = (size_t)(*layer)[i].N * (*layer)[i].K;
+                std::vector<float> h1(n), h2(n);
+                CK(hipMemcpy(h1.data(), outs[i], n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), outs2[i], n * 4, hipMemcpyDeviceToHost));
+                double num = 0, den = 0;
+                for (size_t e = 0; e < n; ++e) { num += (double)(h1[e] - h2[e]) * (h1[e] - h2[e]); den += (double)h1[e] * h1[e]; }
+                worst = std::max(worst, std::sqrt(num / (den + 1e-30)));
+            }
+            double t1 = 1e30, t2 = 1e30;
+            for (int rep = 0; rep < 4; ++rep) {
+                t1 = std::min(t1, time_us([&] { for (auto& a : args) fm_gemm_tn(&a, 0); }, 10, 2));
+                t2 = std::min(t2, time_us([&] { fm_gemm_tn_multi(jobs.data(), (int)jobs.size(), 0); }, 10, 2));
+            }
+            printf("%s layer (%zu dW GEMMs, R=%d): separate %7.1f us %5.0f TF | one launch %7.1f us %5.0f TF | rel diff %.2e\n",
+                   layer == &enc ? "encoder" : "decoder", jobs.size(), Rm, t1, flops / t1 / 1e6, t2, flops / t2 / 1e6, worst);
+            for (size_t i = 0; i < jobs.size(); ++i) { CK(hipFree((void*)jobs[i].A)); CK(hipFree((void*)jobs[i].B)); CK(hipFree(outs[i])); CK(hipFree(outs2[i])); }
+        }
     }
     return 0;
 }
