@@ -153,6 +153,7 @@ f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
 bf16_to_f32_scaled = _sig("fm_bf16_to_f32_scaled", vp, vp, i64, f32, vp)
 lib.fm_set_reserved_cus.argtypes = [C.c_int]
 lib.fm_get_reserved_cus.restype = C.c_int
+lib.fm_get_reserved_cus.argtypes = []
 adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp, vp)
 adamw_shadow = _sig("fm_adamw_shadow", vp, i32, i32, f32, f32, f32, f32, f32, i64, vp, vp, vp)
 sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
