@@ -257,7 +257,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // Sequences of up to `chunk` (512) rows sit in LDS whole; longer ones (upstream trains 1024 + 1024 tokens,
 // cfgs/default/4m/models/main/*1024*) are walked in chunks that are re-staged once per round of 4 x 32 owned rows.
 // ------------------------------------------------------------------------------------------------
-template <bool TR, int MASK, bool CHUNKED>
+// DS (sequences of up to 128 x 128: every 128-token 4M configuration): pass A also leaves dS^T (bf16, keys x queries) in LDS as
+// 64-query-wide swizzled sub-tiles, and pass B is then dQ = dS K alone - no second QK^T / dO V^T, no second softmax (32 KB more
+// LDS: 68 KB per workgroup, still two per CU).
+template <bool TR, int MASK, bool CHUNKED, bool DS = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
@@ -275,6 +278,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     float4* qs_l = (float4*)(T1 + NP * ROWB);           // per query: {row max (base 2), 1/row sum, delta, cs | mod}
     int16_t* modk_l = (int16_t*)(qs_l + NqP);
     uint8_t* kpad_l = (uint8_t*)(modk_l + NkP);
+    char* dSl = smem + (((size_t)((char*)(kpad_l + NkP) - smem) + 15) & ~(size_t)15);      // DS: sub-tile t = queries [64 t, 64 t + 64)
+    static_assert(!DS || !CHUNKED, "dS^T is kept for single-chunk sequences only");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -399,6 +404,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                 // masked_fill stops the gradient at blocked scores (they matter only in fully blocked rows)
                 dsv[r] = blk ? 0.f : pr * (dp[r] - qs.z) * a.scale;
             }
+            if constexpr (DS) {     // this lane's key row, 4 x 4 consecutive queries: 8-byte stores into the swizzled sub-tile
+                char* sub = dSl + (qb >> 1) * (NkP * ROWB);
+                const int krow = kb * 32 + (lane & 31);
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *(uint2*)tile_addr(sub, krow, (qb & 1) * 32 + 8 * g4 + 4 * fhi) =
+                        make_uint2(pack2bf(dsv[4 * g4], dsv[4 * g4 + 1]), pack2bf(dsv[4 * g4 + 2], dsv[4 * g4 + 3]));
+            }
 #pragma unroll
             for (int sblk = 0; sblk < 2; ++sblk) {
                 const bf16x8_t pb = pack8(&pv[8 * sblk]), db = pack8(&dsv[8 * sblk]);
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     __syncthreads();
     if (nKC == 1) {
         stage_rows<4>(Kb, a.ldk, 0, a.Nk, NkP, Kl, wave, lane);
-        stage_rows<4>(Vb, a.ldv, 0, a.Nk, NkP, Vl, wave, lane);
+        if constexpr (!DS) stage_rows<4>(Vb, a.ldv, 0, a.Nk, NkP, Vl, wave, lane);
         __syncthreads();
     }
 
@@ -452,17 +465,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
         const float4 qs = qs_l[q];
         const float mq_ = qs.x, li = qs.y, dl = qs.z;
         const int csq = __float_as_int(qs.w) >> 16, mq = __float_as_int(qs.w) & 0xffff;
+        f32x16_t dQt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
+        if constexpr (DS) {     // dQ[q][:] = sum_k dS[q][k] K[k][:] with dS^T read column-wise (queries = the MFMA's n index)
+            const char* sub = dSl + (qb >> 1) * (NkP * ROWB);
+            for (int kb = 0; kb < nKB; ++kb)
+#pragma unroll
+                for (int sblk = 0; sblk < 2; ++sblk) {
+                    const int rA = kb * 32 + sblk * 16 + 4 * fhi;
+                    const bf16x8_t db = lds_col_frag<TR>([&](int r, int c) { return tile_addr(sub, r, c); }, rA, rA + 8, (qb & 1) * 32);
+#pragma unroll
+                    for (int df = 0; df < 2; ++df) {
+                        const bf16x8_t kcf = lds_col_frag<TR>([&](int r, int c) { return tile_addr(Kl, r, c); }, rA, rA + 8, df * 32);
+                        dQt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kcf, db, dQt[df], 0, 0, 0);
+                    }
+                }
+        } else {
         bf16x8_t qf[4], dof[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             qf[kk] = *(const bf16x8_t*)(Qb + (size_t)qc * a.ldq + (kk * 2 + fhi) * 8);
             dof[kk] = *(const bf16x8_t*)(dOb + (size_t)qc * a.lddo + (kk * 2 + fhi) * 8);
         }
-        f32x16_t dQt[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
         for (int kc_ = 0; kc_ < nKC; ++kc_) {
         const int krow0 = kc_ * NP, krows = min(NP, NkP - krow0);
         if (nKC > 1) {
@@ -514,6 +541,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
             }
         }
         }
+        }
+        (void)mq_; (void)li; (void)dl; (void)csq; (void)mq;
         if (live) {
             bf16_t* dqrow = a.dQ + ((size_t)b * a.Nq + qc) * a.lddq + h * HD;
             const int lim = q < a.Nq ? HD : 0;
@@ -591,16 +620,20 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     // up to 512 rows per tile in one piece (128 KB of tiles); longer sequences in chunks of 256 rows (two workgroups per CU)
     const int NPmax = NqP > NkP ? NqP : NkP;
     a.chunk = NPmax <= 512 ? NPmax : 256;
-    const size_t lds = (size_t)2 * a.chunk * ROWB + (size_t)NqP * 16 + (size_t)NkP * (2 + 1) + 64;
+    // dS^T through LDS (one softmax recompute instead of two) when it fits beside the tiles with two workgroups per CU
+    static const bool ds_on = [] { const char* e = getenv("FOURM_ATTN_BWD_DS"); return !e || atoi(e) != 0; }();
+    const size_t ds_bytes = (size_t)((NqP + 63) / 64) * NkP * ROWB;
+    const bool ds = ds_on && a.chunk == NPmax && ds_bytes <= 32 * 1024;
+    const size_t lds = (size_t)2 * a.chunk * ROWB + (size_t)NqP * 16 + (size_t)NkP * (2 + 1) + 64 + (ds ? ds_bytes + 16 : 0);
     FM_CHECK_ARG(lds <= 160 * 1024, "fm_attn_bwd: Nq=%d Nk=%d need %zu bytes of LDS for the per-row statistics", a.Nq, a.Nk, lds);
     FM_CHECK_ARG(a.Nq < 0x7fff && a.Nk < 0x7fff, "fm_attn_bwd: sequence too long for the packed 15-bit mask bounds");
     dim3 grid(a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
 #define BWD(TR, MK)                                                                                                   \
-    if (a.chunk < NPmax) BWD2(TR, MK, true) else BWD2(TR, MK, false)
-#define BWD2(TR, MK, CH)                                                                                              \
+    if (a.chunk < NPmax) BWD2(TR, MK, true, false) else if (ds) BWD2(TR, MK, false, true) else BWD2(TR, MK, false, false)
+#define BWD2(TR, MK, CH, DSV)                                                                                         \
     {                                                                                                                 \
-        auto k = attn_bwd_kernel<TR, MK, CH>;                                                                         \
+        auto k = attn_bwd_kernel<TR, MK, CH, DSV>;                                                                       \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess); \
         (void)once;                                                                                                   \
         hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, a);                                          \
