@@ -6,9 +6,9 @@ sampling of every position -> keep the ``num_select`` most confident samples and
 the engine's HIP kernels; the sampling + commit are two launches of csrc/sample.hip instead of upstream's topk / sort / softmax /
 cumsum / argsort / gather / multinomial / topk / scatter chain.
 
-Scope (first slice): the MaskGIT scheme, batched, for grid-token target modalities.  ROAR and the autoregressive
-scheme (which upstream runs WITHOUT a K/V cache, generate.py:850-914), guidance and chained schedules are not implemented yet and
-raise; nothing falls back to eager PyTorch.
+Scope: the MaskGIT and ROAR (random order) schemes, batched, with and without classifier-free guidance, for
+grid-token target modalities.  The autoregressive scheme (which upstream runs WITHOUT a K/V cache, generate.py:850-914),
+multi-condition guidance and chained schedules are not implemented yet and raise; nothing falls back to eager PyTorch.
 
 Determinism: the only randomness is one uniform per decoded position drawn with ``torch.rand`` from the generator passed in (or the
 device default): same logits + same uniforms -> same tokens (csrc/sample.hip, bit-exact against oracle/sample_oracle.py).
@@ -70,8 +70,10 @@ class GenerationSampler(nn.Module):
     # one MaskGIT forward  (generate.py:407-480, :628-647)
     # ------------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward_enc_dec_maskgit_batched(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], target_mod: str, seed: Optional[int] = None):
-        """-> (logits (B, N, V) for the N still-masked positions of ``target_mod`` in position order, mod_pos (B, N) int32)."""
+    def forward_enc_dec_maskgit_batched(self, mod_dict: Dict[str, Dict[str, torch.Tensor]], target_mod: str, seed: Optional[int] = None,
+                                        decode_mask: Optional[torch.Tensor] = None):
+        """-> (logits (B, N, V) for the N still-masked positions of ``target_mod`` in position order, mod_pos (B, N) int32).
+        ``decode_mask`` (B, L) bool, False = decode this position: replaces the modality's target_mask for this forward (ROAR)."""
         from fourm.hip import _lib as L, ops
         m = self.model
         eng = m.engine
@@ -87,12 +89,14 @@ class GenerationSampler(nn.Module):
         # budget = the largest number of visible tokens of a sample (generate.py:413, one host read like upstream's .max())
         vis = sum((~mod_dict[n]["input_mask"].reshape(B, -1).bool()).sum(1) for n in enc_names)
         n_enc = int(vis.max())
-        tm = mod_dict[target_mod]["target_mask"].reshape(B, -1).bool()
+        tm = (mod_dict[target_mod]["target_mask"] if decode_mask is None else decode_mask).reshape(B, -1).bool()
         n_dec = int((~tm[0]).sum())                                  # "assumes num_decoder_tokens is the same across the batch" (:460)
         if n_enc == 0 or n_dec == 0:
             raise ValueError("nothing to condition on / nothing left to decode")
         enc = eng.select(mod_dict, n_enc, False, enc_names, "gen.enc.")
         dd = dict(mod_dict[target_mod])
+        if decode_mask is not None:
+            dd["target_mask"] = tm.view_as(dd["target_mask"]).contiguous()
         if "decoder_attention_mask" not in dd:                        # generation dicts need none (no decoder self-attention mask)
             dd["decoder_attention_mask"] = torch.zeros_like(tm, dtype=torch.int32)
         dec = eng.select({target_mod: dd}, n_dec, True, [target_mod], "gen.dec.", heads=[target_mod])
@@ -111,10 +115,15 @@ class GenerationSampler(nn.Module):
     @torch.no_grad()
     def maskgit_step_batched(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, seed=None, generator=None, uniforms=None):
         """One MaskGIT step: mod_dict[target_mod]['tensor' | 'input_mask' | 'target_mask'] are updated in place (and returned)."""
-        from fourm.hip import _lib as L, ops
         if seed is not None:
             generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
         logits, mod_pos = self.forward_enc_dec_maskgit_batched(mod_dict, target_mod)
+        return self._sample_and_commit(mod_dict, target_mod, logits, mod_pos, num_select, temperature, top_k, top_p, generator, uniforms)
+
+    def _sample_and_commit(self, mod_dict, target_mod, logits, mod_pos, num_select, temperature, top_k, top_p, generator, uniforms):
+        """Sample every decoded position, keep the ``num_select`` most confident, write them into mod_dict (generate.py:393-405,
+        :655-661): fm_sample_tokens + fm_maskgit_commit."""
+        from fourm.hip import _lib as L, ops
         B, N, V = logits.shape
         rows = logits.reshape(B * N, V) if logits.is_contiguous() else logits.as_strided((B * N, V), (logits.stride(1), 1))
         samples, probs = self.sample_tokens(rows, temperature, top_k, top_p, generator, uniforms)
@@ -147,8 +156,105 @@ class GenerationSampler(nn.Module):
             remaining -= k
         return mod_dict
 
-    def guided_maskgit_step_batched(self, *a, **k):
-        raise NotImplementedError("classifier-free guidance is not implemented yet (SURVEY §8 f2)")
+    # ------------------------------------------------------------------------------------------------------------------------
+    # ROAR = random order autoregression  (generate.py:481-514, :745-781)
+    # ------------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def roar_decode_mask(self, mod_dict, target_mod, num_select, generator=None, order_noise=None):
+        """The positions one ROAR step decodes: the ``num_select`` still-masked positions with the smallest entries of one random
+        vector shared by the batch (upstream: argsort(target_mask + rand * 1e-6)[:, :num_select], generate.py:495-499).
+        -> decode_mask (B, L) bool, False at the chosen positions."""
+        tm = mod_dict[target_mod]["target_mask"]
+        B = tm.shape[0]
+        tm = tm.reshape(B, -1).bool()
+        L_ = tm.shape[1]
+        if order_noise is None:
+            order_noise = torch.rand(L_, device=tm.device, generator=generator)
+        n = min(int(num_select), int((~tm[0]).sum()))
+        if n <= 0:
+            raise ValueError("nothing left to decode")
+        key = tm.float() + order_noise.reshape(1, L_).float() * 1e-6
+        chosen = torch.argsort(key, dim=1)[:, :n]
+        return torch.ones_like(tm).scatter_(1, chosen, False)
+
+    @torch.no_grad()
+    def forward_enc_dec_roar_batched(self, mod_dict, target_mod, num_select, seed=None, generator=None, order_noise=None):
+        """-> (logits (B, n, V), mod_pos (B, n)) for the n = min(num_select, #masked) randomly chosen positions, in position order
+        (upstream returns them in the random order; every position is sampled independently, so only the row order differs)."""
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        dm = self.roar_decode_mask(mod_dict, target_mod, num_select, generator, order_noise)
+        return self.forward_enc_dec_maskgit_batched(mod_dict, target_mod, decode_mask=dm)
+
+    @torch.no_grad()
+    def roar_step_batched(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, seed=None, generator=None, uniforms=None,
+                          order_noise=None):
+        """One ROAR step: every chosen position is sampled and committed (generate.py:766-781)."""
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        logits, mod_pos = self.forward_enc_dec_roar_batched(mod_dict, target_mod, num_select, generator=generator, order_noise=order_noise)
+        return self._sample_and_commit(mod_dict, target_mod, logits, mod_pos, logits.shape[1], temperature, top_k, top_p, generator, uniforms)
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    # classifier-free guidance  (generate.py:28-80, :665-703, :783-816)
+    # ------------------------------------------------------------------------------------------------------------------------
+    def unconditional_dict(self, mod_dict, conditioning):
+        """A copy of ``mod_dict`` with the ``conditioning`` modalities emptied the way upstream's empty_img_modality /
+        empty_seq_modality / empty_seq_emb_modality do (generate.py:30-80)."""
+        out = {m: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for m, d in mod_dict.items()}
+        for mod in conditioning:
+            d, kind = out[mod], self.model.modality_info[mod]["type"]
+            if kind in ("seq", "seq_token"):
+                s1_id = 5                                      # id of the first sentinel token [S_1]
+                d["tensor"][:] = 0
+                d["tensor"][:, [0, 1]] = s1_id
+                d["tensor"][:, -1] = s1_id + 1
+                d["input_mask"][:] = True
+                d["input_mask"][:, 0] = False
+                d["target_mask"] = ~d["input_mask"]
+                d["decoder_attention_mask"][:] = 1
+                d["decoder_attention_mask"][:, 0] = 0
+            elif kind == "seq_emb":
+                d["tensor"] = torch.zeros_like(d["tensor"])
+                d["input_mask"] = torch.ones_like(d["input_mask"])
+                d["input_mask"][:, 0] = False
+                d["target_mask"] = torch.ones_like(d["target_mask"])
+                d["decoder_attention_mask"][:] = False
+            else:
+                d["input_mask"][:] = True
+                d["target_mask"][:] = False
+        return out
+
+    @torch.no_grad()
+    def _guided_logits(self, mod_dict, target_mod, conditioning, guidance_scale, decode_mask=None):
+        if target_mod in conditioning:
+            raise ValueError("the target modality cannot be part of the conditioning that is dropped")
+        cond, mod_pos = self.forward_enc_dec_maskgit_batched(mod_dict, target_mod, decode_mask=decode_mask)
+        cond = cond.float()                                   # (the next forward reuses the logits workspace)
+        unc, _ = self.forward_enc_dec_maskgit_batched(self.unconditional_dict(mod_dict, conditioning), target_mod, decode_mask=decode_mask)
+        return (unc.float() + (cond - unc.float()) * float(guidance_scale)).contiguous(), mod_pos
+
+    @torch.no_grad()
+    def guided_maskgit_step_batched(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, conditioning=(), guidance_scale=1.0,
+                                    seed=None, generator=None, uniforms=None):
+        """MaskGIT step on logits_uncond + (logits_cond - logits_uncond) * guidance_scale (fp32), generate.py:665-703."""
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        logits, mod_pos = self._guided_logits(mod_dict, target_mod, list(conditioning), guidance_scale)
+        return self._sample_and_commit(mod_dict, target_mod, logits, mod_pos, num_select, temperature, top_k, top_p, generator, uniforms)
+
+    @torch.no_grad()
+    def guided_roar_step_batched(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, conditioning=(), guidance_scale=1.0,
+                                 seed=None, generator=None, uniforms=None, order_noise=None):
+        """ROAR step with classifier-free guidance (generate.py:783-816): both passes decode the same random positions."""
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        dm = self.roar_decode_mask(mod_dict, target_mod, num_select, generator, order_noise)
+        logits, mod_pos = self._guided_logits(mod_dict, target_mod, list(conditioning), guidance_scale, decode_mask=dm)
+        return self._sample_and_commit(mod_dict, target_mod, logits, mod_pos, logits.shape[1], temperature, top_k, top_p, generator, uniforms)
+
+    def multi_guided_maskgit_step_batched(self, *a, **k):
+        raise NotImplementedError("multi-condition guidance is not implemented yet (SURVEY §8 f2)")
 
     def autoregressive_step_batched(self, *a, **k):
         raise NotImplementedError("autoregressive decoding (with a K/V cache) is not implemented yet (SURVEY §8 f2)")

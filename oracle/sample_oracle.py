@@ -125,3 +125,21 @@ def upstream_filter_survivors(row, top_k, top_p):
         rem[..., 0] = 0
         logits[torch.gather(rem, -1, torch.argsort(si, dim=-1))] = float("-inf")
     return torch.isfinite(logits[0]).numpy()
+
+
+def roar_positions(target_mask, order_noise, num_select):
+    """Positions one ROAR step decodes (upstream forward_mask_decoder_roar, generate.py:481-514): per sample the first
+    n = min(num_select, #unmasked of sample 0) entries of argsort(target_mask + order_noise * 1e-6) - the still-masked positions with
+    the smallest noise - returned in ascending position order (the HIP path decodes them in position order).  fp32 keys as upstream."""
+    tm = np.asarray(target_mask, dtype=bool)
+    B, L = tm.shape
+    n = min(int(num_select), int((~tm[0]).sum()))
+    key = tm.astype(np.float32) + np.asarray(order_noise, dtype=np.float32).reshape(1, L) * np.float32(1e-6)
+    order = np.argsort(key, axis=1, kind="stable")[:, :n]
+    return np.sort(order, axis=1).astype(np.int32)
+
+
+def cfg_logits(cond, uncond, scale):
+    """Classifier-free guidance on fp32 logits (generate.py:684): uncond + (cond - uncond) * scale, one rounding per operation."""
+    c, u = np.asarray(cond, dtype=np.float32), np.asarray(uncond, dtype=np.float32)
+    return (u + (c - u) * np.float32(scale)).astype(np.float32)

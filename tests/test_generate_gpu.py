@@ -114,3 +114,88 @@ def test_maskgit_step(case_name, target):
     assert bool(dev_md[target]["target_mask"].all()) and not bool(dev_md[target]["input_mask"].any())
     tk = dev_md[target]["tensor"]
     assert int(tk.min()) >= 0 and int(tk.max()) < spec.vocab
+
+
+def _oracle_logits(P, cfg, md, target, positions, B):
+    """Oracle forward of one generation step decoding ``positions`` (same for every sample) of ``target``."""
+    num = O._Num(True)
+    spec = cfg.mod(target)
+    with torch.no_grad():
+        n_enc = max(int(sum((~md[m.name]["input_mask"].reshape(B, -1)[b]).sum() for m in cfg.mods if m.in_enc)) for b in range(B))
+        enc = O.select_encoder(P, cfg, md, n_enc, num)
+        x = O.encoder_forward(P, cfg, enc["tokens"] + enc["emb"], enc["mask"], num)
+        ctx = num.linear(x, P["decoder_proj_context.weight"], P["decoder_proj_context.bias"]) + enc["emb"]
+        _, e, _ = O.embed_decoder_modality(P, spec, md[target])
+        e = e.float()[:, torch.as_tensor(positions, dtype=torch.long)]
+        y = O.decoder_forward(P, cfg, P["mask_token"].expand(B, len(positions), -1) + e, ctx, enc["mask"], None, num)
+        return num.linear(y, P[f"decoder_embeddings.{target}.to_logits.weight"], None)
+
+
+def test_roar_and_guided_steps():
+    """ROAR (random order) step and the classifier-free-guided MaskGIT / ROAR steps (generate.py:481-514, :665-703, :745-816): the
+    decoded positions equal the restated argsort rule, the logits follow the oracle pipeline on those positions, guidance combines the
+    two passes in fp32 exactly, sampling + commit are bit-exact given the kernel's logits and the same uniforms."""
+    case_name, target = "ti_mod7", "tok_depth@224"
+    case = build_case(case_name)
+    cfg = case["cfg"]
+    model = build_hip_model(cfg, case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    model.load_state_dict(case["sd"], strict=True)
+    model = model.cuda().eval()
+    P = tie({k: v.clone() for k, v in case["sd"].items()}, cfg, case["share_embedding"])
+    B, spec = 2, cfg.mod(target)
+    Npos = spec.n_pos
+    md = gen_mod_dict(cfg, B, target, seed=3, cond_tokens=40)
+    dev = lambda d: {k: {a: b.cuda() for a, b in v.items()} for k, v in d.items()}
+    smp = sampler(model)
+    # ---- ROAR ----
+    dev_md = dev(md)
+    noise = torch.rand(Npos, generator=torch.Generator().manual_seed(9))
+    n_sel = 40
+    want_pos = S.roar_positions(md[target]["target_mask"].reshape(B, -1).numpy(), noise.numpy(), n_sel)
+    logits, mod_pos = smp.forward_enc_dec_roar_batched(dev_md, target, n_sel, order_noise=noise.cuda())
+    assert np.array_equal(mod_pos.cpu().numpy(), want_pos) and tuple(logits.shape) == (B, n_sel, spec.vocab)
+    assert np.array_equal(want_pos[0], want_pos[1])
+    want = _oracle_logits(P, cfg, md, target, want_pos[0], B)
+    err = float((logits.float().cpu() - want).norm() / want.norm())
+    record("generate.roar_logits", case=case_name, rel=err)
+    assert err < 1.2e-2, err
+    u = torch.rand(B * n_sel, generator=torch.Generator().manual_seed(6))
+    lf = logits.float().cpu().numpy().reshape(B * n_sel, -1).copy()
+    smp.roar_step_batched(dev_md, target, n_sel, 1.0, 0, 0.95, uniforms=u.cuda(), order_noise=noise.cuda())
+    ids, _ = S.sample_tokens(lf, 1.0, 0, 0.95, u.numpy())
+    got_t = dev_md[target]["tensor"].cpu().numpy().reshape(B, -1)
+    tmk, im = dev_md[target]["target_mask"].cpu().numpy().reshape(B, -1), dev_md[target]["input_mask"].cpu().numpy().reshape(B, -1)
+    for b in range(B):
+        assert np.array_equal(got_t[b, want_pos[b]], ids.reshape(B, n_sel)[b])
+        chosen = np.zeros(Npos, dtype=bool); chosen[want_pos[b]] = True
+        assert np.array_equal(tmk[b], chosen) and np.array_equal(~im[b], chosen)          # exactly the chosen positions were committed
+    # a second step decodes n_sel OTHER positions
+    smp.roar_step_batched(dev_md, target, n_sel, 1.0, 0, 0.95, generator=torch.Generator(device="cuda").manual_seed(1))
+    assert int(dev_md[target]["target_mask"].sum()) == 2 * B * n_sel
+    # ---- classifier-free guidance ----
+    cond_mod = next(m.name for m in cfg.mods if m.in_enc and m.name != target and m.kind == "tok"
+                    and bool((~md[m.name]["input_mask"]).any()))
+    dev_md = dev(md)
+    unc_md = smp.unconditional_dict(dev_md, [cond_mod])
+    assert bool(unc_md[cond_mod]["input_mask"].all()) and not bool(unc_md[cond_mod]["target_mask"].any())       # empty_img_modality
+    assert bool((~dev_md[cond_mod]["input_mask"]).any())                                                     # ... on a copy
+    lc, _ = smp.forward_enc_dec_maskgit_batched(dev_md, target); lc = lc.float().cpu().numpy()
+    lu, _ = smp.forward_enc_dec_maskgit_batched(unc_md, target); lu = lu.float().cpu().numpy()
+    assert float(np.abs(lc - lu).max()) > 1e-3                                                                # the conditioning matters
+    g, pos = smp._guided_logits(dev_md, target, [cond_mod], 2.5)
+    want_g = S.cfg_logits(lc, lu, 2.5)
+    assert np.array_equal(g.cpu().numpy(), want_g)
+    u = torch.rand(B * Npos, generator=torch.Generator().manual_seed(8))
+    k_sel = 30
+    before = {k: v.clone() for k, v in dev_md[target].items()}
+    smp.guided_maskgit_step_batched(dev_md, target, k_sel, 0.7, 50, 0.0, conditioning=[cond_mod], guidance_scale=2.5, uniforms=u.cuda())
+    ids, probs = S.sample_tokens(want_g.reshape(B * Npos, -1), 0.7, 50, 0.0, u.numpy())
+    t = before["tensor"].cpu().numpy().reshape(B, -1).copy()
+    im, tmk = before["input_mask"].cpu().numpy().reshape(B, -1).copy(), before["target_mask"].cpu().numpy().reshape(B, -1).copy()
+    S.maskgit_commit(probs.reshape(B, Npos), ids.reshape(B, Npos), pos.cpu().numpy(), k_sel, t, im, tmk)
+    assert np.array_equal(dev_md[target]["tensor"].cpu().numpy().reshape(B, -1), t)
+    assert np.array_equal(dev_md[target]["target_mask"].cpu().numpy().reshape(B, -1), tmk)
+    # guided ROAR: runs, commits exactly n_sel positions per sample
+    smp.guided_roar_step_batched(dev_md, target, n_sel, 1.0, 0, 0.9, conditioning=[cond_mod], guidance_scale=1.5,
+                                 generator=torch.Generator(device="cuda").manual_seed(4))
+    assert int(dev_md[target]["target_mask"].sum()) == B * (k_sel + n_sel)

@@ -48,3 +48,20 @@ def test_commit_keeps_the_most_confident():
     t, im, tm = np.zeros((1, 6), np.int64), np.ones((1, 6), bool), np.zeros((1, 6), bool)
     top = S.maskgit_commit(prob, samples, pos, 2, t, im, tm)
     assert top.tolist() == [[1, 2]] and t[0, 2] == 8 and t[0, 0] == 9 and not im[0, 2] and tm[0, 0] and im[0, 5]
+
+
+def test_roar_positions_follow_upstream_argsort():
+    """oracle roar_positions == upstream's argsort(target_mask + rand * 1e-6)[:, :n] (generate.py:495-499), as a set per sample."""
+    import torch
+    g = torch.Generator().manual_seed(0)
+    B, L_ = 3, 50
+    tm = torch.rand(B, L_, generator=g) < 0.4
+    tm[1] = tm[0]; tm[2] = tm[0]                      # upstream assumes one decoded count for the batch
+    noise = torch.rand(L_, generator=g)
+    n = 7
+    ids = torch.argsort(tm + noise.unsqueeze(0) * 1e-6, dim=1)[:, :n]
+    got = S.roar_positions(tm.numpy(), noise.numpy(), n)
+    for b in range(B):
+        assert sorted(ids[b].tolist()) == got[b].tolist()
+        assert not tm[b, got[b]].any()
+    assert S.roar_positions(tm.numpy(), noise.numpy(), 10 ** 6).shape[1] == int((~tm[0]).sum())
