@@ -153,10 +153,12 @@ typedef struct fm_attn_args {
     /* backward only */
     const void* dO; void* dQ; void* dK; void* dV;
     int32_t lddo, lddq, lddk, lddv;
-    int32_t force_tr, pad_;   /* -1 = library default, 0 = 2-byte LDS gathers, 1 = transpose reads */
+    int32_t force_tr;         /* -1 = library default, 0 = 2-byte LDS gathers, 1 = transpose reads */
+    int32_t kv_batch_rows;    /* forward only: rows between two samples in K / V (0 = Nk).  A K/V cache of capacity T holds sample b's
+                                 keys at rows [b*T, b*T + Nk): incremental decoding attends to the Nk filled rows without copying */
 } fm_attn_args;
 int fm_attn_fwd(const fm_attn_args* args, void* stream);
-int fm_attn_bwd(const fm_attn_args* args, void* stream);   /* Nq, Nk <= 256 */
+int fm_attn_bwd(const fm_attn_args* args, void* stream);   /* any Nq, Nk (single pass up to 512 rows, 256-row chunks above) */
 void fm_set_attn_transpose_read(int on);
 int fm_get_attn_transpose_read(void);
 

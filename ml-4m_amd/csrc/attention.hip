@@ -41,6 +41,7 @@ struct AttnArgs {
     // backward only
     const bf16_t* dO; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
     int lddo, lddq, lddk, lddv;
+    int kvr;                      // forward: rows between two samples in K / V (>= Nk: a K/V cache filled up to Nk)
     int chunk;                    // rows of the two LDS tiles of the backward (a multiple of 32; >= max(Nq, Nk) padded when one chunk does)
 };
 
@@ -109,8 +110,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int qc = q < a.Nq ? q : a.Nq - 1;
 
     const bf16_t* Qb = a.Q + (size_t)b * a.Nq * a.ldq + h * HD;
-    const bf16_t* Kb = a.K + (size_t)b * a.Nk * a.ldk + h * HD;
-    const bf16_t* Vb = a.V + (size_t)b * a.Nk * a.ldv + h * HD;
+    const bf16_t* Kb = a.K + (size_t)b * a.kvr * a.ldk + h * HD;
+    const bf16_t* Vb = a.V + (size_t)b * a.kvr * a.ldv + h * HD;
 
     bf16x8_t qf[4];
 #pragma unroll
@@ -574,6 +575,8 @@ int fill(AttnArgs& a, const fm_attn_args* p, const char* who) {
     a.B = p->B; a.H = p->H; a.Nq = p->Nq; a.Nk = p->Nk; a.scale = p->scale; a.mask_kind = p->mask_kind;
     a.kpad = (const uint8_t*)p->kpad; a.cs = p->cs; a.modq = p->modq; a.modk = p->modk; a.dense = (const uint8_t*)p->dense;
     a.causal = p->causal;
+    a.kvr = p->kv_batch_rows > 0 ? p->kv_batch_rows : p->Nk;
+    FM_CHECK_ARG(a.kvr >= p->Nk, "%s: kv_batch_rows=%d < Nk=%d", who, p->kv_batch_rows, p->Nk);
     a.dO = (const bf16_t*)p->dO; a.dQ = (bf16_t*)p->dQ; a.dK = (bf16_t*)p->dK; a.dV = (bf16_t*)p->dV;
     a.lddo = p->lddo; a.lddq = p->lddq; a.lddk = p->lddk; a.lddv = p->lddv;
     return 0;
@@ -615,6 +618,7 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     AttnArgs a{};
     if (int rc = fill(a, p, "fm_attn_bwd")) return rc;
     FM_CHECK_ARG(a.dO && a.dQ && a.dK && a.dV && a.stat_m && a.stat_l, "fm_attn_bwd: null pointer");
+    FM_CHECK_ARG(a.kvr == a.Nk, "fm_attn_bwd: kv_batch_rows is a forward-only (K/V cache) option");
     FM_CHECK_ARG(p->lddo % 8 == 0 && p->lddq % 4 == 0 && p->lddk % 4 == 0 && p->lddv % 4 == 0, "fm_attn_bwd: leading dims");
     const int NqP = (a.Nq + 31) & ~31, NkP = (a.Nk + 31) & ~31;
     // up to 512 rows per tile in one piece (128 KB of tiles); longer sequences in chunks of 256 rows (two workgroups per CU)

@@ -390,6 +390,7 @@ extern "C" int fm_gemm_f32(const fm_gemm_f32_args* p, void* stream) {
 
 static int fill32(Attn32& a, const fm_attn_args* p) {
     FM_CHECK_ARG(p && p->Q && p->K && p->V && p->O && p->head_dim == 64, "fm_attn_f32: bad argument");
+    FM_CHECK_ARG(p->kv_batch_rows == 0 || p->kv_batch_rows == p->Nk, "fm_attn_f32: kv_batch_rows (K/V cache layout) is a bf16 forward option");
     a.Q = (const float*)p->Q; a.K = (const float*)p->K; a.V = (const float*)p->V; a.O = (float*)p->O;
     a.dO = (const float*)p->dO; a.dQ = (float*)p->dQ; a.dK = (float*)p->dK; a.dV = (float*)p->dV;
     a.ldq = p->ldq; a.ldk = p->ldk; a.ldv = p->ldv; a.ldo = p->ldo; a.lddo = p->lddo; a.lddq = p->lddq; a.lddk = p->lddk; a.lddv = p->lddv;

@@ -581,12 +581,12 @@ class FourMEngine:
         return dict(mask_kind=L.MASK_DECODER, cs=None if m.decoder_causal_mask else cs, causal=m.decoder_causal_mask,
                     modq=mod_pre if m.decoder_sep_mask else None, modk=mod_pre if m.decoder_sep_mask else None)
 
-    def trunk_forward(self, enc, dec, save: bool):
-        """Encoder + context projection + decoder on the selected tokens.  Returns the final decoder
-        residual stream (f32) and, when saving, the per-layer state."""
+    def encode_context(self, enc, st=None):
+        """Encoder + encoder_norm + context projection on the selected input tokens (fm.py:477-480, :679).
+        -> (final encoder stream f32, context f32 (Rp, D), key-padding mask kwargs, saved top-level state | None)."""
         m = self.model
-        B, N, Mt = enc["B"], enc["Nt"], dec["Nt"]
-        st = dict(enc_layers=[], dec_layers=[]) if save else None
+        save = st is not None
+        B, N = enc["B"], enc["Nt"]
         emask = self.keypad(enc["mask"])
         x = enc["x0"]
         for i, blk in enumerate(m.encoder):
@@ -600,6 +600,15 @@ class FourMEngine:
         ctx = self._buf(sv_top, "top", "ctx", (Rp, D), torch.float32)
         pc = m.decoder_proj_context
         ops.gemm_nt(xn, self.w(pc.weight), ctx, epilogue=L.EPI_RESIDUAL, res=enc["emb"], bias=pc.bias, M=R, N=D, K=D)
+        return x, ctx, emask, sv_top
+
+    def trunk_forward(self, enc, dec, save: bool):
+        """Encoder + context projection + decoder on the selected tokens.  Returns the final decoder
+        residual stream (f32) and, when saving, the per-layer state."""
+        m = self.model
+        B, N, Mt = enc["B"], enc["Nt"], dec["Nt"]
+        st = dict(enc_layers=[], dec_layers=[]) if save else None
+        x, ctx, emask, sv_top = self.encode_context(enc, st)
         y = dec["x0"]
         smask = self.decoder_mask(dec["cs"], dec["mod_pre"]) if "cs" in dec else dec["sa_mask"]
         for i, blk in enumerate(m.decoder):

@@ -261,9 +261,11 @@ def _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk,
 
 
 def attn_fwd(q, k, v, o, B, H, Nq, Nk, scale, *, mask_kind=L.MASK_NONE, kpad=None, cs=None, modq=None, modk=None, dense=None,
-             causal=False, stat_m=None, stat_l=None, force_tr=-1):
-    """q/k/v/o: 2-D bf16 views whose row t of sample b is row b*N + t; head h occupies columns [64h, 64h+64)."""
+             causal=False, stat_m=None, stat_l=None, force_tr=-1, kv_batch_rows=0):
+    """q/k/v/o: 2-D bf16 views whose row t of sample b is row b*N + t; head h occupies columns [64h, 64h+64).
+    kv_batch_rows > Nk: k / v are views of a K/V cache whose sample b starts at row b * kv_batch_rows."""
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
+    a.kv_batch_rows = kv_batch_rows
     if q.dtype == torch.float32:
         L.check(L.attn_f32_fwd(C.byref(a), _stream()))
         return o

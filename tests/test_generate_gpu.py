@@ -199,3 +199,67 @@ def test_roar_and_guided_steps():
     smp.guided_roar_step_batched(dev_md, target, n_sel, 1.0, 0, 0.9, conditioning=[cond_mod], guidance_scale=1.5,
                                  generator=torch.Generator(device="cuda").manual_seed(4))
     assert int(dev_md[target]["target_mask"].sum()) == B * (k_sel + n_sel)
+
+
+@pytest.mark.parametrize("case_name,target", [("micro_swiglu", None), ("ti_mod7", "caption")])
+def test_autoregressive_kv_cache(case_name, target):
+    """Autoregressive decoding of a sequence modality with the K/V cache (upstream generate.py:850-914 recomputes the whole prefix per
+    token): the logits of every step follow the oracle's NON-cached recompute on the same prefix (full decoder under a causal mask),
+    and the sampled ids are bit-exact given the kernel's logits and the same uniforms."""
+    case = build_case(case_name)
+    cfg = case["cfg"]
+    if target is None:
+        target = next(m.name for m in cfg.mods if m.kind == "seq" and m.in_dec)
+    spec = cfg.mod(target)
+    model = build_hip_model(cfg, case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    model.load_state_dict(case["sd"], strict=True)
+    model = model.cuda().eval()
+    P = tie({k: v.clone() for k, v in case["sd"].items()}, cfg, case["share_embedding"])
+    B, n_prompt, n_gen = 3, 2, 9
+    md = O.synthetic_mod_dict(cfg, B, 30, 0, seed=11, no_target=tuple(m.name for m in cfg.mods))
+    for name, d in md.items():
+        d["target_mask"][:] = True
+    t = md[target]
+    g = torch.Generator().manual_seed(12)
+    t["tensor"] = torch.randint(5, spec.vocab, t["tensor"].shape, generator=g, dtype=t["tensor"].dtype)
+    t["input_mask"][:] = True; t["input_mask"][:, :n_prompt] = False          # a short visible prompt ...
+    t["target_mask"][:] = True; t["target_mask"][:, n_prompt:n_prompt + n_gen] = False      # ... then the positions to generate
+    dev_md = {k: {a: b.cuda() for a, b in v.items()} for k, v in md.items()}
+    smp = sampler(model)
+    steps = n_gen
+    u = torch.rand(steps, B, generator=torch.Generator().manual_seed(13))
+    out = smp.autoregressive_generate(dev_md, target, temperature=0.9, top_k=40, top_p=0.0, use_eos=False, uniforms=u.cuda(), keep_logits=True)
+    assert tuple(out.shape) == (B, 1 + steps)
+    assert torch.equal(out[:, 0].cpu(), t["tensor"].reshape(B, -1)[:, n_prompt].long())      # starts from the first target token
+    got = [l.cpu() for l in smp.last_ar["logits"]]
+    # ---- sampling bit-exact from the kernel's own logits ----
+    for i in range(steps):
+        ids, _ = S.sample_tokens(got[i].numpy().copy(), 0.9, 40, 0.0, u[i].numpy())
+        assert np.array_equal(out[:, i + 1].cpu().numpy(), ids), i
+    # ---- logits vs the oracle's non-cached recompute of the same prefix ----
+    num = O._Num(True)
+    with torch.no_grad():
+        n_enc = max(int(sum((~md[m.name]["input_mask"].reshape(B, -1)[b]).sum() for m in cfg.mods if m.in_enc)) for b in range(B))
+        enc = O.select_encoder(P, cfg, md, n_enc, num)
+        x = O.encoder_forward(P, cfg, enc["tokens"] + enc["emb"], enc["mask"], num)
+        ctx = num.linear(x, P["decoder_proj_context.weight"], P["decoder_proj_context.bias"]) + enc["emb"]
+        _, e, _ = O.embed_decoder_modality(P, spec, md[target])
+        y_emb = e.float()[:, n_prompt:n_prompt + n_gen]
+        table = P[f"decoder_embeddings.{target}.token_emb.weight"]
+        worst = 0.0
+        for i in range(steps):
+            cur = i + 1
+            prefix = out[:, :cur].cpu()
+            y = table[prefix] + y_emb[:, :cur]
+            causal = torch.ones(cur, cur, dtype=torch.bool).triu(1)[None].expand(B, -1, -1)
+            yd = O.decoder_forward(P, cfg, y, ctx, enc["mask"], causal, num)
+            want = num.linear(yd[:, -1], P[f"decoder_embeddings.{target}.to_logits.weight"], None)
+            worst = max(worst, float((got[i] - want).norm() / want.norm()))
+    record("generate.autoregressive_logits", case=case_name, worst_rel=worst, steps=steps)
+    assert worst < 1.2e-2, worst
+    # ---- end-of-sequence: decoding stops as soon as every sample has produced it (here: a batch of one, same draws) ----
+    eos = int(out[0, 3])
+    one = {k: {a: b[:1].cuda() for a, b in v.items()} for k, v in md.items()}
+    out2 = smp.autoregressive_generate(one, target, temperature=0.9, top_k=40, top_p=0.0, use_eos=True, eos_token=eos, uniforms=u[:, :1].cuda())
+    first = int((out[0] == eos).nonzero()[0])
+    assert out2.shape[1] == first + 1 and torch.equal(out2[0], out[0, :first + 1])

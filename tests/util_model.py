@@ -13,7 +13,7 @@ def build_hip_model(cfg, share_embedding=True, norm_bias=False, learned_pos=()):
     enc, dec, info = {}, {}, {}
     for m in cfg.mods:
         side = int(round(np.sqrt(m.n_pos))) if not m.is_seq else 0
-        info[m.name] = {"id": m.id, "type": {"tok": "img", "patch": "img", "seq": "seq", "seq_emb": "seq_emb"}[m.kind]}
+        info[m.name] = {"id": m.id, "type": {"tok": "img", "patch": "img", "seq": "seq", "seq_emb": "seq_emb"}[m.kind], "max_tokens": m.n_pos}
         sincos = m.name not in learned_pos
         if m.in_enc:
             if m.kind == "tok":
