@@ -368,9 +368,98 @@ class GenerationSampler(nn.Module):
                 break
         return out
 
+    @staticmethod
+    def sentinel_ids(text_tokenizer, match_str="[S_"):
+        """Ids of the span-masking sentinel tokens "[S_0]", "[S_1]", ... of a ``tokenizers.Tokenizer`` (text_tokenizer.py:108-112)."""
+        return {i for tok, i in text_tokenizer.get_vocab().items() if tok.startswith(match_str)}
+
+    @staticmethod
+    def merge_span_masking(input_ids, decoder_ids, sentinels):
+        """Undo T5-style span masking (text_tokenizer.py:115-136): every sentinel of the input is replaced by the tokens the decoder
+        produced after that sentinel; decoder tokens before its first sentinel are dropped."""
+        spans, cur = {}, None
+        for tok in decoder_ids:
+            if tok in sentinels:
+                cur = tok
+                spans.setdefault(cur, [])
+            elif cur is not None:
+                spans[cur].append(tok)
+        out = []
+        for tok in input_ids:
+            out.extend(spans.get(tok, [])) if tok in sentinels else out.append(tok)
+        return out
+
+    def merge_sequences_batched(self, mod_dict, pred_ids, target_mod, text_tokenizer, default_sentinel="[S_1]"):
+        """Write generated sequences back into ``mod_dict[target_mod]`` (generate.py:550-626): per sample the visible input ids with
+        their sentinels expanded by the prediction, right-padded with [PAD] to the longest sample; everything becomes input
+        (input_mask False on real tokens), nothing is left to decode."""
+        d = mod_dict[target_mod]
+        dev = d["tensor"].device
+        B = d["tensor"].shape[0]
+        tens = d["tensor"].reshape(B, -1).cpu()
+        vis = ~d["input_mask"].reshape(B, -1).bool().cpu()
+        preds = pred_ids.reshape(B, -1).cpu().tolist()
+        sent = self.sentinel_ids(text_tokenizer)
+        pad_id = text_tokenizer.token_to_id("[PAD]")
+        merged = []
+        for b in range(B):
+            inp = tens[b][vis[b]].tolist() or [text_tokenizer.get_vocab()[default_sentinel]]
+            merged.append(self.merge_span_masking(inp, preds[b], sent))
+        Lm = max(1, max(len(x) for x in merged))
+        t = torch.full((B, Lm), pad_id, dtype=d["tensor"].dtype)
+        im = torch.ones(B, Lm, dtype=torch.bool)
+        for b, ids in enumerate(merged):
+            t[b, :len(ids)] = torch.tensor(ids, dtype=t.dtype)
+            im[b, :len(ids)] = False
+        mod_dict[target_mod] = {"tensor": t.to(dev), "input_mask": im.to(dev), "target_mask": im.clone().to(dev),
+                                "decoder_attention_mask": torch.zeros(B, Lm, dtype=torch.bool, device=dev)}
+        return mod_dict
+
     def autoregressive_step_batched(self, mod_dict, target_mod, temperature, top_k, top_p, use_eos=True, eos_token=None, start_tokens=None,
-                                    text_tokenizer=None, seed=None):
-        """Upstream signature (generate.py:850): needs the text tokenizer to merge the prediction back into ``mod_dict`` - that
-        host-side step (merge_sequences_batched, generate.py:581-626) is outside this package; call ``autoregressive_generate`` for the
-        ids and merge them with upstream's helper."""
-        raise NotImplementedError("use autoregressive_generate(); merging the ids back into mod_dict is tokenizer-level host code upstream")
+                                    text_tokenizer=None, seed=None, generator=None):
+        """Upstream's step (generate.py:850-914): decode the sequence (K/V cache) and merge it back into ``mod_dict``."""
+        if text_tokenizer is None:
+            raise ValueError("autoregressive_step_batched needs the text tokenizer to merge the prediction (sentinel / [PAD] ids); "
+                             "autoregressive_generate() returns the raw ids without one")
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        out = self.autoregressive_generate(mod_dict, target_mod, temperature, top_k, top_p, use_eos, eos_token, start_tokens, generator)
+        return self.merge_sequences_batched(mod_dict, out, target_mod, text_tokenizer)
+
+    def guided_autoregressive_step_batched(self, *a, **k):
+        raise NotImplementedError("classifier-free guidance for autoregressive decoding is not implemented yet (SURVEY §8 f2)")
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    # chained schedules  (generate.py:1029-1096)
+    # ------------------------------------------------------------------------------------------------------------------------
+    def generate(self, mod_dict, schedule, top_k=0.0, top_p=0.0, text_tokenizer=None, verbose=False, seed=None):
+        """Run a generation schedule: a list of {target_domain, scheme, num_tokens, temperature, cfg_scale, cfg_cond_domains} steps
+        (built by upstream's fourm/utils/generation.py build_chained_generation_schedules).  Works on a copy of ``mod_dict``."""
+        mod_dict = {m: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for m, d in mod_dict.items()}
+        for step, info in enumerate(schedule):
+            target, temp = info["target_domain"], info["temperature"]
+            scale, cond = info.get("cfg_scale", 1.0), list(info.get("cfg_cond_domains", []))
+            seed_i = seed + step if seed is not None else None
+            guided = scale != 1.0 and len(cond) > 0
+            kind = self.model.modality_info[target]["type"]
+            if verbose:
+                print(f"[generate] step {step}: {target} {info.get('scheme', 'autoregressive')} temperature {temp}")
+            if kind == "img":
+                scheme, k = info["scheme"].lower(), info["num_tokens"]
+                if scheme not in ("maskgit", "roar"):
+                    raise ValueError("Invalid sampling scheme")
+                if guided:
+                    fn = self.guided_maskgit_step_batched if scheme == "maskgit" else self.guided_roar_step_batched
+                    mod_dict = fn(mod_dict, target, k, temp, top_k, top_p, conditioning=cond, guidance_scale=scale, seed=seed_i)
+                else:
+                    fn = self.maskgit_step_batched if scheme == "maskgit" else self.roar_step_batched
+                    mod_dict = fn(mod_dict, target, k, temp, top_k, top_p, seed=seed_i)
+            elif kind in ("seq", "seq_token"):
+                if guided:
+                    mod_dict = self.guided_autoregressive_step_batched(mod_dict, target, temp, top_k, top_p, text_tokenizer=text_tokenizer,
+                                                                       conditioning=cond, guidance_scale=scale, seed=seed_i)
+                else:
+                    mod_dict = self.autoregressive_step_batched(mod_dict, target, temp, top_k, top_p, text_tokenizer=text_tokenizer, seed=seed_i)
+            else:
+                raise ValueError("Invalid schedule")
+        return mod_dict

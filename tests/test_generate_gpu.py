@@ -263,3 +263,16 @@ def test_autoregressive_kv_cache(case_name, target):
     out2 = smp.autoregressive_generate(one, target, temperature=0.9, top_k=40, top_p=0.0, use_eos=True, eos_token=eos, uniforms=u[:, :1].cuda())
     first = int((out[0] == eos).nonzero()[0])
     assert out2.shape[1] == first + 1 and torch.equal(out2[0], out[0, :first + 1])
+    # ---- the upstream-shaped step: decode + merge back into mod_dict (tokenizer-level merge tested on the CPU) ----
+    class Tok:
+        vocab = {"[PAD]": 0, **{f"[S_{i}]": 5 + i for i in range(6)}}
+
+        def get_vocab(self):
+            return dict(self.vocab)
+
+        def token_to_id(self, t):
+            return self.vocab.get(t)
+    dev_md = {k: {a: b.cuda() for a, b in v.items()} for k, v in md.items()}
+    merged = smp.autoregressive_step_batched(dev_md, target, 0.9, 40, 0.0, use_eos=False, text_tokenizer=Tok(), seed=3)[target]
+    assert merged["tensor"].shape[0] == B and merged["tensor"].shape == merged["input_mask"].shape == merged["target_mask"].shape
+    assert merged["tensor"].is_cuda and torch.equal(merged["input_mask"], merged["target_mask"]) and not bool(merged["input_mask"][:, 0].any())

@@ -1,4 +1,3 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-python tools/ar_bench.py 16 64 2>&1 | grep -v Warn | tail -4
-python tools/ar_bench.py 1 64 2>&1 | grep -v Warn | tail -1
+timeout 900 python -m pytest tests/test_generate_gpu.py -q -m gpu --tb=short -x 2>&1 | grep -v Warning | tail -12 | cut -c1-400
