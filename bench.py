@@ -192,8 +192,14 @@ def cpu_baseline_reference_worker(batch=8, steps=3):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import ref_stubs
     ref_stubs.install()
+    # this child process times UPSTREAM's package: `fourm` must resolve to the reference tree, not to ml-4m_amd/fourm
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p) != os.path.join(ROOT, "ml-4m_amd")]
+    for name in [n for n in sys.modules if n == "fourm" or n.startswith("fourm.")]:
+        del sys.modules[name]
     sys.path.insert(0, REFERENCE_TREE)
     from tests.golden.make_golden import upstream_model, clone_mod_dict
+    import fourm.models.fm as ref_fm
+    assert os.path.abspath(ref_fm.__file__).startswith(REFERENCE_TREE), ref_fm.__file__
     from oracle import fourm_oracle as O
     threads = min(64, os.cpu_count() or 1)
     torch.set_num_threads(threads)
