@@ -149,6 +149,28 @@ int main(int argc, char** argv) {
         printf("sum over a 4M-B step (ms):");
         for (size_t k = 0; k < cfgs.size(); ++k) printf("  c%d: %.2f", cfgs[k], tot[k] / 1e3);
         printf("\n");
+    } else if (mode == "cold") {
+        // the same GEMM on operands that are resident in the Infinity Cache (one buffer set reused) vs streamed from HBM (a ring of
+        // buffer sets larger than the 256 MB cache): how much of the in-situ / lab gap is operand residency
+        struct { const char* name; int N, K; } cases[] = {{"N768 K768", 768, 768}, {"N2304 K768", 2304, 768}, {"N768 K4096", 768, 4096}};
+        for (auto& c : cases) {
+            const int SETS = 12;
+            std::vector<void*> Xs, Os;
+            void* W = dev_rand_bf16((size_t)c.N * c.K, 1);
+            for (int i = 0; i < SETS; ++i) { Xs.push_back(dev_rand_bf16((size_t)R * c.K, 3 + i)); Os.push_back(dev_zero((size_t)R * c.N * 2)); }
+            fm_gemm_nt_args a{};
+            a.W = W; a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.epilogue = FM_EPI_BF16;
+            fm_set_gemm_nt_config(265);
+            double warm = 1e30, cold = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                a.X = Xs[0]; a.out = Os[0];
+                warm = std::min(warm, time_us([&] { fm_gemm_nt(&a, 0); }, 24, 2));
+                int i = 0;
+                cold = std::min(cold, time_us([&] { a.X = Xs[i % SETS]; a.out = Os[i % SETS]; ++i; fm_gemm_nt(&a, 0); }, 24, 2));
+            }
+            printf("%-12s cache-resident operands %7.1f us   streamed from HBM %7.1f us\n", c.name, warm, cold);
+            CK(hipFree(W)); for (auto p : Xs) CK(hipFree(p)); for (auto p : Os) CK(hipFree(p));
+        }
     } else if (mode == "tnmulti") {
         // all weight-gradient GEMMs of one 4M-B layer: one fm_gemm_tn launch each  vs  ONE fm_gemm_tn_multi launch
         struct Shape { int N, K; };
