@@ -8,8 +8,7 @@ cumsum / argsort / gather / multinomial / topk / scatter chain.
 
 Scope: the MaskGIT and ROAR (random order) schemes, batched, with and without classifier-free guidance, for
 grid-token target modalities, and autoregressive decoding of sequence modalities with a K/V cache (upstream re-runs the decoder
-on the whole prefix per token, generate.py:850-914).  Multi-condition guidance, chained schedules and the tokenizer-level merge of
-generated sequences are not implemented and raise; nothing falls back to eager PyTorch.
+on the whole prefix per token, generate.py:850-914).  Guided autoregressive decoding and generate_sam_dense are not implemented and raise; nothing falls back to eager PyTorch.
 
 Determinism: the only randomness is one uniform per decoded position drawn with ``torch.rand`` from the generator passed in (or the
 device default): same logits + same uniforms -> same tokens (csrc/sample.hip, bit-exact against oracle/sample_oracle.py).
@@ -254,8 +253,77 @@ class GenerationSampler(nn.Module):
         logits, mod_pos = self._guided_logits(mod_dict, target_mod, list(conditioning), guidance_scale, decode_mask=dm)
         return self._sample_and_commit(mod_dict, target_mod, logits, mod_pos, logits.shape[1], temperature, top_k, top_p, generator, uniforms)
 
-    def multi_guided_maskgit_step_batched(self, *a, **k):
-        raise NotImplementedError("multi-condition guidance is not implemented yet (SURVEY §8 f2)")
+    # conjunction of several weighted conditions: l_uncond + sum_i w_i (l_cond_i - l_uncond)   (generate.py:705-743, :817-848)
+    @torch.no_grad()
+    def _multi_guided_logits(self, uncond_dict, cond_dicts, cond_weights, target_mod, decode_mask=None):
+        conds = []
+        for cd in cond_dicts:
+            lc, _ = self.forward_enc_dec_maskgit_batched(cd, target_mod, decode_mask=decode_mask)
+            conds.append(lc.float())                           # (copies: the next forward reuses the logits workspace)
+        lu, mod_pos = self.forward_enc_dec_maskgit_batched(uncond_dict, target_mod, decode_mask=decode_mask)
+        lu = lu.float()
+        acc = torch.zeros_like(lu)
+        for w, lc in zip(cond_weights, conds):
+            acc += float(w) * (lc - lu)
+        return (lu + acc).contiguous(), mod_pos
+
+    def _mirror_target(self, uncond_dict, cond_dicts, target_mod):
+        for cd in cond_dicts:
+            for k in ("tensor", "input_mask", "target_mask"):
+                cd[target_mod][k] = uncond_dict[target_mod][k].clone()
+
+    @torch.no_grad()
+    def multi_guided_maskgit_step_batched(self, uncond_dict, cond_dicts, cond_weights, target_mod, num_select, temperature, top_k, top_p,
+                                          seed=None, generator=None, uniforms=None):
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        logits, mod_pos = self._multi_guided_logits(uncond_dict, cond_dicts, cond_weights, target_mod)
+        self._sample_and_commit(uncond_dict, target_mod, logits, mod_pos, num_select, temperature, top_k, top_p, generator, uniforms)
+        self._mirror_target(uncond_dict, cond_dicts, target_mod)
+        return uncond_dict, cond_dicts
+
+    @torch.no_grad()
+    def multi_guided_roar_step_batched(self, uncond_dict, cond_dicts, cond_weights, target_mod, num_select, temperature, top_k, top_p,
+                                       seed=None, generator=None, uniforms=None, order_noise=None):
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        dm = self.roar_decode_mask(uncond_dict, target_mod, num_select, generator, order_noise)
+        logits, mod_pos = self._multi_guided_logits(uncond_dict, cond_dicts, cond_weights, target_mod, decode_mask=dm)
+        self._sample_and_commit(uncond_dict, target_mod, logits, mod_pos, logits.shape[1], temperature, top_k, top_p, generator, uniforms)
+        self._mirror_target(uncond_dict, cond_dicts, target_mod)
+        return uncond_dict, cond_dicts
+
+    def generate_multi_guided(self, uncond_dict, cond_dicts, schedule, top_k=0.0, top_p=0.0, text_tokenizer=None, verbose=False, seed=None):
+        """Chained generation under several weighted conditions (generate.py:1169-1228): a modality that has been generated becomes
+        one more condition for the next one.  Image-like targets only, as upstream."""
+        cp = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+        uncond_dict = {m: cp(d) for m, d in uncond_dict.items()}
+        cond_dicts = [{m: cp(d) for m, d in cd.items()} for cd in cond_dicts]
+        cur = schedule[0]["target_domain"]
+        for cd in cond_dicts:
+            cd[cur] = cp(uncond_dict[cur])
+        for info in schedule:
+            target, temp, k, weights = info["target_domain"], info["temperature"], info["num_tokens"], info["cfg_scale"]
+            if cur != target:
+                for cd in cond_dicts:
+                    del cd[cur]
+                    cd[target] = cp(uncond_dict[target])
+                uncond_dict[cur]["input_mask"][:] = True
+                new_cond = {cur: cp(uncond_dict[cur]), target: cp(uncond_dict[target])}
+                new_cond[cur]["input_mask"][:] = False
+                new_cond[cur]["target_mask"][:] = True
+                cond_dicts.append(new_cond)
+                cur = target
+            if self.model.modality_info[target]["type"] != "img":
+                raise NotImplementedError("Only image modalities are supported for now")
+            scheme = info["scheme"].lower()
+            if scheme == "maskgit":
+                uncond_dict, cond_dicts = self.multi_guided_maskgit_step_batched(uncond_dict, cond_dicts, weights, target, k, temp, top_k, top_p, seed=seed)
+            elif scheme == "roar":
+                uncond_dict, cond_dicts = self.multi_guided_roar_step_batched(uncond_dict, cond_dicts, weights, target, k, temp, top_k, top_p, seed=seed)
+            else:
+                raise ValueError("Invalid sampling scheme")
+        return uncond_dict
 
     # ------------------------------------------------------------------------------------------------------------------------
     # autoregressive decoding of a sequence modality with a K/V cache  (generate.py:516-548, :850-914)

@@ -195,6 +195,21 @@ def test_roar_and_guided_steps():
     S.maskgit_commit(probs.reshape(B, Npos), ids.reshape(B, Npos), pos.cpu().numpy(), k_sel, t, im, tmk)
     assert np.array_equal(dev_md[target]["tensor"].cpu().numpy().reshape(B, -1), t)
     assert np.array_equal(dev_md[target]["target_mask"].cpu().numpy().reshape(B, -1), tmk)
+    # several weighted conditions: l_u + sum_i w_i (l_i - l_u) of three separate forwards, then the same sample + commit on every dict
+    md_m = dev(md)
+    cond2 = next(m.name for m in cfg.mods if m.in_enc and m.name not in (target, cond_mod) and m.kind == "tok" and bool((~md[m.name]["input_mask"]).any()))
+    unc = smp.unconditional_dict(md_m, [cond_mod, cond2])
+    c1, c2 = smp.unconditional_dict(md_m, [cond2]), smp.unconditional_dict(md_m, [cond_mod])
+    l1, _ = smp.forward_enc_dec_maskgit_batched(c1, target); l1 = l1.float().cpu().numpy()
+    l2, _ = smp.forward_enc_dec_maskgit_batched(c2, target); l2 = l2.float().cpu().numpy()
+    l0, _ = smp.forward_enc_dec_maskgit_batched(unc, target); l0 = l0.float().cpu().numpy()
+    gm, _ = smp._multi_guided_logits(unc, [c1, c2], [1.5, 0.5], target)
+    want_m = l0 + (np.float32(1.5) * (l1 - l0) + np.float32(0.5) * (l2 - l0))
+    assert np.allclose(gm.cpu().numpy(), want_m, rtol=0, atol=2e-5 * float(np.abs(want_m).max()))
+    unc, conds = smp.multi_guided_maskgit_step_batched(unc, [c1, c2], [1.5, 0.5], target, k_sel, 1.0, 0, 0.9, seed=2)
+    assert int(unc[target]["target_mask"].sum()) == B * k_sel
+    for cd in conds:
+        assert torch.equal(cd[target]["tensor"], unc[target]["tensor"]) and torch.equal(cd[target]["target_mask"], unc[target]["target_mask"])
     # guided ROAR: runs, commits exactly n_sel positions per sample
     smp.guided_roar_step_batched(dev_md, target, n_sel, 1.0, 0, 0.9, conditioning=[cond_mod], guidance_scale=1.5,
                                  generator=torch.Generator(device="cuda").manual_seed(4))
