@@ -8,7 +8,7 @@ cumsum / argsort / gather / multinomial / topk / scatter chain.
 
 Scope: the MaskGIT and ROAR (random order) schemes, batched, with and without classifier-free guidance, for
 grid-token target modalities, and autoregressive decoding of sequence modalities with a K/V cache (upstream re-runs the decoder
-on the whole prefix per token, generate.py:850-914).  Guided autoregressive decoding and generate_sam_dense are not implemented and raise; nothing falls back to eager PyTorch.
+on the whole prefix per token, generate.py:850-914).  generate_sam_dense / generate_iter are not implemented and raise; nothing falls back to eager PyTorch.
 
 Determinism: the only randomness is one uniform per decoded position drawn with ``torch.rand`` from the generator passed in (or the
 device default): same logits + same uniforms -> same tokens (csrc/sample.hip, bit-exact against oracle/sample_oracle.py).
@@ -330,14 +330,16 @@ class GenerationSampler(nn.Module):
     # ------------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def autoregressive_generate(self, mod_dict, target_mod, temperature=1.0, top_k=0.0, top_p=0.0, use_eos=True, eos_token=None,
-                                start_tokens=None, generator=None, uniforms=None, keep_logits=False):
-        """Upstream ``autoregressive_step_batched`` up to (not including) the tokenizer-level merge: returns the generated ids
-        ``out`` (B, T) starting with the start token(s).
+                                start_tokens=None, generator=None, uniforms=None, keep_logits=False, conditioning=(), guidance_scale=1.0):
+        """Upstream ``autoregressive_step_batched`` / ``guided_autoregressive_step_batched`` up to (not including) the tokenizer-level
+        merge: returns the generated ids ``out`` (B, T) starting with the start token(s).
 
         Upstream re-runs the whole decoder on the growing prefix for every token (no K/V cache, generate.py:885-896).  Here each
         layer keeps the prefix's q | k | v rows in a (B, T_max, 3 D) cache the qkv GEMM writes into directly, the new token attends
         to the filled part of it (fm_attn_fwd, kv_batch_rows = T_max), and the cross-attention keys / values of the encoded
         context are computed once per layer: one token costs one pass over B rows instead of B * prefix rows.
+        With ``conditioning`` and ``guidance_scale != 1`` a second decoder state runs on the context of the emptied conditioning
+        (classifier-free guidance, generate.py:919-1027) and the last-token logits are combined in fp32.
         ``uniforms`` (steps, B) fixes the random draws (one per sampled token)."""
         from fourm.hip import _lib as L, ops
         m = self.model
@@ -349,16 +351,11 @@ class GenerationSampler(nn.Module):
         if eng.qk_norm or eng.fp32:
             raise NotImplementedError("the K/V-cache decode path covers the bf16 models without qk_norm")
         D, H, ws, bf, f32 = eng.D, eng.H, eng.ws, eng.adt, torch.float32
-        # ---- encoder + context, once ----
+        guided = len(conditioning) > 0 and float(guidance_scale) != 1.0
+        if target_mod in conditioning:
+            raise ValueError("the target modality cannot be part of the conditioning that is dropped")
         enc_names = [n for n in mod_dict if n in m.encoder_embeddings]
         B = mod_dict[enc_names[0]]["tensor"].shape[0]
-        vis = sum((~mod_dict[n]["input_mask"].reshape(B, -1).bool()).sum(1) for n in enc_names)
-        n_enc = int(vis.max())
-        if n_enc == 0:
-            raise ValueError("nothing to condition on")
-        enc = eng.select(mod_dict, n_enc, False, enc_names, "gen.enc.")
-        _, ctx, emask, _ = eng.encode_context(enc)
-        N, Rc, Rcp = n_enc, B * n_enc, ctx.shape[0]
         # ---- the target sequence: unmasked positions in order, their embeddings, start / end tokens (generate.py:516-548) ----
         d = demb.forward_embed(dict(mod_dict[target_mod]))
         tm = d["target_mask"].reshape(B, -1).bool()
@@ -378,55 +375,79 @@ class GenerationSampler(nn.Module):
             eos_token = torch.as_tensor(eos_token, device=out.device)
             if bool((out == eos_token).any(dim=-1).all()):
                 return out
-        # ---- per-layer state: context keys / values once, an empty q|k|v cache ----
         Rp = ops.ru(B, 128)
         Tc = T + out.shape[1]                                        # cache capacity: prefix + up to T new tokens
-        kvc, cache = [], []
-        hc = ws.get("ar.hc", (Rcp, D), bf)
-        for l, blk in enumerate(m.decoder):
-            ops.layernorm_fwd(ctx, blk.context_norm.weight, blk.context_norm.bias, hc, eps=blk.context_norm.eps, R=Rc)
-            kv = ws.get(f"ar.kv{l}", (Rcp, 2 * D), bf)
-            ops.gemm_nt(hc, eng.w(blk.cross_attn.kv.weight), kv, bias=blk.cross_attn.kv.bias, M=Rc, N=2 * D, K=D)
-            kvc.append(kv)
-            cache.append(ws.get(f"ar.cache{l}", (B, Tc, 3 * D), bf))
         table = demb.token_emb.weight
         w_logits = demb.to_logits.weight
         V = w_logits.shape[0]
-        ya, yb = ws.get("ar.ya", (Rp, D), f32), ws.get("ar.yb", (Rp, D), f32)
-        h, o = ws.get("ar.h", (Rp, D), bf), ws.get("ar.o", (Rp, D), bf)
-        y1, y2 = ws.get("ar.y1", (Rp, D), f32), ws.get("ar.y2", (Rp, D), f32)
-        q2 = ws.get("ar.q2", (Rp, D), bf)
-        lg = ws.get("ar.logits", (Rp, ops.ru(V, 8)), bf)
 
-        def decode(tok, p):
-            """Token ids (B,) at sequence position p -> logits (B, V) bf16 predicting position p + 1."""
-            y = ya
-            y[:B] = table[tok] + y_emb[:, min(p, T - 1)]
-            for l, blk in enumerate(m.decoder):
-                sa, xa, c = blk.self_attn, blk.cross_attn, cache[l]
-                ops.layernorm_fwd(y, blk.norm1.weight, blk.norm1.bias, h, eps=blk.norm1.eps, R=B)
-                row = c.view(B, Tc * 3 * D)[:, p * 3 * D:(p + 1) * 3 * D]                  # this token's q | k | v inside the cache
-                ops.gemm_nt(h, eng.w(sa.qkv.weight), row, bias=sa.qkv.bias, M=B, N=3 * D, K=D)
-                flat = c.view(B * Tc, 3 * D)
-                ops.attn_fwd(row[:, :D], flat[:, D:2 * D], flat[:, 2 * D:], o, B, H, 1, p + 1, eng.scale, kv_batch_rows=Tc)
-                ops.gemm_nt(o, eng.w(sa.proj.weight), y1, epilogue=L.EPI_RESIDUAL, res=y, bias=sa.proj.bias, M=B, N=D, K=D)
-                ops.layernorm_fwd(y1, blk.query_norm.weight, blk.query_norm.bias, h, eps=blk.query_norm.eps, R=B)
-                ops.gemm_nt(h, eng.w(xa.q.weight), q2, bias=xa.q.bias, M=B, N=D, K=D)
-                ops.attn_fwd(q2, kvc[l][:, :D], kvc[l][:, D:], o, B, H, 1, N, eng.scale, **emask)
-                ops.gemm_nt(o, eng.w(xa.proj.weight), y2, epilogue=L.EPI_RESIDUAL, res=y1, bias=xa.proj.bias, M=B, N=D, K=D)
-                ops.layernorm_fwd(y2, blk.norm2.weight, blk.norm2.bias, h, eps=blk.norm2.eps, R=B)
-                y = yb if y is ya else ya
-                eng._mlp_fwd(blk.mlp, h, y2, y, B, Rp, None, "ar")
-            ops.layernorm_fwd(y, m.decoder_norm.weight, m.decoder_norm.bias, h, eps=m.decoder_norm.eps, R=B)
-            ops.gemm_nt(h, eng.w(w_logits), lg, M=B, N=V, K=D)
-            return lg[:B, :V]
+        def make_decoder(cond_dict, slot):
+            """Encode ``cond_dict`` once; -> decode(tok (B,), p) = logits (B, V) bf16 predicting position p + 1, with this context's
+            own per-layer K/V cache (workspace names carry ``slot``: the guided run keeps two of them alive)."""
+            names = [k for k in cond_dict if k in m.encoder_embeddings]
+            vis = sum((~cond_dict[k]["input_mask"].reshape(B, -1).bool()).sum(1) for k in names)
+            n_enc = int(vis.max())
+            if n_enc == 0:
+                raise ValueError("nothing to condition on")
+            enc = eng.select(cond_dict, n_enc, False, names, f"gen.enc{slot}.")
+            _, ctx, emask, _ = eng.encode_context(enc)
+            N, Rc, Rcp = n_enc, B * n_enc, ctx.shape[0]
+            pre = f"ar{slot}."
+            kvc, cache = [], []
+            hc = ws.get(pre + "hc", (Rcp, D), bf)
+            for l, blk in enumerate(m.decoder):                      # context keys / values once per layer, an empty q|k|v cache
+                ops.layernorm_fwd(ctx, blk.context_norm.weight, blk.context_norm.bias, hc, eps=blk.context_norm.eps, R=Rc)
+                kv = ws.get(f"{pre}kv{l}", (Rcp, 2 * D), bf)
+                ops.gemm_nt(hc, eng.w(blk.cross_attn.kv.weight), kv, bias=blk.cross_attn.kv.bias, M=Rc, N=2 * D, K=D)
+                kvc.append(kv)
+                cache.append(ws.get(f"{pre}cache{l}", (B, Tc, 3 * D), bf))
+            ya, yb = ws.get(pre + "ya", (Rp, D), f32), ws.get(pre + "yb", (Rp, D), f32)
+            h, o = ws.get(pre + "h", (Rp, D), bf), ws.get(pre + "o", (Rp, D), bf)
+            y1, y2 = ws.get(pre + "y1", (Rp, D), f32), ws.get(pre + "y2", (Rp, D), f32)
+            q2 = ws.get(pre + "q2", (Rp, D), bf)
+            lg = ws.get(pre + "logits", (Rp, ops.ru(V, 8)), bf)
 
-        for p in range(out.shape[1] - 1):                            # given start tokens beyond the first: fill the cache
-            decode(out[:, p], p)
+            def decode(tok, p):
+                y = ya
+                y[:B] = table[tok] + y_emb[:, min(p, T - 1)]
+                for l, blk in enumerate(m.decoder):
+                    sa, xa, c = blk.self_attn, blk.cross_attn, cache[l]
+                    ops.layernorm_fwd(y, blk.norm1.weight, blk.norm1.bias, h, eps=blk.norm1.eps, R=B)
+                    row = c.view(B, Tc * 3 * D)[:, p * 3 * D:(p + 1) * 3 * D]              # this token's q | k | v inside the cache
+                    ops.gemm_nt(h, eng.w(sa.qkv.weight), row, bias=sa.qkv.bias, M=B, N=3 * D, K=D)
+                    flat = c.view(B * Tc, 3 * D)
+                    ops.attn_fwd(row[:, :D], flat[:, D:2 * D], flat[:, 2 * D:], o, B, H, 1, p + 1, eng.scale, kv_batch_rows=Tc)
+                    ops.gemm_nt(o, eng.w(sa.proj.weight), y1, epilogue=L.EPI_RESIDUAL, res=y, bias=sa.proj.bias, M=B, N=D, K=D)
+                    ops.layernorm_fwd(y1, blk.query_norm.weight, blk.query_norm.bias, h, eps=blk.query_norm.eps, R=B)
+                    ops.gemm_nt(h, eng.w(xa.q.weight), q2, bias=xa.q.bias, M=B, N=D, K=D)
+                    ops.attn_fwd(q2, kvc[l][:, :D], kvc[l][:, D:], o, B, H, 1, N, eng.scale, **emask)
+                    ops.gemm_nt(o, eng.w(xa.proj.weight), y2, epilogue=L.EPI_RESIDUAL, res=y1, bias=xa.proj.bias, M=B, N=D, K=D)
+                    ops.layernorm_fwd(y2, blk.norm2.weight, blk.norm2.bias, h, eps=blk.norm2.eps, R=B)
+                    y = yb if y is ya else ya
+                    eng._mlp_fwd(blk.mlp, h, y2, y, B, Rp, None, "ar")
+                ops.layernorm_fwd(y, m.decoder_norm.weight, m.decoder_norm.bias, h, eps=m.decoder_norm.eps, R=B)
+                ops.gemm_nt(h, eng.w(w_logits), lg, M=B, N=V, K=D)
+                return lg[:B, :V]
+            return decode
+
+        decoders = [make_decoder(mod_dict, 0)]
+        if guided:
+            decoders.append(make_decoder(self.unconditional_dict(mod_dict, list(conditioning)), 1))
+
+        def step_logits(tok, p):
+            lc = decoders[0](tok, p)
+            if not guided:
+                return lc
+            lu = decoders[1](tok, p).float()
+            return (lu + (lc.float() - lu) * float(guidance_scale)).contiguous()
+
+        for p in range(out.shape[1] - 1):                            # given start tokens beyond the first: fill the cache(s)
+            for dec in decoders:
+                dec(out[:, p], p)
         self.last_ar = dict(logits=[]) if keep_logits else None
         for i in range(T):
             p = out.shape[1] - 1
-            logits = decode(out[:, p], p)
+            logits = step_logits(out[:, p], p)
             if keep_logits:
                 self.last_ar["logits"].append(logits.float().clone())
             u = None if uniforms is None else uniforms[i].contiguous()
@@ -494,8 +515,16 @@ class GenerationSampler(nn.Module):
         out = self.autoregressive_generate(mod_dict, target_mod, temperature, top_k, top_p, use_eos, eos_token, start_tokens, generator)
         return self.merge_sequences_batched(mod_dict, out, target_mod, text_tokenizer)
 
-    def guided_autoregressive_step_batched(self, *a, **k):
-        raise NotImplementedError("classifier-free guidance for autoregressive decoding is not implemented yet (SURVEY §8 f2)")
+    def guided_autoregressive_step_batched(self, mod_dict, target_mod, temperature, top_k, top_p, use_eos=True, eos_token=None,
+                                           start_tokens=None, text_tokenizer=None, conditioning=(), guidance_scale=1.0, seed=None, generator=None):
+        """Upstream's guided step (generate.py:919-1027): two decoder states (with / without the conditioning), fp32 combination."""
+        if text_tokenizer is None:
+            raise ValueError("guided_autoregressive_step_batched needs the text tokenizer to merge the prediction")
+        if seed is not None:
+            generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
+        out = self.autoregressive_generate(mod_dict, target_mod, temperature, top_k, top_p, use_eos, eos_token, start_tokens, generator,
+                                           conditioning=conditioning, guidance_scale=guidance_scale)
+        return self.merge_sequences_batched(mod_dict, out, target_mod, text_tokenizer)
 
     # ------------------------------------------------------------------------------------------------------------------------
     # chained schedules  (generate.py:1029-1096)

@@ -291,3 +291,20 @@ def test_autoregressive_kv_cache(case_name, target):
     merged = smp.autoregressive_step_batched(dev_md, target, 0.9, 40, 0.0, use_eos=False, text_tokenizer=Tok(), seed=3)[target]
     assert merged["tensor"].shape[0] == B and merged["tensor"].shape == merged["input_mask"].shape == merged["target_mask"].shape
     assert merged["tensor"].is_cuda and torch.equal(merged["input_mask"], merged["target_mask"]) and not bool(merged["input_mask"][:, 0].any())
+    # ---- classifier-free guidance: a second decoder state on the emptied conditioning, fp32 combination of the last-token logits ----
+    cond_mod = next(m.name for m in cfg.mods if m.in_enc and m.name != target and m.kind == "tok" and bool((~md[m.name]["input_mask"]).any()))
+    fresh = lambda: {k: {a: b.cuda() for a, b in v.items()} for k, v in md.items()}
+    smp.autoregressive_generate(fresh(), target, 0.9, 40, 0.0, use_eos=False, uniforms=u.cuda(), keep_logits=True)
+    lc0 = smp.last_ar["logits"][0].cpu().numpy()
+    smp.autoregressive_generate(smp.unconditional_dict(fresh(), [cond_mod]), target, 0.9, 40, 0.0, use_eos=False, uniforms=u.cuda(), keep_logits=True)
+    lu0 = smp.last_ar["logits"][0].cpu().numpy()
+    assert float(np.abs(lc0 - lu0).max()) > 1e-3
+    outg = smp.autoregressive_generate(fresh(), target, 0.9, 40, 0.0, use_eos=False, uniforms=u.cuda(), keep_logits=True,
+                                       conditioning=[cond_mod], guidance_scale=3.0)
+    assert np.array_equal(smp.last_ar["logits"][0].cpu().numpy(), S.cfg_logits(lc0, lu0, 3.0))        # same start token: exact
+    for i in range(steps):                                                                             # sampling from the guided logits
+        ids, _ = S.sample_tokens(smp.last_ar["logits"][i].cpu().numpy().copy(), 0.9, 40, 0.0, u[i].numpy())
+        assert np.array_equal(outg[:, i + 1].cpu().numpy(), ids), i
+    merged = smp.guided_autoregressive_step_batched(fresh(), target, 0.9, 40, 0.0, use_eos=False, text_tokenizer=Tok(), conditioning=[cond_mod],
+                                                    guidance_scale=3.0, seed=3)[target]
+    assert merged["tensor"].shape[0] == B and torch.equal(merged["input_mask"], merged["target_mask"])
