@@ -373,6 +373,14 @@ int fm_l2norm_rows(const void* x, int ldx, void* y, int ldy, int R, int D, void*
 int fm_vq_assign(const void* z, int ldz, const void* codes_normalized, const void* embed, int K, int D, int R,
                  int tokens_per_image, int normalize_latents, void* ws_val, void* ws_idx, int splits, int64_t* tokens,
                  void* quant, void* stream);
+/* Codebook training statistics (CosineSimCodebook.forward, training branch, quantize_lucid.py:409-419): bins[k] = number of
+ * latents assigned to code k, sums[k][:] = sum of those latents after L2 normalisation.  z: f32 (R, ldz); tokens: int64 (R);
+ * bins f32 (K), sums f32 (K, D): zeroed here, accumulated with fp32 atomics.  With a synchronised codebook the caller all-reduces
+ * bins and sums over the ranks between the two calls (:411, :419).  D <= 64. */
+int fm_vq_code_stats(const void* z, int ldz, const int64_t* tokens, int R, int D, int K, void* bins, void* sums, void* stream);
+/* EMA update (quantize_lucid.py:413, :421-425): cluster_size = cluster_size * decay + bins * (1 - decay);
+ * embed = embed * decay + target * (1 - decay), target = l2norm(sums / bins) where bins > 0, l2norm(embed) elsewhere. */
+int fm_vq_ema_update(const void* bins, const void* sums, void* embed, void* cluster_size, int K, int D, float decay, void* stream);
 
 #ifdef __cplusplus
 }

@@ -129,6 +129,39 @@ extern "C" int fm_l2norm_rows(const void* x, int ldx, void* y, int ldy, int R, i
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Codebook training statistics and EMA update (CosineSimCodebook.forward, training branch: quantize_lucid.py:409-425)
+// ------------------------------------------------------------------------------------------------
+// bins[tok[r]] += 1;  sums[tok[r]][:] += l2norm(z[r])     (fp32 atomics; a wave per latent row, lane = feature)
+__global__ __launch_bounds__(256) void vq_code_stats_kernel(const float* __restrict__ z, int ldz, const long long* __restrict__ tokens, int R, int D,
+                                                            float* __restrict__ bins, float* __restrict__ sums) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        const float v = lane < D ? z[(size_t)r * ldz + lane] : 0.f;
+        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);
+        const long long k = tokens[r];
+        if (lane < D) unsafeAtomicAdd(sums + (size_t)k * D + lane, v * inv);
+        if (lane == 0) unsafeAtomicAdd(bins + k, 1.0f);
+    }
+}
+
+// cluster_size = cluster_size * decay + bins * (1 - decay);  embed = embed * decay + target * (1 - decay) with
+// target = l2norm(sums / bins) for codes that received latents, l2norm(embed) for the others.  A wave per code.
+__global__ __launch_bounds__(256) void vq_ema_finalize_kernel(const float* __restrict__ bins, const float* __restrict__ sums, float* __restrict__ embed,
+                                                              float* __restrict__ cluster, int K, int D, float decay) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float alpha = 1.0f - decay;
+    for (int k = blockIdx.x * 4 + wave; k < K; k += gridDim.x * 4) {
+        const float b = bins[k];
+        const float e = lane < D ? embed[(size_t)k * D + lane] : 0.f;
+        float t = e;
+        if (b != 0.f) t = lane < D ? sums[(size_t)k * D + lane] / b : 0.f;
+        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(t * t)), 1e-12f);
+        if (lane < D) embed[(size_t)k * D + lane] = __fmaf_rn(alpha, t * inv, e * decay);
+        if (lane == 0) cluster[k] = __fmaf_rn(alpha, b, cluster[k] * decay);
+    }
+}
+
 extern "C" int fm_vq_assign(const void* z, int ldz, const void* codes_normalized, const void* embed, int K, int D, int R,
                             int tokens_per_image, int normalize_latents, void* ws_val, void* ws_idx, int splits, int64_t* tokens,
                             void* quant, void* stream) {
@@ -142,5 +175,29 @@ extern "C" int fm_vq_assign(const void* z, int ldz, const void* codes_normalized
     hipLaunchKernelGGL(vq_merge_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws_val, (const int*)ws_idx, splits,
                        (const float*)embed, (long long*)tokens, (float*)quant, R, D, tokens_per_image);
     FM_CHECK_LAUNCH("fm_vq_assign");
+    return 0;
+}
+
+extern "C" int fm_vq_code_stats(const void* z, int ldz, const int64_t* tokens, int R, int D, int K, void* bins, void* sums, void* stream) {
+    FM_CHECK_ARG(z && tokens && bins && sums && R > 0 && K > 0 && D > 0 && D <= 64, "fm_vq_code_stats: bad argument (latent_dim <= 64)");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(bins, 0, (size_t)K * 4, s) != hipSuccess || hipMemsetAsync(sums, 0, (size_t)K * D * 4, s) != hipSuccess) {
+        fm_set_error("fm_vq_code_stats: memset failed");
+        return -2;
+    }
+    int grid = (R + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(vq_code_stats_kernel, dim3(grid), dim3(256), 0, s, (const float*)z, ldz, (const long long*)tokens, R, D, (float*)bins, (float*)sums);
+    FM_CHECK_LAUNCH("fm_vq_code_stats");
+    return 0;
+}
+
+extern "C" int fm_vq_ema_update(const void* bins, const void* sums, void* embed, void* cluster_size, int K, int D, float decay, void* stream) {
+    FM_CHECK_ARG(bins && sums && embed && cluster_size && K > 0 && D > 0 && D <= 64 && decay >= 0.f && decay <= 1.f, "fm_vq_ema_update: bad argument");
+    int grid = (K + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(vq_ema_finalize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)bins, (const float*)sums, (float*)embed,
+                       (float*)cluster_size, K, D, decay);
+    FM_CHECK_LAUNCH("fm_vq_ema_update");
     return 0;
 }

@@ -109,7 +109,7 @@ def vq_encode(vq, x):
     ops.gemm_nt(stream, vq.quant_proj.weight.detach().reshape(Ld, D), z, epilogue=L.EPI_F32, bias=vq.quant_proj.bias, M=R, N=Ld, K=D)
     cb = vq.quantize._codebook
     K = cb.embed.shape[0]
-    key = ("codes", cb.embed._version, cb.embed.data_ptr())
+    key = ("codes", cb.embed._version, cb.embed.data_ptr(), getattr(cb, "epoch", 0))
     en = eng._cache.get(key)
     if en is None:
         en = torch.empty_like(cb.embed)

@@ -1,7 +1,7 @@
 """Codebook containers in the upstream layout (``fourm/vq/quantizers/quantize_lucid.py``: ``CosineSimCodebook``
-:303-428, ``VectorQuantize`` :432-568).  Inference (eval-mode) semantics only: nearest code by cosine
-similarity, ``quantize = embed[index]``, zero loss.  The EMA / dead-code training branch is out of scope
-(SURVEY §8f item 4)."""
+:303-428, ``VectorQuantize`` :432-568): nearest code by cosine similarity, ``quantize = embed[index]``, and in training mode the
+EMA codebook update with dead-code replacement (``CosineSimCodebook.ema_update_``: fm_vq_code_stats + fm_vq_ema_update).  The
+gradient path of tokenizer training (commitment loss into the encoder, decoders) is out of scope."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -14,6 +14,8 @@ class CosineSimCodebook(nn.Module):
         if learnable_codebook or sample_codebook_temp:
             raise NotImplementedError("learnable / sampled codebooks are not implemented")
         self.decay, self.codebook_size, self.eps = decay, codebook_size, eps
+        self.threshold_ema_dead_code, self.code_replacement_policy, self.use_ddp = threshold_ema_dead_code, code_replacement_policy, use_ddp
+        self.epoch = 0                       # bumped by every in-place codebook update (derived copies are keyed on it)
         if kmeans_init:
             embed = torch.zeros(codebook_size, dim)
         else:
@@ -23,6 +25,46 @@ class CosineSimCodebook(nn.Module):
         self.register_buffer("initted", torch.Tensor([not kmeans_init]))
         self.register_buffer("cluster_size", torch.zeros(codebook_size))
         self.register_buffer("embed", embed)
+
+
+    @torch.no_grad()
+    def ema_update_(self, z, tokens, generator=None):
+        """Training-mode branch of upstream ``forward`` after the code assignment (quantize_lucid.py:409-426): per-code counts and
+        sums of the L2-normalised latents (all-reduced when the codebook is synchronised), EMA of ``cluster_size`` and ``embed``,
+        then ``expire_codes_`` ('batch_random': dead codes take random normalised latents of the batch, :366-383).
+        z: f32 (R, d) latents as fed to the quantizer; tokens: int64 (R)."""
+        import torch.distributed as dist
+        from fourm.hip import _lib as L, ops
+        if not bool(self.initted):
+            raise NotImplementedError("k-means codebook initialisation is not implemented (load or initialise the codebook first)")
+        z = z.reshape(-1, z.shape[-1])
+        if z.dtype != torch.float32 or z.stride(1) != 1:
+            z = z.float().contiguous()
+        tokens = tokens.reshape(-1).contiguous()
+        K, D = self.embed.shape
+        R = z.shape[0]
+        bins = torch.empty(K, dtype=torch.float32, device=z.device)
+        sums = torch.empty(K, D, dtype=torch.float32, device=z.device)
+        L.check(L.vq_code_stats(ops._p(z), z.stride(0), ops._p(tokens), R, D, K, ops._p(bins), ops._p(sums), ops._stream()))
+        if self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(bins)
+            dist.all_reduce(sums)
+        L.check(L.vq_ema_update(ops._p(bins), ops._p(sums), ops._p(self.embed), ops._p(self.cluster_size), K, D, float(self.decay), ops._stream()))
+        self.epoch += 1
+        if self.threshold_ema_dead_code > 0:
+            dead = self.cluster_size < self.threshold_ema_dead_code
+            n_dead = int(dead.sum())                                     # (upstream reads mask.sum().item() as well)
+            if n_dead:
+                if self.code_replacement_policy != "batch_random":
+                    raise NotImplementedError(f"code_replacement_policy {self.code_replacement_policy!r} is not implemented")
+                if self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    raise NotImplementedError("distributed dead-code sampling (sample_vectors_distributed) is not implemented")
+                if R >= n_dead:
+                    idx = torch.randperm(R, device=z.device, generator=generator)[:n_dead]
+                else:
+                    idx = torch.randint(0, R, (n_dead,), device=z.device, generator=generator)
+                self.embed[dead] = F.normalize(z[idx], p=2, dim=-1)
+        return bins
 
 
 class VectorQuantize(nn.Module):
@@ -35,7 +77,7 @@ class VectorQuantize(nn.Module):
             raise NotImplementedError("multi-head codebooks / codebook projections are not implemented")
         if not use_cosine_sim:
             raise NotImplementedError("only the cosine-similarity codebook (norm_codes=True) has a HIP kernel")
-        self.heads, self.codebook_size, self.norm_latents = heads, codebook_size, norm_latents
+        self.heads, self.codebook_size, self.norm_latents, self.commitment_weight = heads, codebook_size, norm_latents, commitment_weight
         self.project_in, self.project_out = nn.Identity(), nn.Identity()
         self._codebook = CosineSimCodebook(dim=dim, codebook_size=codebook_size, kmeans_init=kmeans_init, kmeans_iters=kmeans_iters,
                                            decay=decay, eps=eps, threshold_ema_dead_code=threshold_ema_dead_code,

@@ -1,6 +1,7 @@
 """``VQ``: tokenizer front half (image -> ViT encoder -> 1x1 projection -> nearest code), API of upstream
 ``fourm/vq/vqvae.py`` (``VQ`` :39-331: constructor arguments, ``encode`` / ``tokenize`` / ``tokens_to_embedding``,
-state_dict keys).  Inference only; decoders, diffusion and tokenizer training are out of scope.
+state_dict keys).  Forward only: in training mode ``encode`` also runs the quantizer's EMA codebook update; decoders, diffusion and the
+gradient path of tokenizer training are out of scope.
 
 Precision = upstream's autocast arithmetic: the 12 ViT blocks with bf16 GEMM operands (fp32 accumulate, fp32 residual /
 LayerNorm / softmax); the tanh post-MLP, the 1x1 projection and the codebook search in exact fp32 (upstream disables
@@ -85,8 +86,18 @@ class VQ(nn.Module, PyTorchModelHubMixin):
         """(quant (B, latent_dim, h, w) f32, code_loss (1,) zeros, tokens (B, h, w) int64)   [vqvae.py:302-318]"""
         from .engine import vq_encode
         if self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("VQ training (EMA codebook updates, commitment loss) is out of scope; call .eval()")
-        return vq_encode(self, self.prepare_input(x))
+            raise NotImplementedError("the gradient path of tokenizer training (commitment loss into the encoder) is out of scope; "
+                                      "freeze the parameters (the EMA codebook update still runs in training mode) or call .eval()")
+        quant, loss, tokens = vq_encode(self, self.prepare_input(x))
+        if self.training and self.quantize.training:
+            # upstream's training-mode quantizer: EMA codebook update + the commitment term's VALUE (quantize_lucid.py:409-426, :540-548)
+            z = self._last_latents                                    # (B, G, d) f32, as fed to the quantizer
+            cb = self.quantize._codebook
+            cb.ema_update_(z, tokens)
+            if self.quantize.commitment_weight > 0:
+                zq = torch.nn.functional.normalize(z, dim=-1) if self.quantize.norm_latents else z
+                loss = (torch.nn.functional.mse_loss(quant.flatten(2).transpose(1, 2), zq) * self.quantize.commitment_weight).reshape(1)
+        return quant, loss, tokens
 
     def tokenize(self, x: torch.Tensor) -> torch.LongTensor:
         return self.encode(x)[2]

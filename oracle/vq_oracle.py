@@ -118,3 +118,36 @@ def assign_codes(z: Tensor, embed: Tensor):
     zn, en = F.normalize(z.float(), dim=-1), F.normalize(embed, dim=-1)
     ind = (zn @ en.t()).argmax(-1)
     return ind, embed[ind]
+
+
+def codebook_ema_update(embed: Tensor, cluster_size: Tensor, z: Tensor, ind: Tensor, decay: float, threshold_dead: float = 0.0,
+                        replace_rows: Tensor = None, world_bins: Tensor = None, world_sums: Tensor = None):
+    """Training-mode branch of upstream ``CosineSimCodebook.forward`` (fourm/vq/quantizers/quantize_lucid.py:409-426) after the code
+    assignment: returns (new embed (K, d), new cluster_size (K)).
+
+        bins[k]      = #latents assigned to k                                   (:410, all-reduced over ranks :411)
+        cluster_size = cluster_size * decay + bins * (1 - decay)                (:413, ema_inplace :56-57)
+        embed_sum    = sum of the L2-NORMALISED latents per code                (:418, all-reduced :419)
+        target[k]    = l2norm(embed_sum[k] / bins[k])  (codes that got latents)  |  l2norm(embed[k])  (codes that got none)   (:421-424)
+        embed        = embed * decay + target * (1 - decay)                     (:425)
+        expire_codes_ (:366-383, 'batch_random'): codes with cluster_size < threshold_dead take ``replace_rows`` = the L2-normalised
+        latents upstream draws with sample_vectors (:62-70); the draw itself (torch.randperm) is the caller's.
+    ``world_bins`` / ``world_sums``: contributions of the other ranks (sync_codebook), added before the update like the all-reduce."""
+    K = embed.shape[0]
+    zn = F.normalize(z.float().reshape(-1, z.shape[-1]), dim=-1)
+    ind = ind.reshape(-1).long()
+    bins = torch.bincount(ind, minlength=K).float()
+    sums = torch.zeros(K, zn.shape[1]).index_add_(0, ind, zn)
+    if world_bins is not None:
+        bins = bins + world_bins
+        sums = sums + world_sums
+    cluster = cluster_size.clone().mul_(decay).add_(bins, alpha=1 - decay)
+    zero = bins == 0
+    target = F.normalize(sums / bins.masked_fill(zero, 1.0).unsqueeze(1), dim=-1)
+    target = torch.where(zero[:, None], F.normalize(embed, dim=-1), target)
+    new_embed = embed.clone().mul_(decay).add_(target, alpha=1 - decay)
+    if threshold_dead > 0:
+        dead = cluster < threshold_dead
+        if bool(dead.any()):
+            new_embed[dead] = replace_rows
+    return new_embed, cluster

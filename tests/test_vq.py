@@ -117,3 +117,64 @@ def test_tokenize_end_to_end(name):
         mine = sims[r, tokens.cpu().reshape(-1)[r]]
         assert float(top[0] - mine) < 2e-2, (r, float(top[0] - mine))
     print(f"{name}: latent rel err {rel:.2e}, token agreement fp32 {agree_fp32:.3f} / bf16-oracle {agree_bf16:.3f}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,R,thr", [(64, 500, 0.0), (16384, 12544, 0.25), (128, 40, 2.0)])
+def test_codebook_ema_update(K, R, thr):
+    """Training-mode codebook update (fm_vq_code_stats + fm_vq_ema_update + dead-code replacement) against the oracle restatement of
+    upstream CosineSimCodebook.forward's training branch (pinned to upstream by tests/test_vq_ema_oracle.py)."""
+    from fourm.vq.quantizers.quantize_lucid import CosineSimCodebook
+    g = torch.Generator().manual_seed(K + R)
+    cb = CosineSimCodebook(dim=32, codebook_size=K, decay=0.9, threshold_ema_dead_code=thr, code_replacement_policy="batch_random")
+    cb.cluster_size.copy_(torch.rand(K, generator=g) * 3)
+    e0, c0 = cb.embed.clone(), cb.cluster_size.clone()
+    z = torch.randn(R, 32, generator=g) * 1.7
+    ind, _ = V.assign_codes(z, e0)
+    cb = cb.cuda().train()
+    bins = cb.ema_update_(z.cuda(), ind.cuda(), generator=torch.Generator(device="cuda").manual_seed(5))
+    assert torch.equal(bins.cpu(), torch.bincount(ind, minlength=K).float())
+    e1, c1 = V.codebook_ema_update(e0, c0, z, ind, 0.9)
+    rows = None
+    if thr > 0 and bool((c1 < thr).any()):
+        n = int((c1 < thr).sum())
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        idx = (torch.randperm(R, device="cuda", generator=gen)[:n] if R >= n else torch.randint(0, R, (n,), device="cuda", generator=gen)).cpu()
+        rows = torch.nn.functional.normalize(z[idx], dim=-1)
+        e1, c1 = V.codebook_ema_update(e0, c0, z, ind, 0.9, threshold_dead=thr, replace_rows=rows)
+    assert torch.allclose(cb.cluster_size.cpu(), c1, rtol=1e-6, atol=1e-7)
+    err = float((cb.embed.cpu() - e1).abs().max())
+    assert err < 2e-6, err                                       # fp32 atomics order + one fused multiply-add
+    assert cb.epoch == 1
+
+
+@pytest.mark.gpu
+def test_training_mode_encode_updates_the_codebook():
+    """VQ.encode in training mode (parameters frozen): same tokens / quantised vectors as eval, the commitment term's value, and the
+    codebook moved exactly as the oracle update of the kernel's own latents says; the next encode searches the UPDATED codebook."""
+    c, cfg, sd, x, g = case("vq_small")
+    vq = build(c, cfg)
+    vq.load_state_dict(sd, strict=True)
+    for p in vq.parameters():
+        p.requires_grad = False
+    vq = vq.cuda().eval()
+    q0, l0, t0 = vq.encode(x.cuda())
+    assert float(l0) == 0.0
+    e0, c0 = vq.quantize._codebook.embed.cpu().clone(), vq.quantize._codebook.cluster_size.cpu().clone()
+    vq.train()
+    vq.quantize._codebook.threshold_ema_dead_code = 0.0
+    q1, l1, t1 = vq.encode(x.cuda())
+    assert torch.equal(t1, t0) and torch.equal(q1, q0)
+    z = vq._last_latents.float().cpu()
+    want = torch.nn.functional.mse_loss(q1.cpu().flatten(2).transpose(1, 2), z)
+    assert abs(float(l1) - float(want)) < 1e-6 * max(1.0, float(want))
+    e1, c1 = V.codebook_ema_update(e0, c0, z, t1.cpu(), vq.ema_decay)
+    assert float((vq.quantize._codebook.embed.cpu() - e1).abs().max()) < 2e-6 and torch.allclose(vq.quantize._codebook.cluster_size.cpu(), c1, rtol=1e-6)
+    assert float((e1 - e0).abs().max()) > 1e-4                                      # it did move
+    t2 = vq.eval().tokenize(x.cuda())
+    ind2, _ = V.assign_codes(z.reshape(-1, z.shape[-1]), vq.quantize._codebook.embed.cpu())
+    assert (t2.cpu().reshape(-1) == ind2).float().mean() > 0.999                   # the cached normalised codes were rebuilt
+    with pytest.raises(NotImplementedError):
+        for p in vq.parameters():
+            p.requires_grad = True
+        vq.train().encode(x.cuda())
