@@ -382,6 +382,15 @@ int fm_vq_code_stats(const void* z, int ldz, const int64_t* tokens, int R, int D
  * embed = embed * decay + target * (1 - decay), target = l2norm(sums / bins) where bins > 0, l2norm(embed) elsewhere. */
 int fm_vq_ema_update(const void* bins, const void* sums, void* embed, void* cluster_size, int K, int D, float decay, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Data side: input / target masks of an image-like modality (UnifiedMasking.image_mask, fourm/data/masking.py:237-266)
+ * noise: f32 (B, L) uniform draws (the caller's RNG); input_budget / target_budget: int32 (B) (target_budget NULL = "None":
+ * every non-input position is a target).  With ids = stable argsort(noise[b]):  input_mask[b][i] = ids[i] >= input_budget[b],
+ * target_mask[b][i] = !(input_budget <= ids[i] < input_budget + target_budget)  (uint8, 1 = masked out), and
+ * decoder_attention_mask (int32) = 0 except the number of targets at the first target position.  L <= 4096. */
+int fm_image_mask(const void* noise, const int32_t* input_budget, const int32_t* target_budget, int B, int L, void* input_mask,
+                  void* target_mask, int32_t* decoder_attention_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

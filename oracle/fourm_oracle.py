@@ -705,3 +705,28 @@ def _budget(rs, caps: List[int], total: int) -> List[int]:
         k[i] += add
         rest -= add
     return [int(v) for v in k]
+
+
+# --------------------------------------------------------------------------------------------
+# data side: input / target masks of an image-like modality
+# --------------------------------------------------------------------------------------------
+def image_mask(noise, input_budget: int, target_budget):
+    """``UnifiedMasking.image_mask`` (fourm/data/masking.py:237-266) with the random vector made explicit (upstream draws
+    ``noise = torch.rand(num_tokens)`` itself).  Returns (input_mask bool (L), target_mask bool (L), decoder_attention_mask int32 (L)).
+
+        ids_shuffle = argsort(noise);  input_mask[i] = ids_shuffle[i] >= input_budget   (a gather of [0]*k_in + [1]*rest: position i is
+        an INPUT iff the index of the i-th smallest noise value is below the budget - upstream's gather direction, kept as is);
+        target_mask[i] = not (input_budget <= ids_shuffle[i] < input_budget + target_budget)   (or ~input_mask when target_budget is None);
+        decoder_attention_mask = 0 except at the first target position, which carries the number of targets."""
+    noise = torch.as_tensor(noise, dtype=torch.float32)
+    L_ = noise.shape[0]
+    ids = torch.argsort(noise, dim=0)
+    input_mask = ids >= int(input_budget)
+    if target_budget is None:
+        target_mask = ~input_mask
+    else:
+        target_mask = ~((ids >= int(input_budget)) & (ids < int(input_budget) + int(target_budget)))
+    dam = torch.zeros(L_, dtype=torch.int32)
+    first = int(torch.argmin(target_mask.float() + torch.arange(L_) * 1e-6))
+    dam[first] = int((~target_mask).sum())
+    return input_mask, target_mask, dam
