@@ -1,4 +1,5 @@
 #!/bin/bash
 # scratch driver for one gpurun call: edit the command list, then  gpurun -- 'bash tools/lab_run.sh'
 cd "$(dirname "$0")/.."
-python tools/shadow_bench.py 2>&1 | grep -v Warn | tail -3
+export LD_LIBRARY_PATH=$PWD/ml-4m_amd/fourm/_lib:$LD_LIBRARY_PATH
+timeout 300 tools/bin/gemm_lab nt 265 2>&1 | grep -i "res\|sum"
