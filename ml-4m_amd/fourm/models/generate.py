@@ -330,7 +330,8 @@ class GenerationSampler(nn.Module):
     # ------------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def autoregressive_generate(self, mod_dict, target_mod, temperature=1.0, top_k=0.0, top_p=0.0, use_eos=True, eos_token=None,
-                                start_tokens=None, generator=None, uniforms=None, keep_logits=False, conditioning=(), guidance_scale=1.0):
+                                start_tokens=None, generator=None, uniforms=None, keep_logits=False, conditioning=(), guidance_scale=1.0,
+                                use_graphs=False):
         """Upstream ``autoregressive_step_batched`` / ``guided_autoregressive_step_batched`` up to (not including) the tokenizer-level
         merge: returns the generated ids ``out`` (B, T) starting with the start token(s).
 
@@ -340,7 +341,10 @@ class GenerationSampler(nn.Module):
         context are computed once per layer: one token costs one pass over B rows instead of B * prefix rows.
         With ``conditioning`` and ``guidance_scale != 1`` a second decoder state runs on the context of the emptied conditioning
         (classifier-free guidance, generate.py:919-1027) and the last-token logits are combined in fp32.
-        ``uniforms`` (steps, B) fixes the random draws (one per sampled token)."""
+        ``uniforms`` (steps, B) fixes the random draws (one per sampled token).
+        ``use_graphs``: one token is ~135 small launches (launch bound: 1.7 ms per token on 4M-B whatever the batch); with this flag
+        the launch sequence of each sequence position is captured once into a hipGraph (kept on the sampler, keyed by position and
+        shapes) and replayed afterwards - same kernels, same arguments, bit-identical logits."""
         from fourm.hip import _lib as L, ops
         m = self.model
         eng = m.engine
@@ -367,7 +371,8 @@ class GenerationSampler(nn.Module):
         dec_ids = torch.gather(ids_all, 1, order)
         dec_emb = torch.gather(emb_all, 1, order.unsqueeze(-1).expand(-1, -1, D))
         T = min(int(m.modality_info[target_mod]["max_tokens"]), n)
-        y_emb = dec_emb[:, :T].float().contiguous()                  # (B, T, D): position + modality embedding of step t
+        y_emb = ws.get("ar.y_emb", (B, T, D), f32)                   # (B, T, D): position + modality embedding of step t (a fixed
+        y_emb.copy_(dec_emb[:, :T])                                  # buffer: captured graphs keep reading it in later calls)
         if use_eos and eos_token is None:
             eos_token = dec_ids[0][~torch.gather(tm, 1, order)[0]][-1]
         out = dec_ids[:, :1].long() if start_tokens is None else start_tokens.to(dec_ids.device).long()
@@ -428,6 +433,7 @@ class GenerationSampler(nn.Module):
                 ops.layernorm_fwd(y, m.decoder_norm.weight, m.decoder_norm.bias, h, eps=m.decoder_norm.eps, R=B)
                 ops.gemm_nt(h, eng.w(w_logits), lg, M=B, N=V, K=D)
                 return lg[:B, :V]
+            decode.n_ctx = N
             return decode
 
         decoders = [make_decoder(mod_dict, 0)]
@@ -440,6 +446,26 @@ class GenerationSampler(nn.Module):
                 return lc
             lu = decoders[1](tok, p).float()
             return (lu + (lc.float() - lu) * float(guidance_scale)).contiguous()
+
+        if use_graphs:
+            eager_step = step_logits
+            tok_buf = ws.get("ar.tok", (B,), torch.int64)
+            store = self.__dict__.setdefault("_ar_graphs", {})
+            # everything that decides a workspace shape (hence a captured pointer) or a captured scalar
+            shape_key = (id(m), target_mod, B, T, Tc, guided, float(guidance_scale), tuple(d.n_ctx for d in decoders))
+
+            def step_logits(tok, p):                                 # noqa: F811  (replaces the eager step)
+                tok_buf.copy_(tok)
+                entry = store.get((shape_key, p))
+                if entry is None:
+                    eager_step(tok_buf, p)                           # allocations, shadow refreshes: outside the capture
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        res = eager_step(tok_buf, p)
+                    entry = store[(shape_key, p)] = (g, res)
+                entry[0].replay()
+                return entry[1]
 
         for p in range(out.shape[1] - 1):                            # given start tokens beyond the first: fill the cache(s)
             for dec in decoders:

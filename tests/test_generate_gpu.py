@@ -308,3 +308,13 @@ def test_autoregressive_kv_cache(case_name, target):
     merged = smp.guided_autoregressive_step_batched(fresh(), target, 0.9, 40, 0.0, use_eos=False, text_tokenizer=Tok(), conditioning=[cond_mod],
                                                     guidance_scale=3.0, seed=3)[target]
     assert merged["tensor"].shape[0] == B and torch.equal(merged["input_mask"], merged["target_mask"])
+    # ---- hipGraph replay of the per-position launch sequences: same logits bit for bit, same tokens; a second call reuses the graphs ----
+    for rep in range(2):
+        outr = smp.autoregressive_generate(fresh(), target, 0.9, 40, 0.0, use_eos=False, uniforms=u.cuda(), keep_logits=True, use_graphs=True)
+        assert torch.equal(outr, out), rep
+        for i in range(steps):
+            assert torch.equal(smp.last_ar["logits"][i].cpu(), got[i]), (rep, i)
+    assert len(smp._ar_graphs) == steps
+    outg2 = smp.autoregressive_generate(fresh(), target, 0.9, 40, 0.0, use_eos=False, uniforms=u.cuda(), conditioning=[cond_mod], guidance_scale=3.0,
+                                        use_graphs=True)
+    assert torch.equal(outg2, outg)

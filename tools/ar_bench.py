@@ -23,8 +23,9 @@ for d in md.values():
 cap["input_mask"][:] = True; cap["input_mask"][:, :2] = False
 cap["target_mask"][:, 2:2 + T] = False
 smp = GenerationSampler(model)
-for rep in range(3):
+for rep in range(6):
+    graphs = rep >= 3
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = smp.autoregressive_generate(md, "caption", temperature=1.0, top_k=50, top_p=0.0, use_eos=False)
+    out = smp.autoregressive_generate(md, "caption", temperature=1.0, top_k=50, top_p=0.0, use_eos=False, use_graphs=graphs)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"batch {B}: {out.shape[1] - 1} tokens in {dt * 1e3:.1f} ms = {dt * 1e3 / (out.shape[1] - 1):.2f} ms/token, {B * (out.shape[1] - 1) / dt:.0f} tokens/s", flush=True)
+    print(f"{'graphs' if graphs else 'eager '} batch {B}: {out.shape[1] - 1} tokens in {dt * 1e3:.1f} ms = {dt * 1e3 / (out.shape[1] - 1):.2f} ms/token, {B * (out.shape[1] - 1) / dt:.0f} tokens/s", flush=True)

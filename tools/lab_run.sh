@@ -1,5 +1,5 @@
 #!/bin/bash
 # scratch driver for one gpurun call: edit the command list, then  gpurun -- 'bash tools/lab_run.sh'
 cd "$(dirname "$0")/.."
-export LD_LIBRARY_PATH=$PWD/ml-4m_amd/fourm/_lib:$LD_LIBRARY_PATH
-timeout 300 tools/bin/gemm_lab nt 265 2>&1 | grep -i "res\|sum"
+timeout 900 python -m pytest tests/test_generate_gpu.py -q -m gpu --tb=short -x -k "autoregressive" 2>&1 | grep -v Warning | tail -12 | cut -c1-400
+python tools/ar_bench.py 16 64 2>&1 | grep -v Warn | tail -6
