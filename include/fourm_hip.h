@@ -322,6 +322,11 @@ int fm_sample_tokens(const void* logits, int ld, int logits_are_f32, int R, int 
 /* Per sample b: the num_select entries of prob (B, N) with the largest value (ties: lower index first), in that order, go to
  * top_idx (B, num_select) and are committed: tensor[b][mod_pos[b][i]] = samples[b][i] (int64 or int32 tensor of row length L),
  * input_mask[b][pos] = 0, target_mask[b][pos] = 1 (bool / uint8). */
+/* Classifier-free guidance on logits (generate.py:684, :718): out = base + weight * (cond - uncond) in fp32, one rounding per operation;
+ * base = uncond (accumulate == 0) or the current out (accumulate != 0: further weighted conditions).  uncond / cond: bf16 or f32 (R, V)
+ * with row strides ldu / ldc; out: f32 (R, ldo). */
+int fm_guidance_combine(const void* uncond, int ldu, int uncond_is_f32, const void* cond, int ldc, int cond_is_f32, float weight,
+                        void* out, int ldo, int R, int V, int accumulate, void* stream);
 int fm_maskgit_commit(const void* prob, const void* samples, const int32_t* mod_pos, int B, int N, int num_select, void* tensor,
                       int tensor_is_i64, int L, void* input_mask, void* target_mask, int32_t* top_idx, void* stream);
 

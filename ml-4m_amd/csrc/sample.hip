@@ -249,6 +249,21 @@ extern "C" int fm_sample_tokens(const void* logits, int ld, int logits_are_f32, 
     return 0;
 }
 
+// Classifier-free guidance on logits: out = base + w * (cond - uncond), fp32, one rounding per operation (this file is compiled with
+// -ffp-contract=off), base = uncond for the first condition and the running sum for further ones (generate.py:684, :718).
+template <typename TU, typename TC>
+__global__ __launch_bounds__(256) void guidance_kernel(const TU* __restrict__ uncond, int ldu, const TC* __restrict__ cond, int ldc, float w,
+                                                       float* __restrict__ out, int ldo, int R, int V, int accumulate) {
+    const size_t total = (size_t)R * V;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e / V), c = (int)(e % V);
+        const float u = ldlogit<TU>(uncond + (size_t)r * ldu, c);
+        const float d = ldlogit<TC>(cond + (size_t)r * ldc, c) - u;
+        const float base = accumulate ? out[(size_t)r * ldo + c] : u;
+        out[(size_t)r * ldo + c] = base + w * d;
+    }
+}
+
 extern "C" int fm_maskgit_commit(const void* prob, const void* samples, const int32_t* mod_pos, int B, int N, int num_select, void* tensor,
                                  int tensor_is_i64, int L, void* input_mask, void* target_mask, int32_t* top_idx, void* stream) {
     FM_CHECK_ARG(prob && samples && mod_pos && tensor && input_mask && target_mask && top_idx, "fm_maskgit_commit: null pointer");
@@ -256,5 +271,20 @@ extern "C" int fm_maskgit_commit(const void* prob, const void* samples, const in
     hipLaunchKernelGGL(maskgit_commit_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, (const float*)prob, (const long long*)samples, mod_pos, N,
                        num_select, tensor, tensor_is_i64, L, (uint8_t*)input_mask, (uint8_t*)target_mask, top_idx);
     FM_CHECK_LAUNCH("fm_maskgit_commit");
+    return 0;
+}
+
+extern "C" int fm_guidance_combine(const void* uncond, int ldu, int uncond_is_f32, const void* cond, int ldc, int cond_is_f32, float weight,
+                                   void* out, int ldo, int R, int V, int accumulate, void* stream) {
+    FM_CHECK_ARG(uncond && cond && out && R > 0 && V > 0, "fm_guidance_combine: bad argument");
+    size_t blocks = ((size_t)R * V + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipStream_t s = (hipStream_t)stream;
+#define FM_GC(TU, TC) hipLaunchKernelGGL((guidance_kernel<TU, TC>), dim3((unsigned)blocks), dim3(256), 0, s, (const TU*)uncond, ldu, (const TC*)cond, ldc, \
+                                          weight, (float*)out, ldo, R, V, accumulate)
+    if (uncond_is_f32) { if (cond_is_f32) FM_GC(float, float); else FM_GC(float, bf16_t); }
+    else { if (cond_is_f32) FM_GC(bf16_t, float); else FM_GC(bf16_t, bf16_t); }
+#undef FM_GC
+    FM_CHECK_LAUNCH("fm_guidance_combine");
     return 0;
 }

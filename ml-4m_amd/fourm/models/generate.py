@@ -225,14 +225,29 @@ class GenerationSampler(nn.Module):
                 d["target_mask"][:] = False
         return out
 
+    @staticmethod
+    def _combine(uncond, cond, weight, out=None):
+        """out (f32, same leading shape) = (uncond | out) + weight * (cond - uncond): fm_guidance_combine on 2-D row views."""
+        from fourm.hip import _lib as L, ops
+        V = uncond.shape[-1]
+        u2, c2 = uncond.reshape(-1, V), cond.reshape(-1, V)
+        if u2.stride(1) != 1 or c2.stride(1) != 1:
+            u2, c2 = u2.contiguous(), c2.contiguous()
+        acc = out is not None
+        if out is None:
+            out = torch.empty(uncond.shape, dtype=torch.float32, device=uncond.device)
+        L.check(L.guidance_combine(ops._p(u2), u2.stride(0), int(u2.dtype == torch.float32), ops._p(c2), c2.stride(0), int(c2.dtype == torch.float32),
+                                   float(weight), ops._p(out), V, u2.shape[0], V, int(acc), ops._stream()))
+        return out
+
     @torch.no_grad()
     def _guided_logits(self, mod_dict, target_mod, conditioning, guidance_scale, decode_mask=None):
         if target_mod in conditioning:
             raise ValueError("the target modality cannot be part of the conditioning that is dropped")
         cond, mod_pos = self.forward_enc_dec_maskgit_batched(mod_dict, target_mod, decode_mask=decode_mask)
-        cond = cond.float()                                   # (the next forward reuses the logits workspace)
+        cond = cond.contiguous().clone()                      # (the next forward reuses the logits workspace)
         unc, _ = self.forward_enc_dec_maskgit_batched(self.unconditional_dict(mod_dict, conditioning), target_mod, decode_mask=decode_mask)
-        return (unc.float() + (cond - unc.float()) * float(guidance_scale)).contiguous(), mod_pos
+        return self._combine(unc, cond, guidance_scale), mod_pos
 
     @torch.no_grad()
     def guided_maskgit_step_batched(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, conditioning=(), guidance_scale=1.0,
@@ -259,13 +274,12 @@ class GenerationSampler(nn.Module):
         conds = []
         for cd in cond_dicts:
             lc, _ = self.forward_enc_dec_maskgit_batched(cd, target_mod, decode_mask=decode_mask)
-            conds.append(lc.float())                           # (copies: the next forward reuses the logits workspace)
+            conds.append(lc.contiguous().clone())              # (copies: the next forward reuses the logits workspace)
         lu, mod_pos = self.forward_enc_dec_maskgit_batched(uncond_dict, target_mod, decode_mask=decode_mask)
-        lu = lu.float()
-        acc = torch.zeros_like(lu)
+        out = None
         for w, lc in zip(cond_weights, conds):
-            acc += float(w) * (lc - lu)
-        return (lu + acc).contiguous(), mod_pos
+            out = self._combine(lu, lc, w, out)
+        return out, mod_pos
 
     def _mirror_target(self, uncond_dict, cond_dicts, target_mod):
         for cd in cond_dicts:
@@ -444,8 +458,7 @@ class GenerationSampler(nn.Module):
             lc = decoders[0](tok, p)
             if not guided:
                 return lc
-            lu = decoders[1](tok, p).float()
-            return (lu + (lc.float() - lu) * float(guidance_scale)).contiguous()
+            return self._combine(decoders[1](tok, p), lc, guidance_scale)
 
         if use_graphs:
             eager_step = step_logits

@@ -1,5 +1,4 @@
 #!/bin/bash
 # scratch driver for one gpurun call: edit the command list, then  gpurun -- 'bash tools/lab_run.sh'
 cd "$(dirname "$0")/.."
-timeout 900 python -m pytest tests/test_generate_gpu.py -q -m gpu --tb=short -x -k "autoregressive" 2>&1 | grep -v Warning | tail -12 | cut -c1-400
-python tools/ar_bench.py 16 64 2>&1 | grep -v Warn | tail -6
+timeout 900 python -m pytest tests/test_generate_gpu.py -q -m gpu --tb=short -x 2>&1 | grep -v Warning | tail -12 | cut -c1-400
