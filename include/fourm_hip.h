@@ -396,6 +396,19 @@ int fm_vq_ema_update(const void* bins, const void* sums, void* embed, void* clus
 int fm_image_mask(const void* noise, const int32_t* input_budget, const int32_t* target_budget, int B, int L, void* input_mask,
                   void* target_mask, int32_t* decoder_attention_mask, void* stream);
 
+/* Compact host-to-device batch format: uint8 pixels, uint16 ids and bit-packed masks cross PCIe, the mod_dict tensors
+ * the model takes are rebuilt on the device.
+ *   fm_unpack_image_u8: (B, H, W, C) uint8 -> (B, C, H, W) f32 = ((x / 255) - mean[c]) / std[c]  (to_tensor + normalize,
+ *       fourm/data/modality_transforms.py:215-218; mean / std are HOST arrays of C floats; bit-identical to the float pipeline)
+ *   fm_unpack_ids_u16: n uint16 -> int64
+ *   fm_unpack_mask_bits: row b = ceil(L / 8) bytes, bit (i & 7) of byte (i >> 3) -> uint8 / bool (B, L)
+ *   fm_decoder_attention_from_target: image-like modalities' decoder_attention_mask (target count at the first target position,
+ *       fourm/data/masking.py:262-264) from the unpacked target_mask (1 = masked out) */
+int fm_unpack_image_u8(const void* src, void* dst, int B, int H, int W, int C, const float* mean, const float* stdv, void* stream);
+int fm_unpack_ids_u16(const void* src, int64_t* dst, int64_t n, void* stream);
+int fm_unpack_mask_bits(const void* bits, void* dst, int B, int L, void* stream);
+int fm_decoder_attention_from_target(const void* target_mask, int32_t* decoder_attention_mask, int B, int L, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

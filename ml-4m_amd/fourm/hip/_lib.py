@@ -183,7 +183,11 @@ vq_code_stats = _sig("fm_vq_code_stats", vp, i32, vp, i32, i32, i32, vp, vp, vp)
 vq_ema_update = _sig("fm_vq_ema_update", vp, vp, vp, vp, i32, i32, f32, vp)
 image_mask = _sig("fm_image_mask", vp, vp, vp, i32, i32, vp, vp, vp, vp)
 guidance_combine = _sig("fm_guidance_combine", vp, i32, i32, vp, i32, i32, f32, vp, i32, i32, i32, i32, vp)
-EXPORTS = ["fm_guidance_combine", "fm_image_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
+unpack_image_u8 = _sig("fm_unpack_image_u8", vp, vp, i32, i32, i32, i32, P(C.c_float), P(C.c_float), vp)
+unpack_ids_u16 = _sig("fm_unpack_ids_u16", vp, vp, i64, vp)
+unpack_mask_bits = _sig("fm_unpack_mask_bits", vp, vp, i32, i32, vp)
+decoder_attention_from_target = _sig("fm_decoder_attention_from_target", vp, vp, i32, i32, vp)
+EXPORTS = ["fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",

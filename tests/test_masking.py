@@ -77,3 +77,58 @@ def test_image_mask_kernel_bit_exact(L_, with_target):
         assert torch.equal(out["decoder_attention_mask"][b].cpu(), dam), b
     out2 = image_mask_batched(L_, kin.cuda(), None if kt is None else kt.cuda(), generator=torch.Generator(device="cuda").manual_seed(1))
     assert int((~out2["input_mask"]).sum()) == int(kin.sum())
+
+
+def test_pack_mod_dict_host_side():
+    """Host half of the compact H2D format: bit order, uint16 ids, the derived decoder_attention_mask is dropped only when it IS derived."""
+    from fourm.data import h2d
+    g = torch.Generator().manual_seed(0)
+    B, L_ = 5, 19
+    tm = torch.rand(B, L_, generator=g) < 0.6
+    im = torch.rand(B, L_, generator=g) < 0.5
+    ids = torch.randint(0, 30000, (B, L_), generator=g)
+    dam = h2d._dam_of_target_mask(tm)
+    for b in range(B):
+        free = (~tm[b]).nonzero().reshape(-1)
+        assert int(dam[b].sum()) == len(free) and (len(free) == 0 or int(dam[b, free[0]]) == len(free))
+    md = {"tok": {"tensor": ids, "input_mask": im, "target_mask": tm, "decoder_attention_mask": dam},
+          "seq": {"tensor": ids.int(), "input_mask": im, "target_mask": tm, "decoder_attention_mask": (~tm).int()}}
+    p = h2d.pack_mod_dict(md)
+    assert p["tok"]["kind"] == "ids_u16" and p["tok"]["dam"] is None and p["seq"]["dam"] is not None
+    bits = p["tok"]["target_mask"].numpy()
+    assert bits.shape == (B, 3) and all(((bits[b, i >> 3] >> (i & 7)) & 1) == int(tm[b, i]) for b in range(B) for i in range(L_))
+    assert h2d.packed_nbytes(p) < sum(v.numel() * v.element_size() for d in md.values() for v in d.values()) // 2
+
+
+@pytest.mark.gpu
+def test_compact_h2d_round_trip():
+    """pack on the host -> unpack on the device reproduces the loader's mod_dict exactly: ids, masks, the image-like
+    decoder_attention_mask rebuilt from target_mask, and the normalised pixels bit-identical to to_tensor + normalize."""
+    from fourm.data import h2d
+    g = torch.Generator().manual_seed(1)
+    B = 6
+    md, imgs = {}, {}
+    for name, L_, V in (("tok_rgb@224", 196, 16384), ("tok_depth@224", 196, 8192)):
+        noise = torch.rand(B, L_, generator=g)
+        masks = [O.image_mask(noise[b], 30 + b, 50) for b in range(B)]
+        md[name] = {"tensor": torch.randint(0, V, (B, 14, 14), generator=g), "input_mask": torch.stack([m[0] for m in masks]),
+                    "target_mask": torch.stack([m[1] for m in masks]), "decoder_attention_mask": torch.stack([m[2] for m in masks])}
+    md["caption"] = {"tensor": torch.randint(0, 30000, (B, 514), generator=g).int(), "input_mask": torch.rand(B, 514, generator=g) < 0.9,
+                     "target_mask": torch.rand(B, 514, generator=g) < 0.9, "decoder_attention_mask": torch.randint(0, 5, (B, 514), generator=g).int()}
+    u8 = torch.randint(0, 256, (B, 224, 224, 3), generator=g, dtype=torch.uint8)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    rgb = u8.permute(0, 3, 1, 2).float().div(255)                        # to_tensor
+    rgb = rgb.sub(mean[None, :, None, None]).div(std[None, :, None, None])   # normalize
+    md["rgb@224"] = {"tensor": rgb, "input_mask": torch.rand(B, 196, generator=g) < 0.5, "target_mask": torch.ones(B, 196, dtype=torch.bool),
+                     "decoder_attention_mask": torch.zeros(B, 196, dtype=torch.int32)}
+    imgs["rgb@224"] = u8
+    packed = h2d.pack_mod_dict(md, images_u8=imgs)
+    full = sum(v.numel() * v.element_size() for d in md.values() for v in d.values())
+    assert h2d.packed_nbytes(packed) < 0.3 * full
+    assert packed["tok_rgb@224"]["dam"] is None and packed["caption"]["dam"] is not None
+    out = h2d.unpack_mod_dict(packed, "cuda")
+    for name, d in md.items():
+        for k, v in d.items():
+            got = out[name][k].cpu()
+            assert got.dtype == v.dtype and got.shape == v.shape, (name, k, got.dtype, v.dtype)
+            assert torch.equal(got, v), (name, k)
