@@ -99,7 +99,8 @@ typedef struct fm_gemm_tn_job {
 } fm_gemm_tn_job;
 int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* stream);
 /* tile schedule of fm_gemm_tn (table in csrc/gemm.hip): 0 = K-step 32, two workgroups per CU; 1 = K-step 64,
- * one workgroup per CU, ping-pong schedule (half the workgroups -> half the atomic epilogue traffic). */
+ * one workgroup per CU, ping-pong schedule (half the workgroups -> half the atomic epilogue traffic); 3 = as 1, and
+ * fm_gemm_tn_multi falls back from its 256 x 256 tiles to 128 x 256. */
 void fm_set_gemm_tn_config(int cfg);
 int fm_get_gemm_tn_config(void);
 void fm_set_tn_transpose_read(int on);

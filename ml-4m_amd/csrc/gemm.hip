@@ -814,9 +814,12 @@ struct TNMultiArgs {
     int n_jobs, tiles, tail_rr;
 };
 
-template <bool MASKED>
+// TA = 128, KB = 64: 64 x 64 wave tiles, 144 KB of LDS;  TA = 256, KB = 32: 128 x 64 wave tiles (8 accumulators per wave), 96 KB - per MFMA
+// 2/3 of the LDS-DMA pieces and 3/8 of the transpose reads of the small tile.
+template <bool MASKED, int TA = 128, int KB = 64>
 __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
-    constexpr int TA = 128, TB = 256, WB = 4, KB = 64, STAGES = 3, NWAVES = 8;
+    constexpr int TB = 256, WB = 4, STAGES = 3, NWAVES = 8;
+    constexpr int FWA = TA / 2 / 32;                  // 32-column A fragments per wave
     constexpr int RBA = TA * 2, RBB = TB * 2;
     constexpr int PA = KB * RBA / 1024, PB = KB * RBB / 1024;
     constexpr int LOADS = (PA + PB) / NWAVES;
@@ -835,12 +838,11 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
     const int li = lane & 15;
     const int frow0 = fhi * 8 + (li >> 2), fcol = ((lane >> 4) & 1) * 16 + (li & 3) * 4;
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
-    uint32_t baseA[2], baseB[2];
+    uint32_t baseA[FWA], baseB[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        baseA[i] = (uint32_t)tn_off<RBA>(frow0, wa * 64 + i * 32 + fcol);
-        baseB[i] = (uint32_t)tn_off<RBB>(frow0, wb * 64 + i * 32 + fcol) + KB * RBA;
-    }
+    for (int i = 0; i < FWA; ++i) baseA[i] = (uint32_t)tn_off<RBA>(frow0, wa * (TA / 2) + i * 32 + fcol);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) baseB[i] = (uint32_t)tn_off<RBB>(frow0, wb * 64 + i * 32 + fcol) + KB * RBA;
 
     // one segment: k-tiles [t_begin, t_end) of global tile `tile`, accumulated into its job's output
     auto run = [&](int tile, int t_begin, int t_end) {
@@ -887,9 +889,9 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
                 if (q >= part * NP / nparts && q < (part + 1) * NP / nparts) stage_piece(t, buf, q);
         };
 
-        f32x16_t acc[2][2];
+        f32x16_t acc[FWA][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < FWA; ++i)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
@@ -908,11 +910,11 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
             const int nbuf = buf >= 1 ? buf - 1 : 2;
             const uint32_t st = smem_lds + buf * STAGE;
             union Frag { bf16x8_t v; s16x4_t h[2]; };
-            Frag af[KS][2], bfr[KS][2];
+            Frag af[KS][FWA], bfr[KS][2];
             auto read_k = [&](auto kk_c) {
                 constexpr int kk = decltype(kk_c)::value;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < FWA; ++i) {
                     af[kk][i].h[0] = tr_read<kk * 16 * RBA>(st + baseA[i]);
                     af[kk][i].h[1] = tr_read<kk * 16 * RBA + 4 * RBA>(st + baseA[i]);
                 }
@@ -924,8 +926,8 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
             };
             read_k(std::integral_constant<int, 0>{});
             read_k(std::integral_constant<int, 1>{});
-            read_k(std::integral_constant<int, 2>{});
-            read_k(std::integral_constant<int, 3>{});
+            if constexpr (KS > 2) read_k(std::integral_constant<int, 2>{});
+            if constexpr (KS > 3) read_k(std::integral_constant<int, 3>{});
             if (!lead) {
                 if (more) { stage(t_begin + it + 2, nbuf); wait_vmcnt<LOADS>(); } else wait_vmcnt<0>();
             }
@@ -936,7 +938,7 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < FWA; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)
                         acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk][i].v, bfr[kk][jj].v, acc[i][jj], 0, 0, 0);
@@ -956,10 +958,10 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
             const int k = k0 + wb * 64 + jj * 32 + (lane & 31);
             if (k >= K) continue;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < FWA; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + wa * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                    const int n = n0 + wa * (TA / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
                     if (n < N) unsafeAtomicAdd(out + (size_t)n * ldo + k, acc[i][jj][r]);
                 }
         }
@@ -1204,7 +1206,7 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     //                  fp32 atomic traffic of the epilogue (workgroups x 128 KB per launch, ~25 us at 512 workgroups)
     constexpr int TN_TA = 128, TN_TB = 256, TN_STAGES = 3;
     // (the grouped head GEMM keeps configuration 0: short, uneven reductions - 940 vs 1110 us at the 4M-B shapes)
-    const bool pp = g_tn_config == 1 && !grouped && p->force_tr != 0;
+    const bool pp = (g_tn_config == 1 || g_tn_config == 3) && !grouped && p->force_tr != 0;
     const int kb = pp ? 64 : 32, slots = (pp ? 1 : 2) * n_compute_units();
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
@@ -1250,6 +1252,12 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
     bool masked = false;
     int tiles = 0;
     long long units = 0;
+    // 256 x 256 tiles with K-step 32 (default) or 128 x 256 with K-step 64 (fm_set_gemm_tn_config(3); FOURM_TN_MULTI_TILE=128): the
+    // large tile needs 2/3 of the LDS-DMA pieces and 3/8 of the transpose reads per MFMA - 4M-B decoder layer 646 -> 574 us, encoder
+    // layer 478 -> 461 us (profiles/r02_lab_tn_multi_tiles.txt)
+    static const bool small_env = [] { const char* e = getenv("FOURM_TN_MULTI_TILE"); return e && atoi(e) == 128; }();
+    const bool big = !(small_env || g_tn_config == 3);
+    const int ta = big ? 256 : 128, kb = big ? 32 : 64;
     for (int i = 0; i < n_jobs; ++i) {
         const fm_gemm_tn_job& p = jobs[i];
         FM_CHECK_ARG(p.A && p.B && p.out, "fm_gemm_tn_multi: null pointer");
@@ -1261,26 +1269,28 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         j.a_cols = p.a_cols > 0 ? p.a_cols : p.lda; j.b_cols = p.b_cols > 0 ? p.b_cols : p.ldb;
         FM_CHECK_ARG(j.a_cols >= 8 && j.b_cols >= 8, "fm_gemm_tn_multi: operands need at least 8 readable columns");
         j.n_tiles_b = (p.K + 255) / 256;
-        j.tiles = ((p.N + 127) / 128) * j.n_tiles_b;
+        j.tiles = ((p.N + ta - 1) / ta) * j.n_tiles_b;
         j.tile_start = tiles;
-        j.kt = (p.R + 63) / 64;
+        j.kt = (p.R + kb - 1) / kb;
         tiles += j.tiles;
         units += (long long)j.tiles * j.kt;
-        masked = masked || p.R % 64 != 0;
+        masked = masked || p.R % kb != 0;
     }
     a.n_jobs = n_jobs; a.tiles = tiles;
     int grid = n_compute_units();
     // tiny lists: no more workgroups than 8-k-tile shares (a multiple of the 8 XCDs)
     if (units / 8 < grid) grid = (int)((units / 8 + 7) / 8 * 8);
     if (grid < 8) grid = 8;
-    {   // The cut of the last partial round.  A segment costs its k-tiles + c (ring fill + a 128 KB atomic epilogue; c ~ 8 k-tiles
-        // fits profiles/r02_lab_tn_multi.txt); main and the busiest tail are balanced on that.  With at least as many remaining
+    {   // The cut of the last partial round.  A segment costs its k-tiles + c (ring fill + the atomic epilogue; c fitted on
+        // profiles/r02_lab_tn_multi.txt, r02_lab_tn_multi_tiles.txt); main and the busiest tail are balanced on that.  With at least as many remaining
         // tiles as tail workgroups, whole tails are dealt round-robin: the tails then walk neighbouring tiles over the SAME rows
         // in lock step and share operand panels in L2 like the mains do (4M-B encoder layer, 216 tiles: 476 us against 512 us for
         // contiguous runs).  Otherwise each tail is cut into contiguous runs, ~ ntail / rem per tile.
-        constexpr double c = 8.0;
+        // (in k-tiles of this configuration; the 256 KB atomic epilogue and the refill of the large tile weigh more when a workgroup's
+        // share is a fraction of a tile, i.e. in the contiguous cut)
         const int rem = tiles % grid, ntail = grid - rem;
         a.tail_rr = rem >= ntail;
+        const double c = big ? (a.tail_rr ? 24.0 : 128.0) : 8.0;
         for (int i = 0; i < n_jobs; ++i) {
             TNJob& j = a.job[i];
             if (rem == 0) { j.q = j.kt; continue; }
@@ -1296,19 +1306,18 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
             if (j.q < 0) j.q = 0;
         }
     }
-    constexpr size_t lds = (size_t)3 * 64 * (128 + 256) * 2;
     hipStream_t s = (hipStream_t)stream;
-    if (masked) {
-        auto k = gemm_tn_multi_kernel<true>;
-        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
-    } else {
-        auto k = gemm_tn_multi_kernel<false>;
-        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-        (void)once;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
+#define LAUNCH_TNM(MK, TAV, KBV)                                                                                              \
+    {                                                                                                                         \
+        constexpr size_t lds = (size_t)3 * KBV * (TAV + 256) * 2;                                                             \
+        auto k = gemm_tn_multi_kernel<MK, TAV, KBV>;                                                                          \
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true); \
+        (void)once;                                                                                                           \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);                                                              \
     }
+    if (big) { if (masked) LAUNCH_TNM(true, 256, 32) else LAUNCH_TNM(false, 256, 32) }
+    else { if (masked) LAUNCH_TNM(true, 128, 64) else LAUNCH_TNM(false, 128, 64) }
+#undef LAUNCH_TNM
     FM_CHECK_LAUNCH("fm_gemm_tn_multi");
     return 0;
 }

@@ -250,8 +250,9 @@ TN_MULTI_LISTS = {
 }
 
 
+@pytest.mark.parametrize("tile", [256, 128])
 @pytest.mark.parametrize("name", sorted(TN_MULTI_LISTS))
-def test_gemm_tn_multi(name):
+def test_gemm_tn_multi(name, tile):
     """fm_gemm_tn_multi: every job of the list accumulates dY^T X into its own output, whatever the cut of the tile list over the
     grid (whole tiles, main + tails, round-robin or contiguous); rows past R never count; repeated to screen for races."""
     ops, L = _ops()
@@ -263,11 +264,15 @@ def test_gemm_tn_multi(name):
         a[R:] = 1e4; b[R:] = float("nan")
         refs.append(1.0 + a[:R].float().t() @ b[:R].float())
         jobs.append((a, b, None, N, K, R))
-    for _ in range(3):
-        outs = [torch.full((N, K), 1.0, device=DEV, dtype=torch.float32) for _, N, K in TN_MULTI_LISTS[name]]
-        ops.gemm_tn_multi([(a, b, o, N, K, R) for (a, b, _, N, K, R), o in zip(jobs, outs)])
-        for i, (o, ref) in enumerate(zip(outs, refs)):
-            assert rel_err(o, ref) < 1e-4, (name, i, rel_err(o, ref))
+    L.lib.fm_set_gemm_tn_config(1 if tile == 256 else 3)         # 256 x 256 tiles (default) / 128 x 256
+    try:
+        for _ in range(3):
+            outs = [torch.full((N, K), 1.0, device=DEV, dtype=torch.float32) for _, N, K in TN_MULTI_LISTS[name]]
+            ops.gemm_tn_multi([(a, b, o, N, K, R) for (a, b, _, N, K, R), o in zip(jobs, outs)])
+            for i, (o, ref) in enumerate(zip(outs, refs)):
+                assert rel_err(o, ref) < 1e-4, (name, tile, i, rel_err(o, ref))
+    finally:
+        L.lib.fm_set_gemm_tn_config(1)
 
 
 def test_gemm_tn_multi_column_views():

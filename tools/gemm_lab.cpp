@@ -192,6 +192,7 @@ int main(int argc, char** argv) {
         std::vector<Shape> enc = {{2048, 768}, {2048, 768}, {768, 2048}, {768, 768}, {2304, 768}};
         std::vector<Shape> dec = enc; dec.push_back({768, 768}); dec.push_back({768, 768}); dec.push_back({1536, 768});
         const int Rm = argc > 2 ? atoi(argv[2]) : R;
+        const int multi_cfg = argc > 3 ? atoi(argv[3]) : 1;      // fm_set_gemm_tn_config for the one-launch form (2 = 256 x 256 tiles)
         for (auto* layer : {&enc, &dec}) {
             std::vector<fm_gemm_tn_job> jobs; std::vector<fm_gemm_tn_args> args; std::vector<void*> outs, outs2;
             double flops = 0;
@@ -205,7 +206,9 @@ int main(int argc, char** argv) {
             }
             // correctness: one pass each into zeroed outputs
             for (auto& a : args) if (fm_gemm_tn(&a, 0) != 0) { printf("tn: %s\n", fm_last_error()); return 1; }
+            fm_set_gemm_tn_config(multi_cfg);
             if (fm_gemm_tn_multi(jobs.data(), (int)jobs.size(), 0) != 0) { printf("multi: %s\n", fm_last_error()); return 1; }
+            fm_set_gemm_tn_config(1);
             CK(hipDeviceSynchronize());
             double worst = 0;
             for (size_t i = 0; i < jobs.size(); ++i) {
@@ -219,7 +222,9 @@ int main(int argc, char** argv) {
             double t1 = 1e30, t2 = 1e30;
             for (int rep = 0; rep < 4; ++rep) {
                 t1 = std::min(t1, time_us([&] { for (auto& a : args) fm_gemm_tn(&a, 0); }, 10, 2));
+                fm_set_gemm_tn_config(multi_cfg);
                 t2 = std::min(t2, time_us([&] { fm_gemm_tn_multi(jobs.data(), (int)jobs.size(), 0); }, 10, 2));
+                fm_set_gemm_tn_config(1);
             }
             printf("%s layer (%zu dW GEMMs, R=%d): separate %7.1f us %5.0f TF | one launch %7.1f us %5.0f TF | rel diff %.2e\n",
                    layer == &enc ? "encoder" : "decoder", jobs.size(), Rm, t1, flops / t1 / 1e6, t2, flops / t2 / 1e6, worst);
