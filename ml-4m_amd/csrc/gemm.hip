@@ -808,10 +808,11 @@ struct TNJob {
     int R, N, K, lda, ldb, ldo, a_cols, b_cols;
     int n_tiles_b, tiles, tile_start, kt;        // kt = reduction tiles (of 64 rows) of this job
     int q;                                       // main share of a tile of the last partial round
+    int lb;                                      // banded cut: k-tiles [q, q + lb) of tile i go to tail workgroup i (0: no band)
 };
 struct TNMultiArgs {
     TNJob job[FM_TN_MAX_JOBS];
-    int n_jobs, tiles, tail_rr;
+    int n_jobs, tiles, tail_rr, banded;
 };
 
 // TA = 128, KB = 64: 64 x 64 wave tiles, 144 KB of LDS;  TA = 256, KB = 32: 128 x 64 wave tiles (8 accumulators per wave), 96 KB - per MFMA
@@ -975,14 +976,19 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
     // the segments of this workgroup, one call site for the main loop
     const int full = a.tiles / G, T0 = full * G, rem = a.tiles - T0, ntail = G - rem;
     auto q_of = [&](int j) { return a.job[j].q; };
+    // Banded cut (contiguous mode): the first `rem` tail workgroups take ONE band [q, q + lb) of "their" tile each - they start
+    // together on neighbouring tiles over the same rows, so they share operand panels in L2 like the mains - and only the remaining
+    // ntail - rem workgroups walk what is left ([q + lb, kt) of every tile) as contiguous runs.
+    const int nband = a.banded ? rem : 0, nwalk = ntail - nband;
+    auto q2_of = [&](int j) { return a.job[j].q + (a.banded ? a.job[j].lb : 0); };
     long long u0 = 0, u1 = 0;
-    if (rem > 0 && w >= rem) {
+    if (rem > 0 && w >= rem + nband && !a.tail_rr) {
         long long Lsum = 0;
         for (int j = 0; j < a.n_jobs; ++j) {
             const int lo = max(a.job[j].tile_start, T0), hi = a.job[j].tile_start + a.job[j].tiles;
-            if (hi > lo) Lsum += (long long)(hi - lo) * (a.job[j].kt - q_of(j));
+            if (hi > lo) Lsum += (long long)(hi - lo) * (a.job[j].kt - q2_of(j));
         }
-        u0 = Lsum * (w - rem) / ntail; u1 = Lsum * (w - rem + 1) / ntail;
+        u0 = Lsum * (w - rem - nband) / nwalk; u1 = Lsum * (w - rem - nband + 1) / nwalk;
     }
     int phase = 0, f = 0, tj = 0, ci = -1;
     long long P = 0;
@@ -991,9 +997,11 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
         bool have = false;
         if (phase == 0) {
             if (f < full) { tile = f * G + w; t1 = a.job[job_of(tile)].kt; ++f; have = true; }
-            else { phase = rem == 0 ? 3 : (w < rem ? 1 : 2); f = 0; }
+            else { phase = rem == 0 ? 3 : (w < rem ? 1 : ((!a.tail_rr && w < rem + nband) ? 4 : 2)); f = 0; }
         } else if (phase == 1) {
             tile = T0 + w; t1 = q_of(job_of(tile)); phase = 3; have = true;
+        } else if (phase == 4) {
+            tile = T0 + (w - rem); const int j = job_of(tile); t0 = q_of(j); t1 = t0 + a.job[j].lb; phase = 3; have = true;
         } else if (phase == 2 && a.tail_rr) {
             const int sgm = (w - rem) + f * ntail;          // f counts this tail's segments here
             if (sgm >= rem) phase = 3;
@@ -1002,7 +1010,7 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
             if (tj >= a.n_jobs) phase = 3;
             else {
                 const int lo = max(a.job[tj].tile_start, T0), hi = a.job[tj].tile_start + a.job[tj].tiles;
-                const int q = q_of(tj), left = a.job[tj].kt - q;
+                const int q = q2_of(tj), left = a.job[tj].kt - q;
                 bool advance = true;
                 if (hi > lo && left > 0) {
                     const long long Pn = P + (long long)(hi - lo) * left;
@@ -1291,9 +1299,25 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         const int rem = tiles % grid, ntail = grid - rem;
         a.tail_rr = rem >= ntail;
         const double c = big ? (a.tail_rr ? 24.0 : 128.0) : 8.0;
+        // Contiguous cut with bands (rem < ntail): tail workgroup i takes ONE band [q, q + lb) of tile i - the first rem tails start
+        // together on neighbouring tiles over the same rows and share operand panels in L2 like the mains (as plain contiguous runs
+        // the tails re-read 1.9 x the operands: profiles/r02_v6_traffic_table.txt) - the other ntail - rem walk the rest.  4M-B encoder
+        // layer (108 tiles): 474 -> 420 us (profiles/r02_lab_tn_multi_tiles.txt).  FOURM_TN_BANDS=0: plain contiguous runs (A/B).
+        constexpr double cb = 32.0;
+        static const bool band_off = [] { const char* e = getenv("FOURM_TN_BANDS"); return e && atoi(e) == 0; }();
+        a.banded = !a.tail_rr && rem > 0 && ntail > rem && !band_off;
         for (int i = 0; i < n_jobs; ++i) {
             TNJob& j = a.job[i];
+            j.lb = 0;
             if (rem == 0) { j.q = j.kt; continue; }
+            if (a.banded) {       // mains and band tails: one segment of q (+ c); walkers: rem (kt - 2 q) / nwalk + (rem / nwalk + 1) c
+                const double rw = (double)rem / (ntail - rem);
+                double q = (rw * j.kt + rw * cb) / (1.0 + 2.0 * rw);
+                if (q < 0) q = 0;
+                if (2 * q > j.kt) q = j.kt / 2;
+                j.q = j.lb = (int)q;
+                continue;
+            }
             if (a.tail_rr) {      // the busiest tail workgroup has n = ceil(rem / ntail) tails:  q + c = n (kt - q + c)
                 const int n = (rem + ntail - 1) / ntail;
                 double left = (j.kt - (n - 1) * c) / (n + 1.0);
