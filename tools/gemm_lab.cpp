@@ -50,7 +50,7 @@ static void warm_gpu(int ms_target) {
 int main(int argc, char** argv) {
     const int R = 256 * 128;
     std::string mode = argc > 1 ? argv[1] : "nt";
-    warm_gpu(600);
+    if (!getenv("GEMM_LAB_NOWARM")) warm_gpu(600);      // (PMC runs: skip the warm-up so that dispatches can be told apart by order)
     if (mode == "nt") {
         std::vector<int> cfgs;
         if (argc > 2) { char* t = strtok(argv[2], ","); while (t) { cfgs.push_back(atoi(t)); t = strtok(nullptr, ","); } }
