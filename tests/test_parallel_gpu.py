@@ -42,10 +42,33 @@ def _local_grads(model, case, rank, steps):
     return model.engine.flat_grads.detach().clone()
 
 
+def run_workers(argv_list, env, timeout=300):
+    """Start one python process per argv, poll them together: as soon as one fails (or the deadline passes) the others are killed -
+    a rank that dies before the rendezvous must not leave its peer (and the test session) waiting for gloo's 30-minute default."""
+    import time
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for argv in argv_list]
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes) or any(c not in (None, 0) for c in codes):
+            break
+        time.sleep(0.5)
+    timed_out = any(p.poll() is None for p in procs) and all(p.poll() in (None, 0) for p in procs)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+    outs = [p.communicate()[0] for p in procs]
+    assert not timed_out, f"worker processes did not finish within {timeout} s:\n" + "\n".join(outs)[-4000:]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
+    return outs
+
+
 def worker(rank, world, port, out_dir):
+    import datetime
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     from fourm.parallel import DataParallel
     case = build_case(CASE)
     model = _model(case)
@@ -75,10 +98,7 @@ def worker(rank, world, port, out_dir):
 def test_data_parallel_two_processes_one_gpu(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = {**os.environ, "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "ml-4m_amd"), os.environ.get("PYTHONPATH", "")])}
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(r), "2", str(port), str(tmp_path)], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
+    run_workers([[str(r), "2", str(port), str(tmp_path)] for r in range(2)], env)
 
     case = build_case(CASE)
     model = _model(case)
@@ -100,7 +120,8 @@ def nccl_worker(port, out_dir):
     all-gather, the bf16 wire format and the CU reservation all execute; with one rank every exchange is the identity."""
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import datetime
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=180))
     from fourm.hip import _lib
     from fourm.parallel import DataParallel
     case = build_case(CASE)
@@ -127,8 +148,7 @@ def test_rccl_code_path_world_size_one(tmp_path):
     """The backend 'nccl' (= RCCL) branch of the exchange on the one GPU a test box has (it had never executed)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = {**os.environ, "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "ml-4m_amd"), os.environ.get("PYTHONPATH", "")])}
-    p = subprocess.run([sys.executable, os.path.abspath(__file__), "nccl", str(port), str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
+    run_workers([["nccl", str(port), str(tmp_path)]], env, timeout=300)
     res = torch.load(tmp_path / "nccl.pt")
     assert res["allreduce_fp32"] < 1e-6 and res["rs_ag_fp32"] < 1e-6, res          # identity (atomic order noise of the backward only)
     assert res["allreduce_bf16"] < 4e-3 and res["rs_ag_bf16"] < 4e-3, res          # one bf16 rounding of every gradient
@@ -140,7 +160,8 @@ def vq_sync_worker(rank, world, port, out_dir):
     fm_vq_ema_update (quantize_lucid.py:411, :419), so every rank ends with the same codebook."""
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     from fourm.vq.quantizers.quantize_lucid import CosineSimCodebook
     from oracle import vq_oracle as V
     g = torch.Generator().manual_seed(3)
@@ -160,10 +181,7 @@ def test_synchronised_codebook_update_two_processes(tmp_path):
     from oracle import vq_oracle as V
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = {**os.environ, "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "ml-4m_amd"), os.environ.get("PYTHONPATH", "")])}
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "vqsync", str(r), "2", str(port), str(tmp_path)], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
+    run_workers([["vqsync", str(r), "2", str(port), str(tmp_path)] for r in range(2)], env)
     g = torch.Generator().manual_seed(3)
     e0 = torch.nn.functional.normalize(torch.randn(96, 32, generator=g), dim=-1)
     c0 = torch.rand(96, generator=g)
