@@ -142,6 +142,10 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         for (int p = 0; p < PX; ++p) stage_x(kt, buf, p);
     };
 
+    if (a.dephase_groups > 1) {       // experiment: start the workgroups of a CU / of the chip out of phase (epilogue of one under the main loop of another)
+        const int ph = (gridDim.x > 256 ? blockIdx.x / 256 : blockIdx.x / 8) % a.dephase_groups;
+        for (int i = 0; i < ph * a.dephase_step; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     f32x16_t acc[FW][FX];
     const int KT = K / KB;
     auto prologue = [&]() {
@@ -1033,6 +1037,7 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
 }
 
 int g_nt_config = 9, g_nt_prio = 1;
+int g_lab[16] = {0};      // experiment knobs (tools/gemm_lab via fm_lab_set): [0] de-phase groups, [1] de-phase step (x 2048 cycles)
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
@@ -1119,6 +1124,8 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
             case 10: return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, false, true, true>(a, max_n, s);
             case 11: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false, true, true>(a, max_n, s);
             case 12: return launch_nt_cfg<256, 256, 2, 4, 32, 3, EPI, false, true, true>(a, max_n, s);
+            case 13: if constexpr (EPI == EPI_BF16) return launch_nt_cfg<256, 256, 2, 2, 64, 2, EPI, false>(a, max_n, s); else break;
+            case 14: if constexpr (EPI == EPI_BF16) return launch_nt_cfg<256, 256, 2, 2, 32, 3, EPI, false>(a, max_n, s); else break;
             default: return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, false>(a, max_n, s);
         }
     }
@@ -1144,8 +1151,14 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     a.M = p->M; a.N = p->N; a.K = p->K; a.ldw = p->ldw; a.ldx = p->ldx; a.ldo = p->ldo; a.ldo2 = p->ldo2; a.ldr = p->ldr; a.Hp = p->Hp;
     a.groups = p->groups; a.tile_group = p->tile_group;
     a.prio = g_nt_prio;
+    a.dephase_groups = g_lab[0]; a.dephase_step = g_lab[1];
     hipStream_t s = (hipStream_t)stream;
     const int max_n = grouped ? p->max_N : p->N;
+    if (!grouped && g_lab[2]) {               // the lock-step large-tile kernel (gemm_nt3.hip) takes the dense launches it handles
+        const int r = fm_launch_nt3(a, p->epilogue, g_lab[2], s);
+        if (r < 0) { fm_set_error("fm_gemm_nt (nt3): launch failed"); return -2; }
+        if (r > 0) return 0;
+    }
     if (!grouped && g_nt_config == 9) {       // the flattened persistent kernel takes the big dense launches it handles
         const int r = fm_launch_nt_flat(a, p->epilogue, s);
         if (r < 0) { fm_set_error("fm_gemm_nt (flat): launch failed"); return -2; }
@@ -1187,6 +1200,7 @@ extern "C" void fm_set_gemm_nt_config(int cfg) {
     if ((cfg >> 24) & 0xf) g_nt_swiglu = (cfg >> 24) & 0xf;                                             // bits 24-27: the SwiGLU choice
 }
 extern "C" int fm_get_gemm_nt_config(void) { return g_nt_config; }
+extern "C" void fm_lab_set(int key, int value) { if (key >= 0 && key < 16) g_lab[key] = value; }
 extern "C" void fm_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
 extern "C" int fm_get_reserved_cus(void) { return g_reserved_cus; }
 static int g_tn_config = 1;

@@ -16,6 +16,7 @@ struct NTArgs {
     int n_tiles_w, n_tiles_x;
     int group_w;                                          // grouped: W-tiles per column block
     int prio;                                             // raise the wave priority around the MFMA clusters
+    int dephase_groups, dephase_step;                     // experiment (fm_lab_set): staggered workgroup start
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
@@ -27,3 +28,5 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 // gemm_nt_flat.hip: the flattened persistent kernel.  Returns 1 when it took the launch, 0 when the arguments are outside what it
 // handles (the caller then uses the tile-at-a-time kernels of gemm.hip), < 0 on a launch error.
 int fm_launch_nt_flat(const fmk::NTArgs& a, int epilogue, hipStream_t s);
+// gemm_nt3.hip: the lock-step large-tile kernel (same return convention; mode 1 = 256-wide tiles, 2 = 192-wide, 3 = by shape)
+int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s);

@@ -1,0 +1,386 @@
+// Lock-step, large-tile NT GEMM (gfx950):  out[m][n] = sum_k X[m][k] * W[n][k]   for the dense launches of the trunk.
+//
+// What the round-3 micro-benchmarks (tools/ubench.hip, profiles/r03_ubench.txt) say about this chip, and what this kernel does
+// with it:
+//   * v_mfma_f32_32x32x16_bf16 on random bf16 data sustains 1.79-1.89 PFLOP/s (32.0 cycles per MFMA per SIMD at the 1.72 GHz the
+//     power limit leaves): that is the ceiling, not 2.5.
+//   * fragment reads (ds_read_b128) cost the matrix pipe nothing for any wave tile as long as they are SPREAD between the MFMAs;
+//     a burst of reads right behind a workgroup barrier (every wave at once) costs ~200 cycles per barrier.
+//   * s_barrier itself is free under MFMAs (48 cycles, hidden), so ONE barrier per K-tile is fine; the two barriers per K-tile
+//     of the ping-pong schedule in gemm.hip, each followed by a read burst, are what held its main loop at ~1.05 PFLOP/s.
+//   * global_load_lds delivers <= 86 B/ns per CU from L2 and ~30 B/ns per CU from the Infinity Cache or HBM (~8 TB/s chip wide):
+//     a 128 x 256 tile needs 80 B/ns per CU at the MFMA ceiling, a 256 x 256 tile 54, so the tile must be large.
+// Hence: 256 x 256 (or 192 x 256) output tiles, 8 waves as 2 x 4 (wave tile 128 x 64 / 96 x 64), K-step 64, TWO LDS stages,
+// all waves in lock step with one barrier per K-tile.  The barrier sits before the LAST k-step of a K-tile: the fragments of that
+// k-step are already in registers, so behind the barrier every wave has 8 MFMAs to issue while it reads the first fragments of
+// the next K-tile and issues the LDS-DMA of the K-tile after it (into the buffer the barrier just freed), one piece and one
+// fragment read per MFMA.  The K-tiles of ALL output tiles of a persistent workgroup form one stream (as in gemm_nt_flat.hip):
+// the ring never drains at a tile boundary; a finished tile is converted and stored between two K-tiles.
+//
+// vmcnt is one in-order queue of loads and stores: the wait before the barrier allows exactly the stores of a tile that ended
+// one K-tile ago to be outstanding (buffer stores with hardware bounds checks: always the same number of instructions).
+#include <type_traits>
+#include "common.h"
+#include "fourm_hip.h"
+#include "gemm_args.h"
+
+namespace {
+using namespace fmk;
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4v_t;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+constexpr uint32_t OOB = 0x80000000u;       // an offset with bit 31 set is outside num_records: the access is dropped / reads 0
+
+template <int TW, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int TX = 256, KB = 64, WW = 2, WX = 4, NWAVES = 8, KS = 4;
+    constexpr int RB = 128, CPR = 8, RPP = 8;
+    constexpr int FW = TW / WW / 32, FX = TX / WX / 32;             // 4 (3) x 2 fragments of 32 x 32 per wave
+    constexpr int PW = TW / (RPP * NWAVES), PX = TX / (RPP * NWAVES), LOADS = PW + PX;
+    constexpr int STAGE = (TW + TX) * RB;
+    constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
+    constexpr int NMF = FW * FX;                                    // MFMAs per k-step
+    // stores per wave and tile (16 bytes per lane each)
+    constexpr int NST = EPI == EPI_BF16 ? FW * FX * 2 : EPI == EPI_SWIGLU ? FX * (FW / 2) * 2 * 3 : FW * FX * 4;
+    static_assert(TW % (RPP * NWAVES) == 0, "tile rows must split evenly over the DMA pieces");
+    static_assert(EPI != EPI_SWIGLU || FW % 2 == 0, "SwiGLU needs (g,u) fragment pairs per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ww = wave / WX, wx = wave % WX;
+    const int frow = lane & 31, fhi = lane >> 5;
+    const int fswz = (frow >> 1) & (CPR - 1);
+
+    const int total = a.n_tiles_w * a.n_tiles_x;
+    const int n_my = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int KT = a.K / KB;
+    const int G = n_my * KT;
+    const int N = a.N;
+
+    // ---- the DMA stream -------------------------------------------------------------------------------------------------------
+    uint32_t woff[PW], xoff[PX];
+    __amdgpu_buffer_rsrc_t rs_w = rsrc_of(a.W), rs_w2 = rsrc_of(a.W2 ? a.W2 : a.W), rs_x = rsrc_of(a.X);
+    (void)rs_w2;
+    auto tile_origin = [&](int j, int& n0, int& m0) {
+        const int tile = xcd_remap((int)blockIdx.x + j * (int)gridDim.x, total);
+        n0 = (tile % a.n_tiles_w) * NPT; m0 = (tile / a.n_tiles_w) * TX;      // W tiles fastest: the X tile is shared in the XCD's L2
+    };
+    auto set_sources = [&](int j) __attribute__((always_inline)) {
+        int n0, m0;
+        tile_origin(j, n0, m0);
+        rs_w = rsrc_of(a.W + (size_t)n0 * a.ldw);
+        if constexpr (EPI == EPI_SWIGLU) rs_w2 = rsrc_of(a.W2 + (size_t)n0 * a.ldw);
+        rs_x = rsrc_of(a.X + (size_t)m0 * a.ldx);
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            const int t = (p * NWAVES + wave) * RPP + lane / CPR;
+            const int lc = (lane % CPR) ^ ((t >> 1) & (CPR - 1));
+            int r;
+            if constexpr (EPI == EPI_SWIGLU) r = (t >> 6) * 32 + (t & 31);     // rows [0,32) of a 64-row group: g (W), [32,64): u (W2)
+            else r = t;
+            r = n0 + r < N ? r : N - 1 - n0;
+            woff[p] = (uint32_t)r * (uint32_t)a.ldw * 2u + (uint32_t)lc * 16u;
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int t = (p * NWAVES + wave) * RPP + lane / CPR;
+            const int lc = (lane % CPR) ^ ((t >> 1) & (CPR - 1));
+            const int r = m0 + t < a.M ? t : a.M - 1 - m0;
+            xoff[p] = (uint32_t)r * (uint32_t)a.ldx * 2u + (uint32_t)lc * 16u;
+        }
+    };
+    int s_kt = 0, s_j = 0, s_buf = 0;
+    auto stage_piece = [&](int q) __attribute__((always_inline)) {            // piece q of the stream's current stage (q < PW: W rows, else X rows)
+        const int soff = s_kt * (KB * 2);
+        if (q < PW) {
+            const int pi = q < PW ? q : 0;
+            const int t0 = (pi * NWAVES + wave) * RPP;
+            if (EPI == EPI_SWIGLU && ((t0 >> 5) & 1))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w2, LDS_PTR(smem + s_buf * STAGE + (pi * NWAVES + wave) * 1024), 16, woff[pi], soff, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, LDS_PTR(smem + s_buf * STAGE + (pi * NWAVES + wave) * 1024), 16, woff[pi], soff, 0, 0);
+        } else {
+            const int pi = q >= PW ? q - PW : 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, LDS_PTR(smem + s_buf * STAGE + TW * RB + (pi * NWAVES + wave) * 1024), 16, xoff[pi], soff, 0, 0);
+        }
+    };
+    auto stage_advance = [&]() __attribute__((always_inline)) {
+        ++s_kt; s_buf ^= 1;
+        if (s_kt == KT) { s_kt = 0; ++s_j; if (s_j < n_my) set_sources(s_j); }
+    };
+
+    f32x16_t acc[FW][FX];
+#pragma unroll
+    for (int i = 0; i < FW; ++i)
+#pragma unroll
+        for (int j = 0; j < FX; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- epilogue of the tile whose last K-tile was just multiplied --------------------------------------------------------------
+    auto finish_tile = [&](int j_done) __attribute__((always_inline)) {
+        int n0, m0;
+        tile_origin(j_done, n0, m0);
+        if constexpr (EPI == EPI_BF16) {
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
+            const int c0 = n0 + ww * (TW / WW) + 8 * fhi;                       // this lane's first column (chunk 0)
+#pragma unroll
+            for (int j = 0; j < FX; ++j) {
+                const int rl = wx * (TX / WX) + j * 32 + frow;
+                const uint32_t rowoff = (m0 + rl < a.M ? 0u : OOB) | ((uint32_t)(rl * a.ldo) * 2u);
+#pragma unroll
+                for (int i = 0; i < FW; ++i)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int g = 2 * gp;
+                        const uint2 p0 = make_uint2(pack2bf(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
+                        const uint2 p1 = make_uint2(pack2bf(acc[i][j][4 * g + 4], acc[i][j][4 * g + 5]), pack2bf(acc[i][j][4 * g + 6], acc[i][j][4 * g + 7]));
+                        const auto x = __builtin_amdgcn_permlane32_swap(p0.x, p1.x, false, false);
+                        const auto y = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
+                        const u32x4_t v = {x[0], y[0], x[1], y[1]};
+                        const int c = c0 + i * 32 + 16 * gp;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (c < N ? rowoff : OOB) + (uint32_t)c * 2u, 0, 0);
+                    }
+            }
+        } else if constexpr (EPI == EPI_RES) {
+            // out = res + bf16(acc)  (fp32, may alias): the residual values of one fragment are requested while the previous one is
+            // added and stored
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 4);
+            const __amdgpu_buffer_rsrc_t rs_res = rsrc_of((const char*)a.res + (size_t)m0 * a.ldr * 4);
+            const int c0 = n0 + ww * (TW / WW) + 4 * fhi;                       // this lane's first column (group 0)
+            f32x4v_t rv[2][4];
+            auto req = [&](int f, int par) __attribute__((always_inline)) {
+                const int j = f / FW, i = f % FW;
+                const int rl = wx * (TX / WX) + j * 32 + frow;
+                const uint32_t rowoff = (m0 + rl < a.M ? 0u : OOB) | ((uint32_t)(rl * a.ldr) * 4u);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = c0 + i * 32 + 8 * g;
+                    rv[par][g] = __builtin_bit_cast(f32x4v_t, __builtin_amdgcn_raw_buffer_load_b128(rs_res, (c < N ? rowoff : OOB) + (uint32_t)c * 4u, 0, 0));
+                }
+            };
+            req(0, 0);
+#pragma unroll
+            for (int f = 0; f < FW * FX; ++f) {
+                if (f + 1 < FW * FX) req(f + 1, (f + 1) & 1);
+                const int j = f / FW, i = f % FW;
+                const int rl = wx * (TX / WX) + j * 32 + frow;
+                const uint32_t rowoff = (m0 + rl < a.M ? 0u : OOB) | ((uint32_t)(rl * a.ldo) * 4u);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = c0 + i * 32 + 8 * g;
+                    f32x4v_t o = rv[f & 1][g];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += bfround(acc[i][j][4 * g + e]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, (c < N ? rowoff : OOB) + (uint32_t)c * 4u, 0, 0);
+                }
+            }
+        } else if constexpr (EPI == EPI_SWIGLU) {
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
+            const __amdgpu_buffer_rsrc_t rs_out2 = rsrc_of((const char*)(a.out2 ? a.out2 : a.out) + (size_t)m0 * (a.out2 ? a.ldo2 : a.ldo) * 2);
+            const int h0 = n0 + (ww * (TW / WW) / 64) * 32 + 8 * fhi;           // this lane's first hidden unit (chunk 0)
+#pragma unroll
+            for (int j = 0; j < FX; ++j) {
+                const int rl = wx * (TX / WX) + j * 32 + frow;
+                const uint32_t ok = m0 + rl < a.M ? 0u : OOB;
+                const uint32_t ro = ok | ((uint32_t)(rl * a.ldo) * 2u), ro2 = ok | ((uint32_t)(rl * a.ldo2) * 2u);
+                u32x4_t pg[FW / 2][2], pu[FW / 2][2], pa[FW / 2][2];
+#pragma unroll
+                for (int ip = 0; ip < FW / 2; ++ip)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        uint2 qg[2], qu[2], qa[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int g = 2 * gp + u;
+                            float gv[4], uv[4], av[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                gv[e] = bfround(acc[2 * ip][j][4 * g + e]);
+                                uv[e] = bfround(acc[2 * ip + 1][j][4 * g + e]);
+                                av[e] = bfround(silu_f(gv[e])) * uv[e];
+                            }
+                            qg[u] = make_uint2(pack2bf(gv[0], gv[1]), pack2bf(gv[2], gv[3]));
+                            qu[u] = make_uint2(pack2bf(uv[0], uv[1]), pack2bf(uv[2], uv[3]));
+                            qa[u] = make_uint2(pack2bf(av[0], av[1]), pack2bf(av[2], av[3]));
+                        }
+                        auto swz = [&](const uint2 (&p)[2]) {
+                            const auto x = __builtin_amdgcn_permlane32_swap(p[0].x, p[1].x, false, false);
+                            const auto y = __builtin_amdgcn_permlane32_swap(p[0].y, p[1].y, false, false);
+                            const u32x4_t v = {x[0], y[0], x[1], y[1]};
+                            return v;
+                        };
+                        pg[ip][gp] = swz(qg); pu[ip][gp] = swz(qu); pa[ip][gp] = swz(qa);
+                    }
+                // output by output: the 16-byte pieces of one 128-byte line leave back to back
+#pragma unroll
+                for (int which = 0; which < 3; ++which)
+#pragma unroll
+                    for (int ip = 0; ip < FW / 2; ++ip)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const int h = h0 + ip * 32 + 16 * gp;
+                            const uint32_t col = (uint32_t)h * 2u;
+                            if (which == 2) __builtin_amdgcn_raw_buffer_store_b128(pa[ip][gp], rs_out, (h < N ? ro : OOB) + col, 0, 0);
+                            else __builtin_amdgcn_raw_buffer_store_b128(which == 0 ? pg[ip][gp] : pu[ip][gp], rs_out2,
+                                                                        ((h < N && a.out2) ? ro2 : OOB) + col + (which == 1 ? (uint32_t)a.Hp * 2u : 0u), 0, 0);
+                        }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FW; ++i)
+#pragma unroll
+            for (int j = 0; j < FX; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+
+    // ---- prologue: stages 0 and 1 --------------------------------------------------------------------------------------------------
+    set_sources(0);
+#pragma unroll
+    for (int q = 0; q < LOADS; ++q) stage_piece(q);
+    stage_advance();
+    if (G > 1) {
+#pragma unroll
+        for (int q = 0; q < LOADS; ++q) stage_piece(q);
+        stage_advance();
+        wait_vmcnt<LOADS>();
+    } else wait_vmcnt<0>();
+    block_barrier();                                     // stage 0 is in LDS for everyone
+
+    bf16x8_t wf[2][FW], xf[2][FX];
+    auto read_frags = [&](int buf, int kk, int par) __attribute__((always_inline)) {
+        const char* wt = smem + buf * STAGE + (ww * (TW / WW) + frow) * RB;
+        const char* xt = smem + buf * STAGE + TW * RB + (wx * (TX / WX) + frow) * RB;
+        const int off = ((kk * 2 + fhi) ^ fswz) * 16;
+#pragma unroll
+        for (int i = 0; i < FW; ++i) wf[par][i] = *(const bf16x8_t*)(wt + i * 32 * RB + off);
+#pragma unroll
+        for (int j = 0; j < FX; ++j) xf[par][j] = *(const bf16x8_t*)(xt + j * 32 * RB + off);
+    };
+    auto mfmas = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < FW; ++i)
+#pragma unroll
+            for (int j = 0; j < FX; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[par][i], xf[par][j], acc[i][j], 0, 0, 0);
+    };
+    read_frags(0, 0, 0);
+
+    int buf = 0, c_kt = 0, c_j = 0;
+    bool stores_behind = false;                          // did the previous K-tile end an output tile (its stores are the youngest in the queue)?
+    // one K-tile.  NEXT: a stage g + 1 exists; MORE: a stage g + 2 exists (compile time: the steady state has no branch between
+    // the barrier and the end of the k-step, so the reads, DMA pieces and MFMAs behind the barrier can be interleaved)
+    auto k_tile = [&](auto next_c, auto more_c) __attribute__((always_inline)) {
+        constexpr bool NEXT = decltype(next_c)::value, MORE = decltype(more_c)::value;
+        // ---- k-steps 0 .. 2: MFMAs of step kk, fragment reads of step kk + 1 between them ---------------------------------------
+#pragma unroll
+        for (int kk = 0; kk < KS - 1; ++kk) {
+            read_frags(buf, kk + 1, (kk + 1) & 1);
+            mfmas(kk & 1);
+#pragma unroll
+            for (int q = 0; q < FW + FX; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- the barrier: stage g + 1 has landed for everyone, stage g has been read by everyone -------------------------------
+        if constexpr (NEXT) { if (stores_behind) wait_vmcnt<NST>(); else wait_vmcnt<0>(); }
+        wait_lgkmcnt<0>();
+        block_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- k-step 3: its MFMAs; first the fragments of stage g + 1 (two reads per MFMA), then the LDS-DMA of stage g + 2 into
+        //      the freed buffer (the compiler orders a DMA piece behind every LDS read in flight: reads first, pieces after)
+        if constexpr (NEXT) read_frags(buf ^ 1, 0, 0);
+        if constexpr (MORE) {
+#pragma unroll
+            for (int q = 0; q < LOADS; ++q) stage_piece(q);
+        }
+        mfmas(1);
+        constexpr int RD = NEXT ? FW + FX : 0, RSTEPS = (RD + 1) / 2;           // MFMAs that carry two reads each
+#pragma unroll
+        for (int q = 0; q < RSTEPS; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        if constexpr (MORE) {
+            constexpr int LEFT = NMF - RSTEPS - 1;                               // MFMAs that carry DMA pieces (the last one carries none)
+            constexpr int PER = (LOADS + LEFT - 1) / LEFT;
+#pragma unroll
+            for (int q = 0; q < LEFT; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, PER, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE) stage_advance();
+        buf ^= 1;
+        stores_behind = false;
+        if (++c_kt == KT) {
+            finish_tile(c_j);
+            c_kt = 0; ++c_j; stores_behind = true;
+        }
+    };
+    for (int g = 0; g + 2 < G; ++g) k_tile(std::true_type{}, std::true_type{});
+    k_tile(std::true_type{}, std::false_type{});         // (G >= 2: K >= 128)
+    k_tile(std::false_type{}, std::false_type{});
+#endif
+}
+
+template <int TW, int EPI>
+int launch_nt3(NTArgs a, hipStream_t s) {
+    constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
+    a.n_tiles_w = (a.N + NPT - 1) / NPT;
+    a.n_tiles_x = (a.M + 255) / 256;
+    int grid = a.n_tiles_w * a.n_tiles_x;
+    static int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n / 8 * 8;
+    }();
+    if (grid > cus) grid = cus;
+    const size_t lds = (size_t)2 * (TW + 256) * 128;
+    auto k = gemm_nt3_kernel<TW, EPI>;
+    static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
+    if (hipGetLastError() != hipSuccess) return -2;
+    return 1;
+}
+
+}  // namespace
+
+// mode: 1 = 256-wide W tiles only, 2 = 192-wide only, 3 = by shape.  Returns 1 when it took the launch, 0 when the arguments are
+// outside what it handles, < 0 on a launch error.
+int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
+    using namespace fmk;
+    if (!mode || a.groups || a.bias || a.bias2) return 0;
+    if (a.M < 2048 || a.K % 64 != 0 || a.K < 128 || a.N % 8 != 0) return 0;
+    if ((size_t)256 * (size_t)a.ldo * 4 >= 0x7fffffffull || (size_t)256 * (size_t)a.ldx * 2 >= 0x7fffffffull || (size_t)256 * (size_t)a.ldw * 2 >= 0x7fffffffull) return 0;
+    const bool al16 = (((uintptr_t)a.out | (uintptr_t)a.out2 | (uintptr_t)a.res) & 15) == 0;
+    if (!al16) return 0;
+    // 192-wide tiles where they tile N exactly and 256-wide ones do not fill whole rounds (N = 768, 2304 at 32768 rows)
+    const long t256 = (long)((a.N + 255) / 256) * ((a.M + 255) / 256);
+    const bool fits192 = a.N % 192 == 0;
+    const bool use192 = mode == 2 ? fits192 : mode == 3 ? (fits192 && (a.N % 256 != 0 || t256 % 256 != 0)) : false;
+    if (epilogue == FM_EPI_BF16) {
+        if (a.ldo % 8 != 0) return 0;
+        return use192 ? launch_nt3<192, EPI_BF16>(a, s) : launch_nt3<256, EPI_BF16>(a, s);
+    }
+    if (epilogue == FM_EPI_RESIDUAL) {
+        if (a.ldo % 4 != 0 || a.ldr % 4 != 0 || !a.res) return 0;
+        return use192 ? launch_nt3<192, EPI_RES>(a, s) : launch_nt3<256, EPI_RES>(a, s);
+    }
+    if (epilogue == FM_EPI_SWIGLU) {
+        if (a.N % 64 != 0 || a.Hp % 8 != 0 || a.ldo % 8 != 0 || (a.out2 && a.ldo2 % 8 != 0) || !a.W2) return 0;
+        return launch_nt3<256, EPI_SWIGLU>(a, s);
+    }
+    return 0;
+}

@@ -10,6 +10,7 @@
 #include <vector>
 #include <string>
 #include "fourm_hip.h"
+extern "C" void fm_lab_set(int key, int value);      // experiment knobs of libfourm_hip.so (not part of the ABI header)
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -75,9 +76,24 @@ int main(int argc, char** argv) {
             a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.ldo2 = 2 * c.N; a.ldr = c.N; a.Hp = c.N; a.epilogue = c.epi;
             printf("%s |", c.name);
             std::vector<double> best(cfgs.size(), 1e30);
+            // configurations >= 1000: the lock-step large-tile kernel (gemm_nt3.hip) in mode cfg - 1000 over the default choice
+            auto set_cfg = [&](int cfg) { if (cfg >= 1000) { fm_lab_set(2, cfg - 1000); fm_set_gemm_nt_config(9); } else { fm_lab_set(2, 0); fm_set_gemm_nt_config(cfg); } };
+            {   // every configuration against the first one (bit patterns of the primary output)
+                const size_t nbytes = (size_t)R * c.N * (f32out ? 4 : 2);
+                std::vector<uint16_t> ref(nbytes / 2), got(nbytes / 2);
+                set_cfg(cfgs[0]); CK(hipMemset(out, 0, nbytes)); fm_gemm_nt(&a, 0); CK(hipDeviceSynchronize());
+                CK(hipMemcpy(ref.data(), out, nbytes, hipMemcpyDeviceToHost));
+                for (size_t k = 1; k < cfgs.size(); ++k) {
+                    set_cfg(cfgs[k]); CK(hipMemset(out, 0, nbytes));
+                    if (fm_gemm_nt(&a, 0) != 0) continue;
+                    CK(hipDeviceSynchronize()); CK(hipMemcpy(got.data(), out, nbytes, hipMemcpyDeviceToHost));
+                    size_t bad = 0; for (size_t e = 0; e < ref.size(); ++e) bad += ref[e] != got[e];
+                    if (bad) printf(" [c%d: %zu of %zu halfwords differ from c%d]", cfgs[k], bad, ref.size(), cfgs[0]);
+                }
+            }
             for (int rep = 0; rep < 3; ++rep)                   // interleaved A/B: every configuration sees the same clock history
                 for (size_t k = 0; k < cfgs.size(); ++k) {
-                    fm_set_gemm_nt_config(cfgs[k]);
+                    set_cfg(cfgs[k]);
                     if (fm_gemm_nt(&a, 0) != 0) { printf(" cfg%d: %s", cfgs[k], fm_last_error()); continue; }
                     double us = time_us([&] { fm_gemm_nt(&a, 0); }, 20, 2);
                     if (us < best[k]) best[k] = us;
@@ -93,6 +109,35 @@ int main(int argc, char** argv) {
         printf("sum over a 4M-B step (ms):");
         for (size_t k = 0; k < cfgs.size(); ++k) printf("  c%d: %.2f", cfgs[k], tot[k] / 1e3);
         printf("\n");
+    } else if (mode == "dephase") {
+        // staggered workgroup start (fm_lab_set 0/1): the store epilogue of one workgroup under the main loop of another
+        std::vector<int> cfgs = {266, 267, 268};
+        if (argc > 2) { cfgs.clear(); char* t = strtok(argv[2], ","); while (t) { cfgs.push_back(atoi(t)); t = strtok(nullptr, ","); } }
+        NTCase cases[] = {{"qkv      N2304 K768 ", 2304, 768, FM_EPI_BF16}, {"proj/dX  N768  K768 ", 768, 768, FM_EPI_BF16}, {"dX fc2   N2048 K768 ", 2048, 768, FM_EPI_BF16},
+                          {"dX qkv   N768  K2304", 768, 2304, FM_EPI_BF16}, {"fc2+res  N768  K2048", 768, 2048, FM_EPI_RESIDUAL}, {"proj+res N768  K768 ", 768, 768, FM_EPI_RESIDUAL}};
+        const int knobs[][2] = {{0, 0}, {2, 6}, {2, 12}, {2, 24}, {4, 4}, {4, 8}, {8, 2}, {8, 4}};
+        for (auto& c : cases) {
+            void* W = dev_rand_bf16((size_t)c.N * c.K, 1), *X = dev_rand_bf16((size_t)R * c.K, 3);
+            const bool f32out = c.epi == FM_EPI_RESIDUAL;
+            void* out = dev_zero((size_t)R * c.N * (f32out ? 4 : 2));
+            void* res = f32out ? dev_zero((size_t)R * c.N * 4) : nullptr;
+            fm_gemm_nt_args a{};
+            a.W = W; a.X = X; a.out = out; a.res = res; a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.ldr = c.N; a.epilogue = c.epi;
+            for (int cfg : cfgs) {
+                fm_set_gemm_nt_config(cfg);
+                printf("%s c%d |", c.name, cfg);
+                double best[8]; for (auto& b : best) b = 1e30;
+                for (int rep = 0; rep < 3; ++rep)
+                    for (int k = 0; k < 8; ++k) {
+                        fm_lab_set(0, knobs[k][0]); fm_lab_set(1, knobs[k][1]);
+                        best[k] = std::min(best[k], time_us([&] { fm_gemm_nt(&a, 0); }, 20, 2));
+                    }
+                for (int k = 0; k < 8; ++k) printf("  g%d s%-2d %6.1f", knobs[k][0], knobs[k][1], best[k]);
+                printf("  us\n"); fflush(stdout);
+            }
+            fm_lab_set(0, 0); fm_lab_set(1, 0);
+            CK(hipFree(W)); CK(hipFree(X)); CK(hipFree(out)); if (res) CK(hipFree(res));
+        }
     } else if (mode == "ksweep") {
         // T(K) = fixed + slope * K at fixed M, N: separates per-tile costs from the main-loop rate
         std::vector<int> cfgs = {265, 266, 267};
