@@ -1037,7 +1037,9 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
 }
 
 int g_nt_config = 9, g_nt_prio = 1;
-int g_lab[16] = {0};      // experiment knobs (tools/gemm_lab via fm_lab_set): [0] de-phase groups, [1] de-phase step (x 2048 cycles)
+// experiment knobs (tools/gemm_lab via fm_lab_set): [0] de-phase groups, [1] de-phase step (x 2048 cycles), [2] gemm_nt3 mode (0 off,
+// 1 = 256-wide tiles, 2 = 192-wide, 3 = by shape: the default; FOURM_NT3=0 turns it off), [3] gemm_nt3 experiment flags
+int g_lab[16] = {0, 0, [] { const char* e = getenv("FOURM_NT3"); return e ? atoi(e) : 3; }(), 0};
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
@@ -1151,7 +1153,7 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     a.M = p->M; a.N = p->N; a.K = p->K; a.ldw = p->ldw; a.ldx = p->ldx; a.ldo = p->ldo; a.ldo2 = p->ldo2; a.ldr = p->ldr; a.Hp = p->Hp;
     a.groups = p->groups; a.tile_group = p->tile_group;
     a.prio = g_nt_prio;
-    a.dephase_groups = g_lab[0]; a.dephase_step = g_lab[1];
+    a.dephase_groups = g_lab[0]; a.dephase_step = g_lab[1]; a.lab = g_lab[3];
     hipStream_t s = (hipStream_t)stream;
     const int max_n = grouped ? p->max_N : p->N;
     if (!grouped && g_lab[2]) {               // the lock-step large-tile kernel (gemm_nt3.hip) takes the dense launches it handles

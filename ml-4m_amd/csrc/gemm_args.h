@@ -17,6 +17,7 @@ struct NTArgs {
     int group_w;                                          // grouped: W-tiles per column block
     int prio;                                             // raise the wave priority around the MFMA clusters
     int dephase_groups, dephase_step;                     // experiment (fm_lab_set): staggered workgroup start
+    int lab;                                              // experiment flags of gemm_nt3 (fm_lab_set 3): 1 no wait for the DMA, 2 no DMA, 4 no stores, 16 all DMA pieces in one k-step, 256 take the residual epilogue
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }

@@ -35,7 +35,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* base) {
 }
 constexpr uint32_t OOB = 0x80000000u;       // an offset with bit 31 set is outside num_records: the access is dropped / reads 0
 
-template <int TW, int EPI>
+template <int TW, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TX = 256, KB = 64, WW = 2, WX = 4, NWAVES = 8, KS = 4;
@@ -145,7 +145,11 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
                         const auto y = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
                         const u32x4_t v = {x[0], y[0], x[1], y[1]};
                         const int c = c0 + i * 32 + 16 * gp;
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, (c < N ? rowoff : OOB) + (uint32_t)c * 2u, 0, 0);
+                        const uint32_t so = (c < N ? rowoff : OOB) + (uint32_t)c * 2u;
+                        if (a.lab & 32) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, so, 0, 2);            // nt
+                        else if (a.lab & 64) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, so, 0, 17);      // sc0 sc1 (write-through)
+                        else if (a.lab & 128) __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, so, 0, 3);      // sc0 nt
+                        else __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, so, 0, 0);
                     }
             }
         } else if constexpr (EPI == EPI_RES) {
@@ -275,33 +279,47 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
 
     int buf = 0, c_kt = 0, c_j = 0;
     bool stores_behind = false;                          // did the previous K-tile end an output tile (its stores are the youngest in the queue)?
-    // one K-tile.  NEXT: a stage g + 1 exists; MORE: a stage g + 2 exists (compile time: the steady state has no branch between
-    // the barrier and the end of the k-step, so the reads, DMA pieces and MFMAs behind the barrier can be interleaved)
-    auto k_tile = [&](auto next_c, auto more_c) __attribute__((always_inline)) {
-        constexpr bool NEXT = decltype(next_c)::value, MORE = decltype(more_c)::value;
+    // one K-tile.  NEXT: a stage g + 1 exists; MORE: a stage g + 2 exists; FIRST: g = 0 (compile time: the steady state has no branch
+    // between the barrier and the end of the k-step, so the reads, DMA pieces and MFMAs behind the barrier can be interleaved).
+    // SPLIT: the X pieces of stage g + 2 (streamed from HBM: longest latency) are issued behind the barrier in k-step 3, its W
+    // pieces (L2 hits) in k-step 0 of the next K-tile: half the DMA instructions per k-step in the vector-memory queue.
+    auto k_tile = [&](auto first_c, auto next_c, auto more_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value, NEXT = decltype(next_c)::value, MORE = decltype(more_c)::value;
+        constexpr bool HALF = SPLIT && NEXT && !FIRST;       // the W pieces of stage g + 1 are still to be issued
         // ---- k-steps 0 .. 2: MFMAs of step kk, fragment reads of step kk + 1 between them ---------------------------------------
 #pragma unroll
         for (int kk = 0; kk < KS - 1; ++kk) {
             read_frags(buf, kk + 1, (kk + 1) & 1);
+            if (HALF && kk == 0) {
+#pragma unroll
+                for (int q = 0; q < PW; ++q) stage_piece(q);
+            }
             mfmas(kk & 1);
 #pragma unroll
             for (int q = 0; q < FW + FX; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (HALF && kk == 0 && q < PW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (HALF && kk == 0) stage_advance();
         }
         // ---- the barrier: stage g + 1 has landed for everyone, stage g has been read by everyone -------------------------------
-        if constexpr (NEXT) { if (stores_behind) wait_vmcnt<NST>(); else wait_vmcnt<0>(); }
+        if constexpr (NEXT) {
+            if (!(a.lab & 1)) { if (stores_behind && !SPLIT) wait_vmcnt<NST>(); else wait_vmcnt<0>(); }
+        }
         wait_lgkmcnt<0>();
         block_barrier();
         __builtin_amdgcn_sched_barrier(0);
         // ---- k-step 3: its MFMAs; first the fragments of stage g + 1 (two reads per MFMA), then the LDS-DMA of stage g + 2 into
         //      the freed buffer (the compiler orders a DMA piece behind every LDS read in flight: reads first, pieces after)
         if constexpr (NEXT) read_frags(buf ^ 1, 0, 0);
+        constexpr int NOW = SPLIT ? PX : LOADS;              // pieces issued in this k-step
         if constexpr (MORE) {
+            if (!(a.lab & 2)) {
 #pragma unroll
-            for (int q = 0; q < LOADS; ++q) stage_piece(q);
+                for (int q = SPLIT ? PW : 0; q < LOADS; ++q) stage_piece(q);
+            }
         }
         mfmas(1);
         constexpr int RD = NEXT ? FW + FX : 0, RSTEPS = (RD + 1) / 2;           // MFMAs that carry two reads each
@@ -312,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
         }
         if constexpr (MORE) {
             constexpr int LEFT = NMF - RSTEPS - 1;                               // MFMAs that carry DMA pieces (the last one carries none)
-            constexpr int PER = (LOADS + LEFT - 1) / LEFT;
+            constexpr int PER = (NOW + LEFT - 1) / LEFT;
 #pragma unroll
             for (int q = 0; q < LEFT; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -320,21 +338,23 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MORE) stage_advance();
+        if constexpr (MORE && !SPLIT) stage_advance();
         buf ^= 1;
         stores_behind = false;
         if (++c_kt == KT) {
-            finish_tile(c_j);
+            if (!(a.lab & 4)) finish_tile(c_j);
             c_kt = 0; ++c_j; stores_behind = true;
         }
     };
-    for (int g = 0; g + 2 < G; ++g) k_tile(std::true_type{}, std::true_type{});
-    k_tile(std::true_type{}, std::false_type{});         // (G >= 2: K >= 128)
-    k_tile(std::false_type{}, std::false_type{});
+    using T = std::true_type; using F = std::false_type;
+    if (G > 2) k_tile(T{}, T{}, T{}); else k_tile(T{}, T{}, F{});        // (G >= 2: K >= 128)
+    for (int g = 1; g + 2 < G; ++g) k_tile(F{}, T{}, T{});
+    if (G > 2) k_tile(F{}, T{}, F{});
+    k_tile(F{}, F{}, F{});
 #endif
 }
 
-template <int TW, int EPI>
+template <int TW, int EPI, bool SPLIT = false>
 int launch_nt3(NTArgs a, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (a.N + NPT - 1) / NPT;
@@ -347,7 +367,7 @@ int launch_nt3(NTArgs a, hipStream_t s) {
     }();
     if (grid > cus) grid = cus;
     const size_t lds = (size_t)2 * (TW + 256) * 128;
-    auto k = gemm_nt3_kernel<TW, EPI>;
+    auto k = gemm_nt3_kernel<TW, EPI, SPLIT>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
@@ -372,14 +392,19 @@ int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     const bool use192 = mode == 2 ? fits192 : mode == 3 ? (fits192 && (a.N % 256 != 0 || t256 % 256 != 0)) : false;
     if (epilogue == FM_EPI_BF16) {
         if (a.ldo % 8 != 0) return 0;
+        if (!(a.lab & 16)) return use192 ? launch_nt3<192, EPI_BF16, true>(a, s) : launch_nt3<256, EPI_BF16, true>(a, s);
         return use192 ? launch_nt3<192, EPI_BF16>(a, s) : launch_nt3<256, EPI_BF16>(a, s);
     }
     if (epilogue == FM_EPI_RESIDUAL) {
+        // in situ the in-epilogue residual reads are slower than gemm.hip's tile-start prefetch (88 vs 83 us at N = K = 768): off unless asked for
+        if (!(a.lab & 256)) return 0;
         if (a.ldo % 4 != 0 || a.ldr % 4 != 0 || !a.res) return 0;
+        if (!(a.lab & 16)) return use192 ? launch_nt3<192, EPI_RES, true>(a, s) : launch_nt3<256, EPI_RES, true>(a, s);
         return use192 ? launch_nt3<192, EPI_RES>(a, s) : launch_nt3<256, EPI_RES>(a, s);
     }
     if (epilogue == FM_EPI_SWIGLU) {
         if (a.N % 64 != 0 || a.Hp % 8 != 0 || a.ldo % 8 != 0 || (a.out2 && a.ldo2 % 8 != 0) || !a.W2) return 0;
+        if (!(a.lab & 16)) return launch_nt3<256, EPI_SWIGLU, true>(a, s);
         return launch_nt3<256, EPI_SWIGLU>(a, s);
     }
     return 0;

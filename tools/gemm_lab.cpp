@@ -34,6 +34,8 @@ template <typename F> static double time_us(F fn, int iters = 20, int warm = 3) 
 }
 
 struct NTCase { const char* name; int N, K, epi; };
+// configurations >= 1000: the lock-step large-tile kernel (gemm_nt3.hip) in mode cfg - 1000 over the default choice
+static void set_cfg(int cfg) { if (cfg >= 1000) { fm_lab_set(2, (cfg - 1000) % 10); fm_lab_set(3, (cfg - 1000) / 10); fm_set_gemm_nt_config(9); } else { fm_lab_set(2, 0); fm_set_gemm_nt_config(cfg); } }
 
 // the clocks of an idle box ramp up over hundreds of milliseconds: spin a GEMM before the first timing
 static void warm_gpu(int ms_target) {
@@ -76,8 +78,6 @@ int main(int argc, char** argv) {
             a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.ldo2 = 2 * c.N; a.ldr = c.N; a.Hp = c.N; a.epilogue = c.epi;
             printf("%s |", c.name);
             std::vector<double> best(cfgs.size(), 1e30);
-            // configurations >= 1000: the lock-step large-tile kernel (gemm_nt3.hip) in mode cfg - 1000 over the default choice
-            auto set_cfg = [&](int cfg) { if (cfg >= 1000) { fm_lab_set(2, cfg - 1000); fm_set_gemm_nt_config(9); } else { fm_lab_set(2, 0); fm_set_gemm_nt_config(cfg); } };
             {   // every configuration against the first one (bit patterns of the primary output)
                 const size_t nbytes = (size_t)R * c.N * (f32out ? 4 : 2);
                 std::vector<uint16_t> ref(nbytes / 2), got(nbytes / 2);
@@ -151,7 +151,7 @@ int main(int argc, char** argv) {
                     for (size_t c = 0; c < cfgs.size(); ++c) {
                         fm_gemm_nt_args a{};
                         a.W = W; a.X = X; a.out = out; a.M = R; a.N = N; a.K = Ks[ki]; a.ldw = 6144; a.ldx = 6144; a.ldo = N; a.epilogue = FM_EPI_BF16;
-                        fm_set_gemm_nt_config(cfgs[c]);
+                        set_cfg(cfgs[c]);
                         if (fm_gemm_nt(&a, 0) != 0) { printf("cfg%d: %s\n", cfgs[c], fm_last_error()); continue; }
                         double us = time_us([&] { fm_gemm_nt(&a, 0); }, 20, 2);
                         if (us < t[c][ki]) t[c][ki] = us;
