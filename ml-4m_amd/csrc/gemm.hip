@@ -821,9 +821,13 @@ struct TNMultiArgs {
 
 // TA = 128, KB = 64: 64 x 64 wave tiles, 144 KB of LDS;  TA = 256, KB = 32: 128 x 64 wave tiles (8 accumulators per wave), 96 KB - per MFMA
 // 2/3 of the LDS-DMA pieces and 3/8 of the transpose reads of the small tile.
-template <bool MASKED, int TA = 128, int KB = 64>
+// LS ("lock step", TA = 256, KB = 64, two stages = 128 KB): the structure of gemm_nt3.hip on the TN operands - ONE barrier per K-tile,
+// placed before its last k-step (whose fragments are already in registers), every transpose read of the next k-step and every LDS-DMA
+// piece of the next K-tile issued BETWEEN the MFMAs (a burst of reads behind a barrier costs ~200 cycles, tools/ubench.hip), rows past
+// the live count read as zero through the buffer descriptor's bounds check instead of a per-lane select.
+template <bool MASKED, int TA = 128, int KB = 64, bool LS = false>
 __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
-    constexpr int TB = 256, WB = 4, STAGES = 3, NWAVES = 8;
+    constexpr int TB = 256, WB = 4, STAGES = LS ? 2 : 3, NWAVES = 8;
     constexpr int FWA = TA / 2 / 32;                  // 32-column A fragments per wave
     constexpr int RBA = TA * 2, RBB = TB * 2;
     constexpr int PA = KB * RBA / 1024, PB = KB * RBB / 1024;
@@ -859,6 +863,122 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
         const int n0 = (local / jb.n_tiles_b) * TA, k0 = (local % jb.n_tiles_b) * TB;
         const bf16_t* A = jb.A; const bf16_t* B = jb.B;
         const int lda = jb.lda, ldb = jb.ldb, a_cols = jb.a_cols, b_cols = jb.b_cols, r_lim = jb.R;
+
+#if defined(__HIP_DEVICE_COMPILE__)      // (buffer-descriptor builtins: the host pass only needs the kernel stub)
+        if constexpr (LS) {
+            static_assert(!LS || (TA == 256 && KB == 64), "lock-step form: 256 x 256 tiles, K-step 64");
+            // ---- DMA: 8 pieces of 1 KiB (2 rows x 512 B) per wave and stage; source rows >= R fall outside the descriptor: zeros --------
+            constexpr int NPA = PA / NWAVES, NPB = PB / NWAVES, NP = NPA + NPB;          // 4 + 4
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(A), 0, (int)min((size_t)r_lim * lda * 2, (size_t)0x7fffffff), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(B), 0, (int)min((size_t)r_lim * ldb * 2, (size_t)0x7fffffff), 0x00020000);
+            uint32_t offp[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const bool isa = q < NPA;
+                const int piece = (isa ? q : q - NPA) * NWAVES + wave;
+                const int row = piece * 2 + lane / 32;
+                const int lc = (lane % 32) ^ ((row & 3) << 2);
+                int c = (isa ? n0 : k0) + lc * 8;
+                const int cols = isa ? a_cols : b_cols;
+                c = c <= cols - 8 ? c : cols - 8;
+                offp[q] = (uint32_t)row * (uint32_t)(isa ? lda : ldb) * 2u + (uint32_t)c * 2u;
+            }
+            auto dma = [&](int t, int buf, int q) __attribute__((always_inline)) {
+                char* base = smem + buf * STAGE;
+                if (q < NPA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, LDS_PTR(base + (q * NWAVES + wave) * 1024), 16, offp[q], t * (KB * lda * 2), 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, LDS_PTR(base + KB * RBA + ((q - NPA) * NWAVES + wave) * 1024), 16, offp[q], t * (KB * ldb * 2), 0, 0);
+            };
+            f32x16_t acc[FWA][2];
+#pragma unroll
+            for (int i = 0; i < FWA; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
+            const int NT_ = t_end - t_begin;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) dma(t_begin, 0, q);
+            if (NT_ > 1) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) dma(t_begin + 1, 1, q);
+                wait_vmcnt<NP>();
+            } else wait_vmcnt<0>();
+            block_barrier();
+            union Frag { bf16x8_t v; s16x4_t h[2]; };
+            Frag af[2][FWA], bfr[2][2];
+            // one half (4 rows) of fragment f (f < FWA: A, else B) of k-step kk in stage `st`, into register set PAR
+            auto rd = [&](uint32_t st, auto kk_c, auto f_c, auto h_c, auto par_c) __attribute__((always_inline)) {
+                constexpr int kk = decltype(kk_c)::value, f = decltype(f_c)::value, h = decltype(h_c)::value, PAR = decltype(par_c)::value;
+                if constexpr (f < FWA) af[PAR][f].h[h] = tr_read<kk * 16 * RBA + h * 4 * RBA>(st + baseA[f]);
+                else bfr[PAR][f - FWA].h[h] = tr_read<kk * 16 * RBB + h * 4 * RBB>(st + baseB[f - FWA]);
+            };
+            constexpr int NF = FWA + 2, NMF = FWA * 2;                               // 6 fragments (12 reads), 8 MFMAs per k-step
+            static_assert(!LS || NMF == 8, "k-step of the lock-step form: 8 MFMAs");
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+            // k-step with the fragments of register set PAR: MFMA m, then both halves of fragment m (m < 6) of k-step KN of stage `st_next`
+            // into the other set, and (DN > 0) DMA piece D0 + m of K-tile t_dma behind MFMA m < DN
+            auto k_step = [&](uint32_t st_next, auto kn_c, auto par_c, int t_dma, int buf_dma, auto d0_c, auto dn_c) __attribute__((always_inline)) {
+                constexpr int PAR = decltype(par_c)::value, d0 = decltype(d0_c)::value, dn = decltype(dn_c)::value;
+                wait_lgkmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                auto one = [&](auto m_c) __attribute__((always_inline)) {
+                    constexpr int m = decltype(m_c)::value;
+                    constexpr int i = m / 2, jj = m % 2;
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PAR][i].v, bfr[PAR][jj].v, acc[i][jj], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (m < NF) {
+                        rd(st_next, kn_c, std::integral_constant<int, (m < NF ? m : 0)>{}, I0{}, std::integral_constant<int, PAR ^ 1>{});
+                        rd(st_next, kn_c, std::integral_constant<int, (m < NF ? m : 0)>{}, I1{}, std::integral_constant<int, PAR ^ 1>{});
+                    }
+                    if constexpr (m < dn) { if (t_dma >= 0) dma(t_dma, buf_dma, d0 + m); }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                one(I0{}); one(I1{}); one(I2{}); one(I3{}); one(I4{}); one(I5{}); one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+            };
+            // fragments of (stage 0, k-step 0)
+            {
+                const uint32_t st0 = smem_lds;
+                rd(st0, I0{}, I0{}, I0{}, I0{}); rd(st0, I0{}, I0{}, I1{}, I0{}); rd(st0, I0{}, I1{}, I0{}, I0{}); rd(st0, I0{}, I1{}, I1{}, I0{});
+                rd(st0, I0{}, I2{}, I0{}, I0{}); rd(st0, I0{}, I2{}, I1{}, I0{}); rd(st0, I0{}, I3{}, I0{}, I0{}); rd(st0, I0{}, I3{}, I1{}, I0{});
+                rd(st0, I0{}, I4{}, I0{}, I0{}); rd(st0, I0{}, I4{}, I1{}, I0{}); rd(st0, I0{}, I5{}, I0{}, I0{}); rd(st0, I0{}, I5{}, I1{}, I0{});
+            }
+            int buf = 0;
+            using NA = std::integral_constant<int, NPA>; using NB = std::integral_constant<int, NPB>;
+            for (int it = 0; it < NT_; ++it) {
+                const uint32_t st = smem_lds + buf * STAGE, stn = smem_lds + (buf ^ 1) * STAGE;
+                const bool next = it + 1 < NT_, more = it + 2 < NT_;
+                // k-step 0 carries the B pieces of stage it + 1 (its A pieces went out behind the previous barrier); k-steps 1, 2 none
+                k_step(st, I1{}, I0{}, (it > 0 && next) ? t_begin + it + 1 : -1, buf ^ 1, NA{}, NB{});
+                k_step(st, I2{}, I1{}, 0, 0, I0{}, I0{});
+                k_step(st, I3{}, I0{}, 0, 0, I0{}, I0{});
+                // stage it + 1 landed for everyone, stage `it` read by everyone (k-step 3's fragments are in registers)
+                if (next) wait_vmcnt<0>();
+                wait_lgkmcnt<0>();
+                block_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // k-step 3: first fragments of stage it + 1 (stale bytes, unused, after the last stage), the A pieces of stage it + 2
+                k_step(stn, I0{}, I1{}, more ? t_begin + it + 2 : -1, buf, I0{}, NA{});
+                buf ^= 1;
+            }
+            // accumulator: rows <-> n (A columns), cols <-> k (B columns); lane = k, regs = n
+            float* out = jb.out;
+            const int N = jb.N, K = jb.K, ldo = jb.ldo;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int k = k0 + wb * 64 + jj * 32 + (lane & 31);
+                if (k >= K) continue;
+#pragma unroll
+                for (int i = 0; i < FWA; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = n0 + wa * (TA / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                        if (n < N) unsafeAtomicAdd(out + (size_t)n * ldo + k, acc[i][jj][r]);
+                    }
+            }
+            return;
+        }
+#endif
 
         auto stage_piece = [&](int t, int buf, int q) {
             char* base = smem + buf * STAGE;
@@ -1205,7 +1325,7 @@ extern "C" int fm_get_gemm_nt_config(void) { return g_nt_config; }
 extern "C" void fm_lab_set(int key, int value) { if (key >= 0 && key < 16) g_lab[key] = value; }
 extern "C" void fm_set_reserved_cus(int n) { g_reserved_cus = n < 0 ? 0 : n; }
 extern "C" int fm_get_reserved_cus(void) { return g_reserved_cus; }
-static int g_tn_config = 1;
+static int g_tn_config = [] { const char* e = getenv("FOURM_TN_CONFIG"); return e ? atoi(e) : 1; }();      // 0 lock-step K32 x 2 WG/CU, 1 ping-pong (dW list: 256 x 256 / K32), 3 as 1 with 128 x 256 list tiles, 4 as 1 with the lock-step list kernel (equal in situ: 11.6 ms per 4M-B step either way, profiles/r03_ab_tn_lockstep.txt)
 extern "C" void fm_set_gemm_tn_config(int cfg) { g_tn_config = cfg; }
 extern "C" int fm_get_gemm_tn_config(void) { return g_tn_config; }
 static int g_tn_use_tr = 1;   // ds_read_b64_tr_b16 semantics verified on hardware (tools/probe_gfx950.hip)
@@ -1230,7 +1350,7 @@ extern "C" int fm_gemm_tn(const fm_gemm_tn_args* p, void* stream) {
     //                  fp32 atomic traffic of the epilogue (workgroups x 128 KB per launch, ~25 us at 512 workgroups)
     constexpr int TN_TA = 128, TN_TB = 256, TN_STAGES = 3;
     // (the grouped head GEMM keeps configuration 0: short, uneven reductions - 940 vs 1110 us at the 4M-B shapes)
-    const bool pp = (g_tn_config == 1 || g_tn_config == 3) && !grouped && p->force_tr != 0;
+    const bool pp = (g_tn_config == 1 || g_tn_config == 3 || g_tn_config == 4) && !grouped && p->force_tr != 0;
     const int kb = pp ? 64 : 32, slots = (pp ? 1 : 2) * n_compute_units();
     a.n_tiles_a = (max_n + TN_TA - 1) / TN_TA; a.n_tiles_b = (p->K + TN_TB - 1) / TN_TB;
     int splits = p->splits;
@@ -1281,7 +1401,8 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
     // layer 478 -> 461 us (profiles/r02_lab_tn_multi_tiles.txt)
     static const bool small_env = [] { const char* e = getenv("FOURM_TN_MULTI_TILE"); return e && atoi(e) == 128; }();
     const bool big = !(small_env || g_tn_config == 3);
-    const int ta = big ? 256 : 128, kb = big ? 32 : 64;
+    const bool ls = big && g_tn_config == 4;                 // lock-step form: 256 x 256 tiles, K-step 64, two stages
+    const int ta = big ? 256 : 128, kb = (big && !ls) ? 32 : 64;
     for (int i = 0; i < n_jobs; ++i) {
         const fm_gemm_tn_job& p = jobs[i];
         FM_CHECK_ARG(p.A && p.B && p.out, "fm_gemm_tn_multi: null pointer");
@@ -1314,12 +1435,12 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         // share is a fraction of a tile, i.e. in the contiguous cut)
         const int rem = tiles % grid, ntail = grid - rem;
         a.tail_rr = rem >= ntail;
-        const double c = big ? (a.tail_rr ? 24.0 : 128.0) : 8.0;
+        const double c = ls ? (a.tail_rr ? 12.0 : 64.0) : big ? (a.tail_rr ? 24.0 : 128.0) : 8.0;     // (in k-tiles of this configuration)
         // Contiguous cut with bands (rem < ntail): tail workgroup i takes ONE band [q, q + lb) of tile i - the first rem tails start
         // together on neighbouring tiles over the same rows and share operand panels in L2 like the mains (as plain contiguous runs
         // the tails re-read 1.9 x the operands: profiles/r02_v6_traffic_table.txt) - the other ntail - rem walk the rest.  4M-B encoder
         // layer (108 tiles): 474 -> 420 us (profiles/r02_lab_tn_multi_tiles.txt).  FOURM_TN_BANDS=0: plain contiguous runs (A/B).
-        constexpr double cb = 32.0;
+        const double cb = ls ? 16.0 : 32.0;
         static const bool band_off = [] { const char* e = getenv("FOURM_TN_BANDS"); return e && atoi(e) == 0; }();
         a.banded = !a.tail_rr && rem > 0 && ntail > rem && !band_off;
         for (int i = 0; i < n_jobs; ++i) {
@@ -1347,15 +1468,17 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         }
     }
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_TNM(MK, TAV, KBV)                                                                                              \
+#define LAUNCH_TNM(MK, TAV, KBV, ...)                                                                                         \
     {                                                                                                                         \
-        constexpr size_t lds = (size_t)3 * KBV * (TAV + 256) * 2;                                                             \
-        auto k = gemm_tn_multi_kernel<MK, TAV, KBV>;                                                                          \
+        constexpr bool lsv = sizeof(#__VA_ARGS__) > 1;                                                                        \
+        constexpr size_t lds = (size_t)(lsv ? 2 : 3) * KBV * (TAV + 256) * 2;                                                 \
+        auto k = gemm_tn_multi_kernel<MK, TAV, KBV, lsv>;                                                                     \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true); \
         (void)once;                                                                                                           \
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);                                                              \
     }
-    if (big) { if (masked) LAUNCH_TNM(true, 256, 32) else LAUNCH_TNM(false, 256, 32) }
+    if (ls) LAUNCH_TNM(false, 256, 64, ls)        // (row masking through the buffer descriptor)
+    else if (big) { if (masked) LAUNCH_TNM(true, 256, 32) else LAUNCH_TNM(false, 256, 32) }
     else { if (masked) LAUNCH_TNM(true, 128, 64) else LAUNCH_TNM(false, 128, 64) }
 #undef LAUNCH_TNM
     FM_CHECK_LAUNCH("fm_gemm_tn_multi");

@@ -219,7 +219,7 @@ def test_gemm_tn_pingpong_schedule(R, N, K, splits):
                 ops.gemm_tn(a, b, out, splits=splits)
                 assert rel_err(out, ref) < 1e-4, (cfg, rel_err(out, ref))
         finally:
-            L.lib.fm_set_gemm_tn_config(1)
+            L.lib.fm_set_gemm_tn_config(TN_DEFAULT)
 
 
 @pytest.mark.parametrize("cfg", [0, 1])
@@ -237,9 +237,10 @@ def test_gemm_tn_masks_rows_past_R(cfg, R, Rbuf):
         ops.gemm_tn(a, b, out, R=R)
         assert rel_err(out, ref) < 1e-4, (cfg, R, rel_err(out, ref))
     finally:
-        L.lib.fm_set_gemm_tn_config(1)
+        L.lib.fm_set_gemm_tn_config(TN_DEFAULT)
 
 
+TN_DEFAULT = 1
 TN_MULTI_LISTS = {
     # (R, N, K) per job
     "one_small": [(64, 128, 128)],
@@ -250,7 +251,7 @@ TN_MULTI_LISTS = {
 }
 
 
-@pytest.mark.parametrize("tile", [256, 128])
+@pytest.mark.parametrize("tile", [256, 128, "lockstep"])
 @pytest.mark.parametrize("name", sorted(TN_MULTI_LISTS))
 def test_gemm_tn_multi(name, tile):
     """fm_gemm_tn_multi: every job of the list accumulates dY^T X into its own output, whatever the cut of the tile list over the
@@ -264,7 +265,7 @@ def test_gemm_tn_multi(name, tile):
         a[R:] = 1e4; b[R:] = float("nan")
         refs.append(1.0 + a[:R].float().t() @ b[:R].float())
         jobs.append((a, b, None, N, K, R))
-    L.lib.fm_set_gemm_tn_config(1 if tile == 256 else 3)         # 256 x 256 tiles (default) / 128 x 256
+    L.lib.fm_set_gemm_tn_config({256: 1, 128: 3, "lockstep": 4}[tile])         # 256 x 256 / K-step 32, 128 x 256, lock-step 256 x 256 / 64
     try:
         for _ in range(3):
             outs = [torch.full((N, K), 1.0, device=DEV, dtype=torch.float32) for _, N, K in TN_MULTI_LISTS[name]]
@@ -272,7 +273,7 @@ def test_gemm_tn_multi(name, tile):
             for i, (o, ref) in enumerate(zip(outs, refs)):
                 assert rel_err(o, ref) < 1e-4, (name, tile, i, rel_err(o, ref))
     finally:
-        L.lib.fm_set_gemm_tn_config(1)
+        L.lib.fm_set_gemm_tn_config(TN_DEFAULT)
 
 
 def test_gemm_tn_multi_column_views():

@@ -7,8 +7,10 @@ import sys
 
 
 def plan(jobs, cus, big=True, bands=True):
-    """jobs: list of (N, K, R).  Mirrors the host code."""
-    ta, kb = (256, 32) if big else (128, 64)
+    """jobs: list of (N, K, R).  Mirrors the host code.  big: True = 256 x 256 tiles with K-step 32, False = 128 x 256 / 64,
+    "ls" = the lock-step form (256 x 256 tiles, K-step 64: fm_set_gemm_tn_config(4))."""
+    ls = big == "ls"
+    ta, kb = (256, 64) if ls else (256, 32) if big else (128, 64)
     J, tiles, units = [], 0, 0
     for N, K, R in jobs:
         ntb = (K + 255) // 256
@@ -24,8 +26,8 @@ def plan(jobs, cus, big=True, bands=True):
         grid = 8
     rem, ntail = tiles % grid, grid - tiles % grid
     tail_rr = rem >= ntail
-    c = (24.0 if tail_rr else 128.0) if big else 8.0
-    cb = 32.0
+    c = (12.0 if tail_rr else 64.0) if ls else (24.0 if tail_rr else 128.0) if big else 8.0
+    cb = 16.0 if ls else 32.0
     banded = (not tail_rr) and rem > 0 and ntail > rem and bands
     for j in J:
         j["lb"] = 0
