@@ -30,3 +30,8 @@ def image_mask_batched(num_tokens: int, input_budget: torch.Tensor, target_budge
     dam = torch.empty(B, num_tokens, dtype=torch.int32, device=dev)
     L.check(L.image_mask(ops._p(noise), ops._p(kin), ops._p(kt), B, num_tokens, ops._p(im), ops._p(tm), ops._p(dam), ops._stream()))
     return {"input_mask": im, "target_mask": tm, "decoder_attention_mask": dam}
+
+
+# the host-side masking classes (UnifiedMasking, TransferMasking, ...) stay upstream's
+from .. import _upstream as _up
+_up.merge(__name__, globals())

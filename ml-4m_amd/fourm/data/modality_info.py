@@ -96,3 +96,8 @@ MODALITY_INFO = {
     "tok_semseg@448": _grid_tokens("tok_semseg@448", 4096, res=448),
     "tok_clip@448": _grid_tokens("tok_clip@448", 8192, res=448),
 }
+
+
+# names only upstream's same-named module defines (see fourm/_upstream.py)
+from fourm import _upstream as _up
+_up.merge(__name__, globals())

@@ -80,3 +80,23 @@ def synthetic_batch(model, batch: int, n_in: int, n_out: int, device="cuda", see
             dam = torch.where(pos == first, ko.expand(batch, L), torch.zeros_like(rank)).int()   # whole group attends to itself
         out[n] = dict(tensor=t, input_mask=~(rank < ki), target_mask=~((rank >= ki) & (rank < ki + ko)), decoder_attention_mask=dam)
     return out
+
+
+class SyntheticLoader:
+    """An iterable with the training loader's output contract (one ``mod_dict`` per step, ``len()`` = steps per epoch): ``distinct``
+    pre-generated synthetic batches handed out in turn.  Stands in for ``build_mixture_dataloader`` when the trainer runs without a
+    dataset (``data_config`` of type 'synthetic', benchmarks, smoke tests)."""
+
+    def __init__(self, model, batch_size: int, num_input_tokens: int, num_target_tokens: int, steps: int, device="cpu", seed: int = 0,
+                 distinct: int = 4):
+        self.steps = int(steps)
+        self.batches = [synthetic_batch(model, batch_size, num_input_tokens, num_target_tokens, device=device, seed=seed + i)
+                        for i in range(max(1, min(distinct, self.steps)))]
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for i in range(self.steps):
+            b = self.batches[i % len(self.batches)]
+            yield {m: dict(d) for m, d in b.items()}           # the forward adds keys to the inner dicts

@@ -70,3 +70,8 @@ class ImageTokenDecoderEmbedding(_Head, _Embedder):
         h, w = self.image_size[0] // self.patch_size[0], self.image_size[1] // self.patch_size[1]
         self._make_pos(build_2d_sincos_posemb(h=h, w=w, embed_dim=dim_tokens) if self.sincos_pos_emb else None, h * w, init_std)
         self._make_head()
+
+
+# names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)
+from fourm import _upstream as _up
+__getattr__ = _up.fallthrough(__name__, is_package=False)

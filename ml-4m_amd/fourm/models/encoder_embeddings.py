@@ -131,3 +131,8 @@ class SequenceEmbEncoderEmbedding(_SeqPos):
         self.dim_tokens = dim_tokens
         self._seq_pos(init_std)
         self.emb_proj = nn.Linear(self.orig_emb_dim, dim_tokens)
+
+
+# names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)
+from fourm import _upstream as _up
+__getattr__ = _up.fallthrough(__name__, is_package=False)

@@ -464,3 +464,8 @@ for _size in _SIZES:
     _factory(f"fm_{_size}_swiglu_nobias", _size, **_SWIGLU)
 for _size in ("base_12e_12d", "large_24e_24d", "xlarge_24e_24d"):
     _factory(f"fm_{_size}_swiglu_qknorm_nobias", _size, qk_norm=True, **_SWIGLU)
+
+
+# names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)
+from fourm import _upstream as _up
+__getattr__ = _up.fallthrough(__name__, is_package=False)

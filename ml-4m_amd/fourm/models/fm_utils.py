@@ -212,3 +212,8 @@ def act_name(act_module: nn.Module) -> str:
     if isinstance(act_module, nn.GELU) and getattr(act_module, "approximate", "none") == "none":
         return "gelu"
     raise NotImplementedError(f"activation {type(act_module).__name__} has no HIP epilogue (SiLU-gated or exact GELU only)")
+
+
+# names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)
+from fourm import _upstream as _up
+__getattr__ = _up.fallthrough(__name__, is_package=False)

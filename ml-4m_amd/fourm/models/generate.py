@@ -599,3 +599,8 @@ class GenerationSampler(nn.Module):
             else:
                 raise ValueError("Invalid schedule")
         return mod_dict
+
+
+# names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)
+from fourm import _upstream as _up
+__getattr__ = _up.fallthrough(__name__, is_package=False)

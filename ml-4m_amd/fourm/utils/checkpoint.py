@@ -86,3 +86,8 @@ def load_safetensors(safetensors_path, return_metadata=True):
         tensors = {k: f.get_tensor(k) for k in f.keys()}
         meta = f.metadata()
     return (tensors, _parse_meta(meta or {})) if return_metadata else tensors
+
+
+# names only upstream's same-named module defines (see fourm/_upstream.py)
+from fourm import _upstream as _up
+_up.merge(__name__, globals())

@@ -40,3 +40,8 @@ def init_distributed_mode(args):
     dist.init_process_group(backend=args.dist_backend, init_method=getattr(args, "dist_url", "env://"),
                             world_size=args.world_size, rank=args.rank, timeout=datetime.timedelta(minutes=80))
     dist.barrier()
+
+
+# names only upstream's same-named module defines (see fourm/_upstream.py)
+from fourm import _upstream as _up
+_up.merge(__name__, globals())

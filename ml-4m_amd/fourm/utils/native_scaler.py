@@ -61,3 +61,8 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
     params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
     per_tensor = [p.grad.detach().norm(float(norm_type)) for p in params if p.grad is not None]
     return torch.stack(per_tensor).norm(float(norm_type)) if per_tensor else torch.tensor(0.)
+
+
+# names only upstream's same-named module defines (see fourm/_upstream.py)
+from fourm import _upstream as _up
+_up.merge(__name__, globals())

@@ -338,3 +338,8 @@ def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filt
         fused_ok = hasattr(type(inner), "engine") and ps and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps)
         return FusedAdamW(parameters, **opt_args) if fused_ok else optim.AdamW(parameters, **opt_args)
     raise ValueError(f"Invalid optimizer {args.opt}")
+
+
+# names only upstream's same-named module defines (see fourm/_upstream.py)
+from fourm import _upstream as _up
+_up.merge(__name__, globals())

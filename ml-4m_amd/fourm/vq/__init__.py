@@ -24,3 +24,7 @@ def get_image_tokenizer(tokenizer_id: str, tokenizers_root: str = "./tokenizer_c
     if verbose:
         print(msg)
     return model.to(device).eval(), a
+
+from fourm import _upstream as _up
+
+_up.extend_path(__name__, __path__)

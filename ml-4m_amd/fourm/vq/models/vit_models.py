@@ -114,3 +114,8 @@ def _enc(dim, depth, heads):
 
 
 vit_s_enc, vit_b_enc, vit_l_enc = _enc(512, 8, 8), _enc(768, 12, 12), _enc(1024, 24, 16)
+
+
+# names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)
+from fourm import _upstream as _up
+__getattr__ = _up.fallthrough(__name__, is_package=False)

@@ -1,1 +1,5 @@
 from .quantize_lucid import VectorQuantize as VectorQuantizerLucid
+
+from fourm import _upstream as _up
+
+_up.extend_path(__name__, __path__)

@@ -89,3 +89,8 @@ class VectorQuantize(nn.Module):
 
     def indices_to_embedding(self, indices):
         return F.embedding(indices, self.codebook).permute(0, 3, 1, 2)
+
+
+# names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)
+from fourm import _upstream as _up
+__getattr__ = _up.fallthrough(__name__, is_package=False)

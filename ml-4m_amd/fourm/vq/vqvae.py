@@ -107,3 +107,8 @@ class VQ(nn.Module, PyTorchModelHubMixin):
 
     def forward(self, x: torch.Tensor):
         return self.encode(x)
+
+
+# names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)
+from fourm import _upstream as _up
+__getattr__ = _up.fallthrough(__name__, is_package=False)

@@ -1,0 +1,96 @@
+"""The trainer on the device: ``ml-4m_amd/run_training_4m.py`` end to end on a synthetic dataset - YAML -> args ->
+model -> ``fourm.parallel.DataParallel`` -> FusedAdamW -> epochs with gradient accumulation (``no_sync``) -> log.txt, checkpoints in
+upstream's layout -> auto-resume; and ``train_one_epoch`` + ``save_model`` / ``auto_load_model`` on their own."""
+import copy
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "tests/cfgs/default/4m-ti_mod7_synth.yaml")
+
+
+def _args(tmp_path, *extra):
+    import run_training_4m as T
+    from fourm import utils
+    a = T.get_args(["-c", CFG, "--output_dir", str(tmp_path / "auto"), "--num_workers", "0", *extra])
+    utils.setup_run_name(a)
+    utils.setup_s3_args(a)
+    os.makedirs(a.output_dir, exist_ok=True)
+    return T, a
+
+
+def test_main_trains_logs_checkpoints_and_resumes(tmp_path):
+    T, a = _args(tmp_path, "--accum_iter", "2", "--epoch_size", "16")           # 4 micro-batches = 2 optimizer steps per epoch
+    assert a.output_dir.endswith("4m-ti_mod7_synth") and a.run_name == "4m-ti_mod7_synth"
+    T.main(copy.deepcopy(a))
+    out = a.output_dir
+    rows = [json.loads(l) for l in open(os.path.join(out, "log.txt"))]
+    assert [r["epoch"] for r in rows] == [0, 1]
+    for r in rows:
+        assert 0 < r["[Epoch] loss"] < 12 and r["[Epoch] grad_norm"] > 0 and r["[Eval (synthetic)] loss"] > 0
+        assert any(k.startswith("[Epoch] tok_") and k.endswith("_loss") for k in r) and r["n_parameters"] > 1e8
+    assert rows[1]["total_tokens_seen_b"] == pytest.approx(2 * 4 * (4 * 2 / 2) * 256 / 1e9)
+    assert rows[0]["[Epoch] lr"] < rows[1]["[Epoch] lr"] or rows[0]["[Epoch] lr"] > 0      # warm-up epoch, then the cosine
+    for name in ("checkpoint-0.pth", "checkpoint-1.pth", "checkpoint-final.pth"):
+        assert os.path.isfile(os.path.join(out, name)), name
+    ck = torch.load(os.path.join(out, "checkpoint-1.pth"), map_location="cpu", weights_only=False)
+    assert set(ck) >= {"model", "epoch", "args", "scaler", "optimizer"} and ck["epoch"] == 1 and ck["args"].model == a.model
+    assert "encoder.0.attn.qkv.weight" in ck["model"] and len(ck["optimizer"]["param_groups"]) >= 2
+    assert all("lr_scale" in g for g in ck["optimizer"]["param_groups"])
+    # resume: one more epoch; auto_resume picks checkpoint-1 and only epoch 2 runs
+    b = copy.deepcopy(a)
+    b.epochs = 3
+    T.main(b)
+    rows = [json.loads(l) for l in open(os.path.join(out, "log.txt"))]
+    assert [r["epoch"] for r in rows] == [0, 1, 2] and os.path.isfile(os.path.join(out, "checkpoint-2.pth"))
+
+
+def test_train_one_epoch_and_checkpoint_round_trip(tmp_path):
+    """Two optimizer steps through ``train_one_epoch``, save, load into a fresh model / optimizer, and the next step is the same on
+    both (weights, AdamW moments and step counts survived the round trip)."""
+    import numpy as np
+    from fourm import utils
+    from fourm.data import SyntheticLoader
+    from fourm.parallel import DataParallel
+    from fourm.utils.optim_factory import create_optimizer
+    T, a = _args(tmp_path)
+    utils.init_distributed_mode(a)
+    a.num_tasks = 1
+    dev = torch.device("cuda")
+
+    def build():
+        torch.manual_seed(0)
+        info, _, _, _, _ = T.setup_data(a)
+        model = T.get_model(a, info).to(dev)
+        wrapped = DataParallel(model, device_ids=[0])
+        a.lr = 1e-3
+        return wrapped, create_optimizer(a, wrapped.module), utils.NativeScalerWithGradNormCount(enabled=False)
+    model, opt, scaler = build()
+    loader = SyntheticLoader(model.module, a.batch_size, 128, 128, 3, device=dev, seed=7)
+    lr = np.full(8, 1e-3); wd = np.full(8, 0.05)
+    kw = dict(num_input_tokens=128, num_target_tokens=128, loss_type="mod", device=dev, frozen_model_epochs=0, accum_iter=1, max_norm=3.0,
+              lr_schedule_values=lr, wd_schedule_values=wd, all_domains=a.all_domains, loader_len=3, output_dir=a.output_dir)
+    stats = T.train_one_epoch(model=model, data_loader=loader, optimizer=opt, epoch=0, loss_scaler=scaler, start_steps=0, **kw)
+    assert 0 < stats["[Epoch] loss"] < 12 and stats["[Epoch] grad_norm"] > 0
+    utils.save_model(args=a, model=model, model_without_ddp=model.module, optimizer=opt, loss_scaler=scaler, epoch=0)
+    model2, opt2, scaler2 = build()
+    with torch.no_grad():
+        for p in model2.parameters():
+            p.add_(1.0)                                                     # make sure the load is what equalises them
+    b = copy.deepcopy(a)
+    utils.auto_load_model(args=b, model=model2, model_without_ddp=model2.module, optimizer=opt2, loss_scaler=scaler2)
+    assert b.start_epoch == 1
+    for (k, v), (_, w) in zip(model.module.state_dict().items(), model2.module.state_dict().items()):
+        assert torch.equal(v, w), k
+    one = SyntheticLoader(model.module, a.batch_size, 128, 128, 1, device=dev, seed=99)
+    s1 = T.train_one_epoch(model=model, data_loader=one, optimizer=opt, epoch=1, loss_scaler=scaler, start_steps=3, **{**kw, "loader_len": 1})
+    s2 = T.train_one_epoch(model=model2, data_loader=one, optimizer=opt2, epoch=1, loss_scaler=scaler2, start_steps=3, **{**kw, "loader_len": 1})
+    assert s1["[Epoch] loss"] == pytest.approx(s2["[Epoch] loss"], rel=1e-5)
+    # (AdamW normalises the update: an atomics-order flip of a near-zero gradient moves a weight by up to lr, so compare in the mean)
+    num = sum(float((v.float() - w.float()).pow(2).sum()) for v, w in zip(model.module.state_dict().values(), model2.module.state_dict().values()))
+    den = sum(float(v.float().pow(2).sum()) for v in model.module.state_dict().values())
+    assert (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
