@@ -122,7 +122,7 @@ class FourM(nn.Module):
         try:        # stand-alone ``blk(x, mask)`` calls find the engine through this registry (fourm/hip/functional.py)
             from fourm.hip.functional import register_blocks
             register_blocks(self)
-        except ImportError:      # no libfourm_hip.so: the model is a parameter container only (state_dict tools)
+        except (ImportError, OSError):      # no (loadable) libfourm_hip.so: the model is a parameter container only (state_dict tools)
             pass
 
     # ------------------------------------------------------------------------------------------

@@ -384,6 +384,11 @@ class GenerationSampler(nn.Module):
         order = torch.argsort(tm.float() + torch.arange(tm.shape[1], device=tm.device).unsqueeze(0) * 1e-6, dim=1)[:, :n]
         dec_ids = torch.gather(ids_all, 1, order)
         dec_emb = torch.gather(emb_all, 1, order.unsqueeze(-1).expand(-1, -1, D))
+        # samples with fewer target positions than sample 0 pull masked positions in: upstream zeroes their ids and embeddings
+        # (forward_mask_decoder_autoregressive, generate.py:543-545)
+        gathered_tm = torch.gather(tm, 1, order)
+        dec_ids = dec_ids.masked_fill(gathered_tm, 0)
+        dec_emb = dec_emb.masked_fill(gathered_tm.unsqueeze(-1), 0)
         T = min(int(m.modality_info[target_mod]["max_tokens"]), n)
         y_emb = ws.get("ar.y_emb", (B, T, D), f32)                   # (B, T, D): position + modality embedding of step t (a fixed
         y_emb.copy_(dec_emb[:, :T])                                  # buffer: captured graphs keep reading it in later calls)
@@ -466,6 +471,8 @@ class GenerationSampler(nn.Module):
             store = self.__dict__.setdefault("_ar_graphs", {})
             # everything that decides a workspace shape (hence a captured pointer) or a captured scalar
             shape_key = (id(m), target_mod, B, T, Tc, guided, float(guidance_scale), tuple(d.n_ctx for d in decoders))
+            if store and next(iter(store))[0] != shape_key:          # graphs of another shape pin their memory pools: keep one shape
+                store.clear()
 
             def step_logits(tok, p):                                 # noqa: F811  (replaces the eager step)
                 tok_buf.copy_(tok)

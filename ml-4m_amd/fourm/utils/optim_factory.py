@@ -78,16 +78,28 @@ class FusedAdamW(optim.AdamW):
                             f"{'contiguous' if g.is_contiguous() else 'strided'} on {g.device}; fp32 contiguous expected")
 
     # -- hipGraph support -----------------------------------------------------------------------
-    def enable_device_hyper(self, device):
+    def enable_device_hyper(self, device, slots: int = 8):
+        """Device block + a RING of pinned staging buffers: ``advance_host_state`` only enqueues an asynchronous copy, and the host
+        may run several replays ahead of the GPU - a single staging buffer would be overwritten with step k+1's values before step
+        k's copy has executed.  A slot is reused only after the copy that last read it has run (event), i.e. the host blocks only
+        when it is more than ``slots`` steps ahead."""
         n = len(self.param_groups)
         self._hyper_dev = torch.zeros(n, 4, dtype=torch.float32, device=device)
-        self._hyper_host = torch.zeros(n, 4, dtype=torch.float32).pin_memory()
+        self._hyper_ring = [torch.zeros(n, 4, dtype=torch.float32).pin_memory() for _ in range(slots)]
+        self._hyper_events = [None] * slots
+        self._hyper_slot = 0
+        self._hyper_host = self._hyper_ring[0]          # (the values of the most recent step; kept for introspection)
 
     def advance_host_state(self):
         """What step() does on the host, for a step whose launches are replayed from a graph: step counters + the hyper block
-        (one 16-byte-per-group asynchronous copy on the current stream)."""
+        (one 16-byte-per-group asynchronous copy on the current stream, from the next slot of the staging ring)."""
         if self._hyper_dev is None:
             raise RuntimeError("enable_device_hyper() first")
+        i = self._hyper_slot
+        if self._hyper_events[i] is not None:
+            self._hyper_events[i].synchronize()         # the copy that last used this staging buffer has executed
+        host = self._hyper_ring[i]
+        host.copy_(self._hyper_host)                     # groups without a step this time keep their previous values
         for gi, g in enumerate(self.param_groups):
             step = None
             for p in g["params"]:
@@ -98,9 +110,14 @@ class FusedAdamW(optim.AdamW):
             if step is None:
                 continue
             b1, b2 = g["betas"]
-            self._hyper_host[gi, 0], self._hyper_host[gi, 1] = g["lr"], g["weight_decay"]
-            self._hyper_host[gi, 2], self._hyper_host[gi, 3] = 1.0 - b1 ** step, (1.0 - b2 ** step) ** 0.5
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+            host[gi, 0], host[gi, 1] = g["lr"], g["weight_decay"]
+            host[gi, 2], host[gi, 3] = 1.0 - b1 ** step, (1.0 - b2 ** step) ** 0.5
+        self._hyper_dev.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_events[i] = ev
+        self._hyper_host = host
+        self._hyper_slot = (i + 1) % len(self._hyper_ring)
 
     def _hyper(self, gi):
         """Device hyper block of group ``gi`` while a graph is being captured (eager steps pass the scalars themselves)."""

@@ -109,12 +109,16 @@ def vq_encode(vq, x):
     ops.gemm_nt(stream, vq.quant_proj.weight.detach().reshape(Ld, D), z, epilogue=L.EPI_F32, bias=vq.quant_proj.bias, M=R, N=Ld, K=D)
     cb = vq.quantize._codebook
     K = cb.embed.shape[0]
-    key = ("codes", cb.embed._version, cb.embed.data_ptr(), getattr(cb, "epoch", 0))
-    en = eng._cache.get(key)
-    if en is None:
-        en = torch.empty_like(cb.embed)
+    # ONE buffer of l2-normalised codes, recomputed in place when the codebook changed (in training mode every encode() moves the
+    # codebook: a cache keyed on its version would keep every past copy alive)
+    stamp = (cb.embed._version, cb.embed.data_ptr(), getattr(cb, "epoch", 0), tuple(cb.embed.shape))
+    slot = eng._cache.get("codes")
+    if slot is None or slot[0][1:] != stamp[1:] or slot[1].device != cb.embed.device:
+        slot = eng._cache["codes"] = [None, torch.empty_like(cb.embed)]
+    en = slot[1]
+    if slot[0] != stamp:
         L.check(L.l2norm_rows(ops._p(cb.embed), cb.embed.stride(0), ops._p(en), en.stride(0), K, Ld, ops._stream()))
-        eng._cache[key] = en
+        slot[0] = stamp
     splits = max(1, min(16, K // 1024))
     wv = ws.get("vq.wv", (R, splits), torch.float32)
     wi = ws.get("vq.wi", (R, splits), torch.int32)
