@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 2
+#define FM_ABI_VERSION 3
 int fm_abi_version(void);
 const char* fm_last_error(void);
 
@@ -114,6 +114,11 @@ int fm_get_tn_transpose_read(void);
  * D % 4 == 0, D <= 2048. */
 int fm_layernorm_fwd(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int y_is_f32,
                      void* mean, void* rstd, const int32_t* row_map, int R, int D, float eps, void* stream);
+/* The same with the residual add in front: row = x + delta (delta: bf16 (R, D), the output of the Linear that precedes the norm,
+ * fm_utils.py:332-333, 363-365); the sum is also written to x_out (f32, the new residual stream; may not alias x). */
+int fm_layernorm_fwd_res(const void* x, int ldx, const void* delta, int ldd, void* x_out, int ldxo, const void* w, const void* b,
+                         void* y, int ldy, int y_is_f32, void* mean, void* rstd, const int32_t* row_map, int R, int D, float eps,
+                         void* stream);
 /* dx(f32) = dres + LN'(dy);  dw += sum_r dy*xhat;  db += sum_r dy  (fp32 atomics; dw/db may be NULL).
  * dy: bf16, read at row dy_row_map[r] when a map is given (negative = zero gradient).
  * dres (optional, may alias dx) is the residual-stream gradient flowing around the norm.
@@ -288,6 +293,8 @@ int fm_colsum(const void* dy, int ldy, void* db, int R, int N, void* stream);   
 int fm_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream);
 /* dst(f32)[i] = scale * src(bf16)[i]: unpacks a gradient bucket that travelled in bf16 (optional wire format of the exchange) */
 int fm_bf16_to_f32_scaled(const void* src, void* dst, int64_t n, float scale, void* stream);
+/* out = x + delta over n contiguous elements (x, out f32; delta bf16): the residual add of fm_utils.py:332-333 on its own */
+int fm_add_bf16_f32(const void* x, const void* delta, void* out, int64_t n, void* stream);
 /* torch.optim.AdamW update on a contiguous fp32 range (fourm/utils/optim_factory.py:239-240);
  * grad_mult: optional device scalar multiplied into the gradient (clipping).
  * hyper: optional DEVICE float[4] = {lr, weight_decay, 1 - beta1^step, sqrt(1 - beta2^step)} that overrides the scalar arguments:

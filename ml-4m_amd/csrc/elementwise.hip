@@ -342,6 +342,16 @@ __global__ __launch_bounds__(256) void bf16_to_f32_scaled_kernel(const bf16_t* _
     }
 }
 
+// out = x + float(delta): the residual add of a bf16 Linear output onto the fp32 stream (what fm_layernorm_fwd_res does on the way)
+__global__ __launch_bounds__(256) void add_bf16_f32_kernel(const float* __restrict__ x, const bf16_t* __restrict__ d, float* __restrict__ out, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+        const float4 a = *(const float4*)(x + i);
+        const uint2 p = *(const uint2*)(d + i);
+        *(float4*)(out + i) = make_float4(a.x + bf2f((bf16_t)(p.x & 0xffff)), a.y + bf2f((bf16_t)(p.x >> 16)),
+                                          a.z + bf2f((bf16_t)(p.y & 0xffff)), a.w + bf2f((bf16_t)(p.y >> 16)));
+    }
+}
+
 inline int grid_for(size_t work_items) {
     size_t g = (work_items + 255) / 256;
     if (g > 256 * 8) g = 256 * 8;
@@ -445,6 +455,15 @@ extern "C" int fm_bf16_to_f32_scaled(const void* src, void* dst, int64_t n, floa
     hipLaunchKernelGGL(bf16_to_f32_scaled_kernel, dim3(grid_for((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
                        (float*)dst, (size_t)n, scale);
     FM_CHECK_LAUNCH("fm_bf16_to_f32_scaled");
+    return 0;
+}
+
+extern "C" int fm_add_bf16_f32(const void* x, const void* delta, void* out, int64_t n, void* stream) {
+    FM_CHECK_ARG(x && delta && out && n > 0 && n % 4 == 0 && ((((uintptr_t)x | (uintptr_t)out) & 15) == 0) && (((uintptr_t)delta) & 7) == 0,
+                 "fm_add_bf16_f32: n must be a multiple of 4, x / out 16-byte and delta 8-byte aligned");
+    hipLaunchKernelGGL(add_bf16_f32_kernel, dim3(grid_for((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const bf16_t*)delta,
+                       (float*)out, (size_t)n);
+    FM_CHECK_LAUNCH("fm_add_bf16_f32");
     return 0;
 }
 

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     constexpr int NMF = FW * FX;                                    // MFMAs per k-step
     // stores per wave and tile (16 bytes per lane each)
-    constexpr int NST = EPI == EPI_BF16 ? FW * FX * 2 : EPI == EPI_SWIGLU ? FX * (FW / 2) * 2 * 3 : FW * FX * 4;
+    constexpr int NST = EPI == EPI_BF16 ? FW * FX * 2 : EPI == EPI_SWIGLU ? FX * (FW / 2) * 2 * 3 : EPI == EPI_SWIGLU_BWD ? 60 : FW * FX * 4;
     static_assert(TW % (RPP * NWAVES) == 0, "tile rows must split evenly over the DMA pieces");
     static_assert(EPI != EPI_SWIGLU || FW % 2 == 0, "SwiGLU needs (g,u) fragment pairs per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,6 +184,67 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
                     for (int e = 0; e < 4; ++e) o[e] += bfround(acc[i][j][4 * g + e]);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), rs_out, (c < N ? rowoff : OOB) + (uint32_t)c * 4u, 0, 0);
                 }
+            }
+        } else if constexpr (EPI == EPI_SWIGLU_BWD) {
+            // acc = d(act); res = saved (g | u) (bf16, width 2 * Hp); out = (dg | du) (bf16): the activation backward of GatedMlp
+            // (fm_utils.py:142-144) on registers - d(act) never reaches HBM.  Same arithmetic as fm_swiglu_bwd (bit-identical).
+            // The saved values of one fragment are requested while the previous one is computed and stored.
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
+            const __amdgpu_buffer_rsrc_t rs_gu = rsrc_of((const char*)a.res + (size_t)m0 * a.ldr * 2);
+            const int c0 = n0 + ww * (TW / WW) + 8 * fhi;                       // this lane's first column (chunk 0 of a 16-column pair)
+            u32x4_t sv[2][2];                                                   // [parity][g, u] of one 16-column pair of one fragment
+            constexpr int NU = FW * FX * 2;                                     // units: (fragment, 16-column pair)
+            auto src_off = [&](int unit, int ld) __attribute__((always_inline)) {
+                const int f = unit / 2, gp = unit % 2, j = f / FW, i = f % FW;
+                const int rl = wx * (TX / WX) + j * 32 + frow;
+                const int c = c0 + i * 32 + 16 * gp;
+                return ((m0 + rl < a.M && c < N) ? 0u : OOB) | ((uint32_t)(rl * ld) * 2u + (uint32_t)c * 2u);
+            };
+            auto req = [&](int unit, int par) __attribute__((always_inline)) {
+                const uint32_t off = src_off(unit, a.ldr);
+                sv[par][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_gu, off, 0, 0);
+                sv[par][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_gu, off + (uint32_t)a.Hp * 2u, 0, 0);
+            };
+            req(0, 0);
+#pragma unroll
+            for (int unit = 0; unit < NU; ++unit) {
+                if (unit + 1 < NU) req(unit + 1, (unit + 1) & 1);
+                const int f = unit / 2, gp = unit % 2, j = f / FW, i = f % FW;
+                uint2 g2[2], u2[2], dg2[2], du2[2];
+                {   // each half-wave loaded 16 bytes = groups (2 gp, 2 gp + 1) of its rows: two swaps give every lane its 4 + 4 values
+                    const u32x4_t tg = sv[unit & 1][0], tu = sv[unit & 1][1];
+                    const auto gx = __builtin_amdgcn_permlane32_swap(tg[0], tg[2], false, false);
+                    const auto gy = __builtin_amdgcn_permlane32_swap(tg[1], tg[3], false, false);
+                    const auto ux = __builtin_amdgcn_permlane32_swap(tu[0], tu[2], false, false);
+                    const auto uy = __builtin_amdgcn_permlane32_swap(tu[1], tu[3], false, false);
+                    g2[0] = make_uint2(gx[0], gy[0]); g2[1] = make_uint2(gx[1], gy[1]);
+                    u2[0] = make_uint2(ux[0], uy[0]); u2[1] = make_uint2(ux[1], uy[1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int g = 2 * gp + u;
+                    float xv[4], uv[4], r1[4], r2[4];
+                    unpack_bf4(g2[u], xv); unpack_bf4(u2[u], uv);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = bfround(acc[i][j][4 * g + e]);
+                        const float sg = 1.0f / (1.0f + __expf(-xv[e]));
+                        const float sl = bfround(xv[e] * sg);
+                        const float ds = bfround(d * uv[e]);
+                        r2[e] = d * sl;
+                        r1[e] = ds * (sg * (1.0f + xv[e] * (1.0f - sg)));
+                    }
+                    dg2[u] = make_uint2(pack2bf(r1[0], r1[1]), pack2bf(r1[2], r1[3]));
+                    du2[u] = make_uint2(pack2bf(r2[0], r2[1]), pack2bf(r2[2], r2[3]));
+                }
+                const auto ax = __builtin_amdgcn_permlane32_swap(dg2[0].x, dg2[1].x, false, false);
+                const auto ay = __builtin_amdgcn_permlane32_swap(dg2[0].y, dg2[1].y, false, false);
+                const auto bx = __builtin_amdgcn_permlane32_swap(du2[0].x, du2[1].x, false, false);
+                const auto by = __builtin_amdgcn_permlane32_swap(du2[0].y, du2[1].y, false, false);
+                const u32x4_t vg = {ax[0], ay[0], ax[1], ay[1]}, vu = {bx[0], by[0], bx[1], by[1]};
+                const uint32_t off = src_off(unit, a.ldo);
+                __builtin_amdgcn_raw_buffer_store_b128(vg, rs_out, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(vu, rs_out, off + (uint32_t)a.Hp * 2u, 0, 0);
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
             const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
@@ -401,6 +462,11 @@ int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
         if (a.ldo % 4 != 0 || a.ldr % 4 != 0 || !a.res) return 0;
         if (!(a.lab & 16)) return use192 ? launch_nt3<192, EPI_RES, true>(a, s) : launch_nt3<256, EPI_RES, true>(a, s);
         return use192 ? launch_nt3<192, EPI_RES>(a, s) : launch_nt3<256, EPI_RES>(a, s);
+    }
+    if (epilogue == FM_EPI_SWIGLU_BWD) {
+        if (a.N % 16 != 0 || a.Hp % 8 != 0 || a.ldo % 8 != 0 || a.ldr % 8 != 0 || !a.res || a.Hp < a.N) return 0;
+        if ((size_t)256 * (size_t)a.ldr * 2 >= 0x7fffffffull) return 0;
+        return launch_nt3<256, EPI_SWIGLU_BWD, true>(a, s);
     }
     if (epilogue == FM_EPI_SWIGLU) {
         if (a.N % 64 != 0 || a.Hp % 8 != 0 || a.ldo % 8 != 0 || (a.out2 && a.ldo2 % 8 != 0) || !a.W2) return 0;

@@ -22,11 +22,16 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, f
     *(uint2*)p = make_uint2(pack2bf(a, b), pack2bf(c, d));
 }
 
-template <typename OutT, int MAXC>
+// RES: the row is x + delta (delta = the bf16 output of the Linear that precedes the norm in the residual stream, fm_utils.py:332-333,
+// 363-365); the sum is written to `xo` (the new residual stream, fp32) on the way.  This moves the residual add out of the GEMM
+// epilogue - where every workgroup of the chip reads and rewrites its fp32 tile at the same moment, at ~2.8 TB/s - into this
+// streaming kernel (5.5 TB/s): same bytes, same arithmetic (x + float(bf16)), bit-identical stream.
+template <typename OutT, int MAXC, bool RES = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ b, OutT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
-                                                     const int* __restrict__ row_map, int R, int D, float eps) {
+                                                     const int* __restrict__ row_map, int R, int D, float eps,
+                                                     const bf16_t* __restrict__ delta = nullptr, int ldd = 0, float* __restrict__ xo = nullptr, int ldxo = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
     // weights once per wave; two rows per iteration with both rows' loads issued first (HBM stream: more bytes in flight)
@@ -47,6 +52,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             for (int c = 0; c < MAXC; ++c) {
                 const int ch = lane + 64 * c;
                 v[q][c] = (ch < nch && r < R) ? *(const float4*)(x + (size_t)r * ldx + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if constexpr (RES) {
+            uint2 dl[NR][MAXC];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int r = r0 + q * gridDim.x * 4;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int ch = lane + 64 * c;
+                    dl[q][c] = (ch < nch && r < R) ? *(const uint2*)(delta + (size_t)r * ldd + ch * 4) : make_uint2(0u, 0u);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int r = r0 + q * gridDim.x * 4;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int ch = lane + 64 * c;
+                    float d4[4];
+                    unpack_bf4(dl[q][c], d4);
+                    v[q][c].x += d4[0]; v[q][c].y += d4[1]; v[q][c].z += d4[2]; v[q][c].w += d4[3];
+                    if (ch < nch && r < R) *(float4*)(xo + (size_t)r * ldxo + ch * 4) = v[q][c];
+                }
             }
         }
 #pragma unroll
@@ -291,6 +320,32 @@ extern "C" int fm_layernorm_fwd(const void* x, int ldx, const void* w, const voi
 #undef LN_FWD_C
 #undef LN_FWD
     FM_CHECK_LAUNCH("fm_layernorm_fwd");
+    return 0;
+}
+
+extern "C" int fm_layernorm_fwd_res(const void* x, int ldx, const void* delta, int ldd, void* x_out, int ldxo, const void* w, const void* b,
+                                    void* y, int ldy, int y_is_f32, void* mean, void* rstd, const int32_t* row_map, int R, int D, float eps,
+                                    void* stream) {
+    FM_CHECK_ARG(x && delta && x_out && w && y, "fm_layernorm_fwd_res: null pointer");
+    FM_CHECK_ARG(R > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC_LIMIT, "fm_layernorm_fwd_res: D=%d must be a multiple of 4 and <= %d", D, 64 * 4 * MAXC_LIMIT);
+    FM_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldd % 4 == 0 && ldxo % 4 == 0, "fm_layernorm_fwd_res: leading dims must be multiples of 4");
+    FM_CHECK_ARG((((uintptr_t)delta) & 7) == 0 && (((uintptr_t)x_out | (uintptr_t)x) & 15) == 0, "fm_layernorm_fwd_res: alignment (delta 8 B, x / x_out 16 B)");
+    int grid = (R + 3) / 4;
+    if (grid > 256 * 16) grid = 256 * 16;
+#define LN_FWD(T, C)                                                                                                        \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, C, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)w, \
+                       (const float*)b, (T*)y, ldy, (float*)mean, (float*)rstd, row_map, R, D, eps, (const bf16_t*)delta, ldd, (float*)x_out, ldxo)
+#define LN_FWD_C(T)                                    \
+    switch (chunks_for(D)) {                           \
+        case 2: LN_FWD(T, 2); break;                   \
+        case 3: LN_FWD(T, 3); break;                   \
+        case 4: LN_FWD(T, 4); break;                   \
+        default: LN_FWD(T, 8); break;                  \
+    }
+    if (y_is_f32) { LN_FWD_C(float) } else { LN_FWD_C(bf16_t) }
+#undef LN_FWD_C
+#undef LN_FWD
+    FM_CHECK_LAUNCH("fm_layernorm_fwd_res");
     return 0;
 }
 

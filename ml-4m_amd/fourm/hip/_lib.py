@@ -26,7 +26,7 @@ def _load():
 lib = _load()
 lib.fm_last_error.restype = C.c_char_p
 lib.fm_abi_version.restype = C.c_int
-ABI_VERSION = 2
+ABI_VERSION = 3
 if lib.fm_abi_version() != ABI_VERSION:
     raise FourmHipUnavailable(f"libfourm_hip.so ABI {lib.fm_abi_version()} != expected {ABI_VERSION}; rebuild")
 
@@ -132,6 +132,7 @@ gemm_nt = _sig("fm_gemm_nt", P(GemmNTArgs), vp)
 gemm_tn = _sig("fm_gemm_tn", P(GemmTNArgs), vp)
 gemm_tn_multi = _sig("fm_gemm_tn_multi", P(GemmTNJob), C.c_int, vp)
 layernorm_fwd = _sig("fm_layernorm_fwd", vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, f32, vp)
+layernorm_fwd_res = _sig("fm_layernorm_fwd_res", vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, f32, vp)
 layernorm_bwd = _sig("fm_layernorm_bwd", vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, vp)
 attn_fwd = _sig("fm_attn_fwd", P(AttnArgs), vp)
 attn_bwd = _sig("fm_attn_bwd", P(AttnArgs), vp)
@@ -151,6 +152,7 @@ headnorm_fwd = _sig("fm_headnorm_fwd", vp, i32, vp, vp, vp, i32, vp, i32, i32, C
 headnorm_bwd = _sig("fm_headnorm_bwd", vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp)
 f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
 bf16_to_f32_scaled = _sig("fm_bf16_to_f32_scaled", vp, vp, i64, f32, vp)
+add_bf16_f32 = _sig("fm_add_bf16_f32", vp, vp, vp, i64, vp)
 lib.fm_set_reserved_cus.argtypes = [C.c_int]
 lib.fm_get_reserved_cus.restype = C.c_int
 lib.fm_get_reserved_cus.argtypes = []
@@ -187,8 +189,8 @@ unpack_image_u8 = _sig("fm_unpack_image_u8", vp, vp, i32, i32, i32, i32, P(C.c_f
 unpack_ids_u16 = _sig("fm_unpack_ids_u16", vp, vp, i64, vp)
 unpack_mask_bits = _sig("fm_unpack_mask_bits", vp, vp, i32, i32, vp)
 decoder_attention_from_target = _sig("fm_decoder_attention_from_target", vp, vp, i32, i32, vp)
-EXPORTS = ["fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
-           "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
+EXPORTS = ["fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_add_bf16_f32", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
+           "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_fwd_res", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
            "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_colsum", "fm_f32_to_bf16", "fm_adamw", "fm_adamw_shadow",

@@ -29,6 +29,10 @@ from . import ops
 _WEIGHT_EPOCH = 0
 # run the activation backward inside the fc2 dX GEMM epilogue (bit-identical; measured slightly slower, see _mlp_bwd)
 FUSE_ACT_BWD = os.environ.get("FOURM_FUSE_ACT_BWD", "0") == "1"
+# The residual add behind attn.proj / cross_attn.proj / mlp.fc2 runs in the LayerNorm that follows (fm_layernorm_fwd_res) instead of the
+# GEMM epilogue: the GEMM becomes a plain bf16 launch (the lock-step kernel), the fp32 read-modify-write of the stream moves from an
+# epilogue all workgroups enter together (~2.8 TB/s) into a streaming kernel (5.5 TB/s).  Bit-identical.  FOURM_DEFER_RESIDUAL=0: fused.
+DEFER_RESIDUAL = os.environ.get("FOURM_DEFER_RESIDUAL", "1") == "1"
 
 
 def bump_weight_epoch():
@@ -157,6 +161,7 @@ class FourMEngine:
         self._slices = {}
         self._ctx = None           # saved state of the last training forward
         self._dw_jobs = None       # weight-gradient GEMMs queued by the running block backward (None: launch each at once)
+        self._pending = None       # (stream buffer still to be written, residual input, bf16 delta): see _residual / _ln
         self.reducer = None        # fourm.parallel.GradReducer when gradients are exchanged (data parallel)
 
     # ------------------------------------------------------------------------------------------
@@ -460,8 +465,31 @@ class FourMEngine:
             mean = self.ws.get(f"{tag}.{key}.mu", (x.shape[0],), torch.float32)
             rstd = self.ws.get(f"{tag}.{key}.rs", (x.shape[0],), torch.float32)
             sv[key + ".mu"], sv[key + ".rs"] = mean, rstd
+        pend = self._pending
+        if pend is not None and pend[0] is x:      # x = residual + delta is still owed: this norm computes and stores it on the way
+            self._pending = None
+            ops.layernorm_fwd(pend[1], norm.weight, norm.bias, y, mean, rstd, row_map=row_map, eps=norm.eps, R=R, delta=pend[2], x_out=x)
+            return y
+        self._settle()
         ops.layernorm_fwd(x, norm.weight, norm.bias, y, mean, rstd, row_map=row_map, eps=norm.eps, R=R)
         return y
+
+    def _residual(self, a, lin, x_res, x_out, R, N, K, defer):
+        """x_out = x_res + a W^T (+ bias): fused in the GEMM epilogue, or (defer) a bf16 GEMM whose sum is owed to the next _ln(x_out)."""
+        if defer and DEFER_RESIDUAL and not self.fp32:
+            self._settle()
+            delta = self.ws.get("fwd.delta", (x_out.shape[0], N), self.adt)
+            ops.gemm_nt(a, self.w(lin.weight), delta, bias=lin.bias, M=R, N=N, K=K)
+            self._pending = (x_out, x_res, delta, R)
+        else:
+            ops.gemm_nt(a, self.w(lin.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=lin.bias, M=R, N=N, K=K)
+
+    def _settle(self):
+        """A deferred residual sum nobody normalised (a caller outside the trunk loops wants the stream itself): write it now."""
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            x_out, x_res, delta, R = pend
+            ops.add_bf16_to_f32(x_res, delta, x_out, R)
 
     def _buf(self, sv, tag, key, shape, dtype):
         """Per-layer buffer when saving for backward, shared scratch otherwise."""
@@ -471,7 +499,7 @@ class FourMEngine:
             sv[key] = t
         return t
 
-    def _mlp_fwd(self, mlp, h, x_res, x_out, R, Rp, sv, tag):
+    def _mlp_fwd(self, mlp, h, x_res, x_out, R, Rp, sv, tag, defer=False):
         bf = self.adt
         if self.gated:
             gu = self._buf(sv, tag, "gu", (Rp, 2 * self.Hp), bf) if sv is not None else None       # inference: nothing to save
@@ -482,7 +510,7 @@ class FourMEngine:
             pre = self._buf(sv, tag, "pre", (Rp, self.Hp), bf) if sv is not None else None     # inference: nothing to save
             act = self._buf(sv, tag, "act", (Rp, self.Hp), bf)
             ops.gemm_nt(h, self.w(mlp.fc1.weight), act, epilogue=L.EPI_GELU, out2=pre, bias=mlp.fc1.bias, M=R, N=self.Hd, K=self.D)
-        ops.gemm_nt(act, self.w(mlp.fc2.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=mlp.fc2.bias, M=R, N=self.D, K=self.Hp)
+        self._residual(act, mlp.fc2, x_res, x_out, R, self.D, self.Hp, defer)
 
     def _qk_norm_fwd(self, attn, q, k, Rq, Rk, Rqp, Rkp, sv, tag, key):
         """q_norm / k_norm of NormAttention / NormCrossAttention: bf16 q, k -> normalised bf16 copies + (mean, rstd)."""
@@ -514,7 +542,7 @@ class FourMEngine:
             sm = self._buf(sv, tag, "sm", (B, self.H, N), torch.float32)
             sl = self._buf(sv, tag, "sl", (B, self.H, N), torch.float32)
         ops.attn_fwd(q_in, k_in, qkv[:, 2 * D:], o, B, self.H, N, N, self.scale, stat_m=sm, stat_l=sl, **mask)
-        ops.gemm_nt(o, self.w(attn.proj.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=attn.proj.bias, M=R, N=D, K=D)
+        self._residual(o, attn.proj, x_res, x_out, R, D, D, defer=True)       # (every caller normalises x_out next)
 
     def _cross_attn_fwd(self, attn, hq, hc, x_res, x_out, B, M, N, Rq, Rqp, Rc, Rcp, mask, sv, tag):
         bf, D = self.adt, self.D
@@ -531,10 +559,11 @@ class FourMEngine:
         if self.qk_norm:
             q_in, k_in = self._qk_norm_fwd(attn, q_in, k_in, Rq, Rc, Rqp, Rcp, sv, tag, "xqkn")
         ops.attn_fwd(q_in, k_in, kv[:, D:], o, B, self.H, M, N, self.scale, stat_m=sm, stat_l=sl, **mask)
-        ops.gemm_nt(o, self.w(attn.proj.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=attn.proj.bias, M=Rq, N=D, K=D)
+        self._residual(o, attn.proj, x_res, x_out, Rq, D, D, defer=True)
 
-    def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag):
-        """x_in (Rp, D) f32 -> new (Rp, D) f32 buffer.  [upstream Block.forward, fm_utils.py:331-334]"""
+    def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag, defer_out=False):
+        """x_in (Rp, D) f32 -> new (Rp, D) f32 buffer.  [upstream Block.forward, fm_utils.py:331-334]
+        defer_out (trunk loops only): the block's last residual sum is left to the LayerNorm that consumes the returned buffer next."""
         R, Rp, D = B * N, x_in.shape[0], self.D
         bf, f32 = self.adt, torch.float32
         h1 = self._ln(blk.norm1, x_in, self._buf(sv, tag, "h1", (Rp, D), bf), R, sv, "n1", tag)
@@ -542,12 +571,12 @@ class FourMEngine:
         self._self_attn_fwd(blk.attn, h1, x_in, x_mid, B, N, R, Rp, mask, sv, tag)
         h2 = self._ln(blk.norm2, x_mid, self._buf(sv, tag, "h2", (Rp, D), bf), R, sv, "n2", tag)
         x_out = self.ws.get(tag + ".x_out", (Rp, D), f32) if sv is not None else self.ws.get("scratch.x_out" + tag[-1:], (Rp, D), f32)
-        self._mlp_fwd(blk.mlp, h2, x_mid, x_out, R, Rp, sv, tag)
+        self._mlp_fwd(blk.mlp, h2, x_mid, x_out, R, Rp, sv, tag, defer=defer_out)
         if sv is not None:
             sv["x_in"] = x_in
         return x_out
 
-    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag):
+    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag, defer_out=False):
         """[upstream DecoderBlock.forward, fm_utils.py:362-366]"""
         Rq, Rqp, Rc, Rcp, D = B * M, y_in.shape[0], B * N, ctx.shape[0], self.D
         bf, f32 = self.adt, torch.float32
@@ -560,7 +589,7 @@ class FourMEngine:
         self._cross_attn_fwd(blk.cross_attn, hq, hc, y1, y2, B, M, N, Rq, Rqp, Rc, Rcp, xa_mask, sv, tag)
         h2 = self._ln(blk.norm2, y2, self._buf(sv, tag, "h2", (Rqp, D), bf), Rq, sv, "n2", tag)
         y_out = self.ws.get(tag + ".y_out", (Rqp, D), f32) if sv is not None else self.ws.get("scratch.y_out" + tag[-1:], (Rqp, D), f32)
-        self._mlp_fwd(blk.mlp, h2, y2, y_out, Rq, Rqp, sv, tag)
+        self._mlp_fwd(blk.mlp, h2, y2, y_out, Rq, Rqp, sv, tag, defer=defer_out)
         if sv is not None:
             sv["y_in"] = y_in
         return y_out
@@ -591,7 +620,7 @@ class FourMEngine:
         x = enc["x0"]
         for i, blk in enumerate(m.encoder):
             sv = {} if save else None
-            x = self.encoder_block_fwd(blk, x, B, N, emask, sv, f"enc{i}" if save else f"enc{i % 2}")
+            x = self.encoder_block_fwd(blk, x, B, N, emask, sv, f"enc{i}" if save else f"enc{i % 2}", defer_out=True)   # next: norm1 / encoder_norm
             if save:
                 st["enc_layers"].append(sv)
         R, Rp, D = B * N, x.shape[0], self.D
@@ -613,7 +642,8 @@ class FourMEngine:
         smask = self.decoder_mask(dec["cs"], dec["mod_pre"]) if "cs" in dec else dec["sa_mask"]
         for i, blk in enumerate(m.decoder):
             sv = {} if save else None
-            y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, sv, f"dec{i}" if save else f"dec{i % 2}")
+            y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, sv, f"dec{i}" if save else f"dec{i % 2}",
+                                       defer_out=i + 1 < len(m.decoder))           # next: the following block's norm1
             if save:
                 st["dec_layers"].append(sv)
         if save:

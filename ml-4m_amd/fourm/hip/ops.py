@@ -204,8 +204,14 @@ def make_groups(entries, device):
 # ---------------------------------------------------------------------------------------------
 # LayerNorm
 # ---------------------------------------------------------------------------------------------
-def layernorm_fwd(x, w, b, y, mean=None, rstd=None, row_map=None, eps=1e-6, R=None):
+def layernorm_fwd(x, w, b, y, mean=None, rstd=None, row_map=None, eps=1e-6, R=None, delta=None, x_out=None):
+    """y = LN(x) - or, with ``delta`` (bf16) and ``x_out`` (f32): x_out = x + delta, y = LN(x_out) in one pass."""
     R = x.shape[0] if R is None else R
+    if delta is not None:
+        with _prof("layernorm_fwd", 0.0, R * w.numel() * (10 + y.element_size())):
+            L.check(L.layernorm_fwd_res(_p(x), _ld(x), _p(delta), _ld(delta), _p(x_out), _ld(x_out), _p(w), _p(b), _p(y), _ld(y),
+                                        1 if y.dtype == torch.float32 else 0, _p(mean), _p(rstd), _p(row_map), R, w.numel(), eps, _stream()))
+        return y
     with _prof("layernorm_fwd", 0.0, R * w.numel() * (4 + y.element_size())):
         return _ln_fwd(x, w, b, y, mean, rstd, row_map, eps, R)
 
@@ -379,6 +385,14 @@ def f32_to_bf16(src, dst):
 def bf16_to_f32_scaled(src, dst, scale=1.0):
     L.check(L.bf16_to_f32_scaled(_p(src), _p(dst), src.numel(), float(scale), _stream()))
     return dst
+
+
+def add_bf16_to_f32(x, delta, out, R=None):
+    """out[:R] = x[:R] + delta[:R] (contiguous (rows, D) buffers of equal width)."""
+    R = x.shape[0] if R is None else R
+    assert x.is_contiguous() and delta.is_contiguous() and out.is_contiguous() and x.shape[1] == delta.shape[1] == out.shape[1]
+    L.check(L.add_bf16_f32(_p(x), _p(delta), _p(out), R * x.shape[1], _stream()))
+    return out
 
 
 def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None):

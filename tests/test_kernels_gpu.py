@@ -426,6 +426,36 @@ def test_layernorm(R, D):
     assert rel_err(acc, xr.grad + dres) < 1e-5
 
 
+@pytest.mark.parametrize("R,D", [(300, 768), (129, 1024), (64, 384), (17, 2048)])
+def test_layernorm_with_residual_add(R, D):
+    """fm_layernorm_fwd_res: x_out = x + delta (bf16) and y = LN(x_out) in one pass - bit-identical to the residual epilogue's sum
+    followed by fm_layernorm_fwd (the engine moves the add from the GEMM epilogue into the norm); row_map honoured; fm_add_bf16_f32."""
+    ops, L = _ops()
+    x = randn(R, D, seed=40) * 2 + 0.5
+    delta = bf(randn(R, D, seed=41))
+    w, b = randn(D, seed=42) * 0.2 + 1, randn(D, seed=43) * 0.1
+    xo = torch.full((R, D), 7.0, device=DEV)
+    y = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.zeros(R, device=DEV), torch.zeros(R, device=DEV)
+    ops.layernorm_fwd(x, w, b, y, mean, rstd, delta=delta, x_out=xo)
+    want = x + delta.float()
+    assert torch.equal(xo, want)
+    y2 = torch.zeros_like(y); m2, r2 = torch.zeros_like(mean), torch.zeros_like(rstd)
+    ops.layernorm_fwd(want, w, b, y2, m2, r2)
+    assert torch.equal(y, y2) and torch.equal(mean, m2) and torch.equal(rstd, r2)
+    out = torch.zeros(R, D, device=DEV)
+    ops.add_bf16_to_f32(x, delta, out)
+    assert torch.equal(out, want)
+    # scattered rows (the decoder norm writes into the head-segmented layout)
+    perm = torch.randperm(R, device=DEV).int()
+    perm[::7] = -1
+    ys = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    ops.layernorm_fwd(x, w, None, ys, row_map=perm, delta=delta, x_out=xo)
+    yr = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    ops.layernorm_fwd(want, w, None, yr, row_map=perm)
+    assert torch.equal(ys, yr)
+
+
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------

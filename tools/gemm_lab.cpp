@@ -62,24 +62,24 @@ int main(int argc, char** argv) {
                           {"dX fc2   N2048 K768 ", 2048, 768, FM_EPI_BF16}, {"kv       N1536 K768 ", 1536, 768, FM_EPI_BF16},
                           {"dX fc13  N768  K4096", 768, 4096, FM_EPI_BF16}, {"dX qkv   N768  K2304", 768, 2304, FM_EPI_BF16},
                           {"fc2+res  N768  K2048", 768, 2048, FM_EPI_RESIDUAL}, {"proj+res N768  K768 ", 768, 768, FM_EPI_RESIDUAL},
-                          {"swiglu   N2x2048 K768", 2048, 768, FM_EPI_SWIGLU}};
+                          {"swiglu   N2x2048 K768", 2048, 768, FM_EPI_SWIGLU}, {"fc2dX+act' N2048 K768", 2048, 768, FM_EPI_SWIGLU_BWD}};
         double tot[32] = {0};
-        const double per_step[] = {24, 61, 24, 12, 24, 24, 24, 38, 24};       // launches per 4M-B train step (profiles/r01_v10_shape_table.txt)
+        const double per_step[] = {24, 61, 24, 12, 24, 24, 24, 38, 24, 0};       // launches per 4M-B train step (profiles/r01_v10_shape_table.txt)
         int ci = 0;
         for (auto& c : cases) {
             void* W = dev_rand_bf16((size_t)c.N * c.K, 1), *W2 = dev_rand_bf16((size_t)c.N * c.K, 2), *X = dev_rand_bf16((size_t)R * c.K, 3);
-            const bool f32out = c.epi == FM_EPI_RESIDUAL;
+            const bool f32out = c.epi == FM_EPI_RESIDUAL, actbwd = c.epi == FM_EPI_SWIGLU_BWD;
             const int two = c.epi == FM_EPI_SWIGLU ? 2 : 1;
-            void* out = dev_zero((size_t)R * c.N * (f32out ? 4 : 2));
+            void* out = dev_zero((size_t)R * c.N * (f32out ? 4 : actbwd ? 4 : 2));       // (dg | du) for the activation backward
             void* out2 = c.epi == FM_EPI_SWIGLU ? dev_zero((size_t)R * c.N * 2 * 2) : nullptr;
-            void* res = f32out ? dev_zero((size_t)R * c.N * 4) : nullptr;
+            void* res = f32out ? dev_zero((size_t)R * c.N * 4) : actbwd ? dev_rand_bf16((size_t)R * c.N * 2, 9, 2.0f) : nullptr;
             fm_gemm_nt_args a{};
             a.W = W; a.W2 = c.epi == FM_EPI_SWIGLU ? W2 : nullptr; a.X = X; a.out = out; a.out2 = out2; a.res = res;
-            a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.ldo2 = 2 * c.N; a.ldr = c.N; a.Hp = c.N; a.epilogue = c.epi;
+            a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = actbwd ? 2 * c.N : c.N; a.ldo2 = 2 * c.N; a.ldr = actbwd ? 2 * c.N : c.N; a.Hp = c.N; a.epilogue = c.epi;
             printf("%s |", c.name);
             std::vector<double> best(cfgs.size(), 1e30);
             {   // every configuration against the first one (bit patterns of the primary output)
-                const size_t nbytes = (size_t)R * c.N * (f32out ? 4 : 2);
+                const size_t nbytes = (size_t)R * c.N * ((f32out || actbwd) ? 4 : 2);
                 std::vector<uint16_t> ref(nbytes / 2), got(nbytes / 2);
                 set_cfg(cfgs[0]); CK(hipMemset(out, 0, nbytes)); fm_gemm_nt(&a, 0); CK(hipDeviceSynchronize());
                 CK(hipMemcpy(ref.data(), out, nbytes, hipMemcpyDeviceToHost));
