@@ -1177,6 +1177,10 @@ static int n_compute_units() {
     return avail >= 64 ? avail / 8 * 8 : n;
 }
 
+}  // namespace
+int fm_grid_cus() { return n_compute_units(); }      // (gemm_nt3.hip sizes its persistent grid with the same reservation)
+namespace {
+
 template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false, bool PERSIST = false>
 int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;

@@ -421,11 +421,7 @@ int launch_nt3(NTArgs a, hipStream_t s) {
     a.n_tiles_w = (a.N + NPT - 1) / NPT;
     a.n_tiles_x = (a.M + 255) / 256;
     int grid = a.n_tiles_w * a.n_tiles_x;
-    static int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return n / 8 * 8;
-    }();
+    const int cus = fm_grid_cus();
     if (grid > cus) grid = cus;
     const size_t lds = (size_t)2 * (TW + 256) * 128;
     auto k = gemm_nt3_kernel<TW, EPI, SPLIT>;

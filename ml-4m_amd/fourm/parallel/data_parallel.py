@@ -36,7 +36,8 @@ class GradReducer:
     force      run the collectives even at world size 1 (tests of the RCCL code path on one GPU)."""
 
     def __init__(self, flat: torch.Tensor, ranges_by_stage: Dict[str, Sequence[Tuple[int, int]]], group=None,
-                 bucket_elems: int = 64 * 1024 * 1024, algorithm: str = "all_reduce", wire_dtype=None, force: bool = False):
+                 bucket_elems: int = 64 * 1024 * 1024, algorithm: str = "all_reduce", wire_dtype=None, force: bool = False,
+                 min_launch_mb: float = 0.0):
         if algorithm not in ("all_reduce", "reduce_scatter"):
             raise ValueError(f"algorithm {algorithm!r}")
         if wire_dtype not in (None, torch.float32, torch.bfloat16):
@@ -53,6 +54,8 @@ class GradReducer:
                 raise ValueError("gradient ranges of different stages overlap")
         self._pending = []
         self._done = set()
+        self._waiting = []
+        self.min_launch_elems = int(min_launch_mb * 1024 * 1024 // 4)
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"          # RCCL averages in the collective; gloo has no AVG
         self._wire_bufs = {}                   # (offset, length) -> bf16 staging buffer, allocated once
@@ -76,7 +79,7 @@ class GradReducer:
         return split
 
     def begin(self):
-        self._pending, self._done = [], set()
+        self._pending, self._done, self._waiting = [], set(), []
 
     def _exchange(self, t: torch.Tensor, op):
         """Asynchronous collectives that leave the cross-rank reduction of ``t`` in ``t``; returns the work handles."""
@@ -93,12 +96,18 @@ class GradReducer:
             return works
         return [dist.all_reduce(t, op=op, group=self.group, async_op=True)]
 
-    def stage_done(self, stage: str):
-        """Gradients of ``stage`` are final on the compute stream: start their exchange."""
+    def stage_done(self, stage: str, flush: bool = False):
+        """Gradients of ``stage`` are final on the compute stream: start their exchange - once at least ``min_launch_elems`` elements
+        are waiting (a collective costs the host ~50-100 us whatever its size: ~28 stages x 1-3 ranges per 4M-B step would be +3 ms of
+        launch-side time, tools/overlap_dp.py; a few large messages are also what point-to-point xGMI links want)."""
         if (self.world == 1 and not self.force) or stage in self._done or stage not in self.stages:
             return
         self._done.add(stage)
-        for o, n in self.stages[stage]:
+        self._waiting = getattr(self, "_waiting", []) + list(self.stages[stage])
+        if not flush and sum(n for _, n in self._waiting) < self.min_launch_elems:
+            return
+        ranges, self._waiting = self._merge(self._waiting), []
+        for o, n in ranges:
             t = self.flat[o:o + n]
             if self.wire is not None:
                 from fourm.hip import ops
@@ -115,6 +124,10 @@ class GradReducer:
         """Launch whatever stage has not been reported, then wait for every collective."""
         for s in self.stages:
             self.stage_done(s)
+        if getattr(self, "_waiting", None):       # whatever is still below the launch threshold
+            self._done.discard("__flush__"); self.stages["__flush__"] = []
+            self.stage_done("__flush__", flush=True)
+            del self.stages["__flush__"]
         for works, t, w in self._pending:
             for work in works:
                 work.wait()
@@ -135,7 +148,7 @@ class DataParallel(nn.Module):
 
     def __init__(self, module: nn.Module, device_ids=None, find_unused_parameters: bool = False, process_group=None,
                  bucket_mb: int = 256, algorithm: str = "all_reduce", wire_dtype=None, reserved_cus: Optional[int] = None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, min_launch_mb: Optional[float] = None):
         """``reserved_cus``: compute units the persistent GEMM grids leave to RCCL while gradients are exchanged under the backward
         (env FOURM_DP_RESERVED_CUS).  Default 0: a persistent GEMM workgroup uses 512 of a CU's 2048 thread slots, <= 144 of 160 KB
         of LDS and ~400 of 512 VGPRs per SIMD, so RCCL's small workgroups can be co-resident on the same CUs; reserving whole CUs
@@ -148,17 +161,43 @@ class DataParallel(nn.Module):
         self._sync = True
         self._bucket_elems = bucket_mb * 1024 * 1024 // 4
         self._algorithm, self._wire, self._force = algorithm, wire_dtype, force_collectives
+        # launch a collective only when this much gradient is waiting (env FOURM_DP_MIN_LAUNCH_MB; default 192 MB: ~8 per 4M-B step)
+        self._min_launch_mb = float(os.environ.get("FOURM_DP_MIN_LAUNCH_MB", "192")) if min_launch_mb is None else float(min_launch_mb)
         if reserved_cus is None:
             reserved_cus = int(os.environ.get("FOURM_DP_RESERVED_CUS", "0"))
         self._reserved_cus = reserved_cus
         self._reducer: Optional[GradReducer] = None
         self._reducer_for = None
-        if dist.is_initialized() and dist.get_world_size(process_group) > 1:
-            with torch.no_grad():
-                for t in list(module.parameters()) + list(module.buffers()):
-                    dist.broadcast(t.data, src=0, group=process_group)
-            from fourm.hip.engine import bump_weight_epoch
-            bump_weight_epoch()
+        if dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force_collectives):
+            self.broadcast_from_rank0()
+
+    def broadcast_from_rank0(self):
+        """Replicas start from rank 0's weights (what DDP does at construction, run_training_4m.py:512) - as TWO collectives instead
+        of one per tensor (~360 for 4M-B): the engine's flat fp32 parameter store in one piece (large message: what reaches xGMI
+        link bandwidth), and every buffer / stray parameter packed into one staging tensor per dtype."""
+        module, group = self.module, self.process_group
+        from fourm.hip.engine import bump_weight_epoch
+        with torch.no_grad():
+            done = set()
+            eng = getattr(module, "engine", None) if any(p.is_cuda for p in module.parameters()) else None
+            if eng is not None:
+                eng._ensure_flat()
+                dist.broadcast(eng.flat_params, src=0, group=group)
+                lo, hi = eng.flat_params.data_ptr(), eng.flat_params.data_ptr() + eng.flat_params.numel() * 4
+                done = {id(p) for p in module.parameters() if lo <= p.data_ptr() < hi}
+            rest = [t for t in list(module.parameters()) + list(module.buffers()) if id(t) not in done]
+            by_type = {}
+            for t in rest:
+                by_type.setdefault((t.dtype, t.device), []).append(t)
+            for ts in by_type.values():
+                packed = torch.cat([t.detach().reshape(-1) for t in ts])
+                dist.broadcast(packed, src=0, group=group)
+                o = 0
+                for t in ts:
+                    t.data.copy_(packed[o:o + t.numel()].view_as(t))
+                    o += t.numel()
+            self.n_init_broadcasts = (1 if eng is not None else 0) + len(by_type)
+        bump_weight_epoch()
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -173,7 +212,7 @@ class DataParallel(nn.Module):
         eng._ensure_flat()
         if self._reducer is None or self._reducer_for is not eng.flat_grads:
             self._reducer = GradReducer(eng.flat_grads, eng.grad_stages(), self.process_group, self._bucket_elems,
-                                        algorithm=self._algorithm, wire_dtype=self._wire, force=self._force)
+                                        algorithm=self._algorithm, wire_dtype=self._wire, force=self._force, min_launch_mb=self._min_launch_mb)
             self._reducer_for = eng.flat_grads
             if eng.flat_grads.is_cuda and dist.get_backend(self.process_group) == "nccl":
                 from fourm.hip import _lib

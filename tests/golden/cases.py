@@ -57,6 +57,10 @@ CASES = {
     # BASELINE.json configs[1]: the benched model (4M-B mod7, 12+12 blocks, D=768, hidden 2048), batch 2 of the same
     # 128+128-token batches (the fixture keeps summaries only)
     "b_mod7": dict(cfg=lambda: O.named_cfg("base", O.mod7_specs()), B=2, N=128, M=128, bud=(128, 128), seed=4),
+    # the same model at the BENCHED row count: batch 256 = 32768 encoder + 32768 decoder rows (row padding, 256-row head segments,
+    # persistent tile walks, the dW tail cut all behave differently here than at batch 2).  Generated from the unmodified upstream
+    # model with its blocks wrapped in torch.utils.checkpoint (memory; same arithmetic); summaries only; the oracle is not run
+    "b_mod7_256": dict(cfg=lambda: O.named_cfg("base", O.mod7_specs()), B=256, N=128, M=128, bud=(128, 128), seed=8, big=True),
     # BASELINE.json configs[3]: 4M-L mod21 at FULL depth (24 + 24 blocks, D = 1024, hidden 2730, 19 input / 17 target modalities,
     # 256 + 256 tokens), batch 1 (the fixture keeps summaries only; 1.27 G parameters are regenerated from seeds)
     "l_mod21": dict(cfg=lambda: O.named_cfg("large", O.mod21_specs()), B=1, N=256, M=256, bud=(256, 256), seed=6,
@@ -74,7 +78,7 @@ def build_case(name: str):
     sd = O.seeded_state_dict(cfg, seed=seed, share_embedding=share, learned_pos=learned, norm_bias=nb)
     md = O.synthetic_mod_dict(cfg, c["B"], c["bud"][0], c["bud"][1], seed=seed, no_target=c.get("no_target", ()))
     return dict(cfg=cfg, sd=sd, mod_dict=md, N=c["N"], M=c["M"], loss_type=c.get("loss_type", "mod"),
-                order_seed=seed, share_embedding=share, norm_bias=nb, learned_pos=learned)
+                order_seed=seed, share_embedding=share, norm_bias=nb, learned_pos=learned, big=c.get("big", False))
 
 
 # VQ tokenizer front end (BASELINE.json configs[4] and a small variant)

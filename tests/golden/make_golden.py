@@ -99,6 +99,11 @@ def run_case(name: str, check_only: bool):
     ref_keys = list(model.state_dict().keys())
     assert sorted(ref_keys) == sorted(sd.keys()), "state_dict layout mismatch"
     model.train()
+    big = case.get("big", False)
+    if big:       # batch 256: recompute each block in the backward instead of keeping ~70 GB of activations (identical arithmetic)
+        from torch.utils.checkpoint import checkpoint
+        for blk in list(model.encoder) + list(model.decoder):
+            blk.forward = (lambda f: (lambda *a, **k: checkpoint(f, *a, use_reentrant=False, **k)))(blk.forward)
 
     dec_names = [n for n in md if n in model.decoder_embeddings]
     order = dec_order_for_seed(dec_names, seed)
@@ -121,6 +126,9 @@ def run_case(name: str, check_only: bool):
     with torch.no_grad():
         logits = model(clone_mod_dict(md), N, M, return_logits=True)
 
+    if big:
+        _write(name, model, sd, md, order, ref_keys, cfg, e_tok, e_emb, e_mask, e_mod, d_tok, d_emb, d_mask, d_mod, d_tgt, d_attn, loss, mod_loss, logits, grads)
+        return
     # --- oracle on the same weights / inputs
     P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     # tied tensors must stay tied for gradient accumulation
@@ -166,7 +174,10 @@ def run_case(name: str, check_only: bool):
           f"max rel err: loss {errs['loss']:.1e} grads {gmax:.1e}")
     if check_only:
         return
+    _write(name, model, sd, md, order, ref_keys, cfg, e_tok, e_emb, e_mask, e_mod, d_tok, d_emb, d_mask, d_mod, d_tgt, d_attn, loss, mod_loss, logits, grads)
 
+
+def _write(name, model, sd, md, order, ref_keys, cfg, e_tok, e_emb, e_mask, e_mod, d_tok, d_emb, d_mask, d_mod, d_tgt, d_attn, loss, mod_loss, logits, grads):
     out = {
         "meta/order": np.array(order), "meta/keys": np.array(ref_keys),
         "meta/shapes": np.array([",".join(map(str, model.state_dict()[k].shape)) for k in ref_keys]),
