@@ -122,7 +122,7 @@ class LaunchProfiler:
 
 
 KERNEL_REGEX = {   # profiler family -> regex on the demangled kernel name (7th template argument of gemm_nt = epilogue)
-    "gemm_nt": r"gemm_nt_kernel<\d+, \d+, \d+, \d+, \d+, \d+, {epi}, false",
+    "gemm_nt": r"(gemm_nt3_kernel<\d+, {epi}, |gemm_nt_kernel<\d+, \d+, \d+, \d+, \d+, \d+, {epi}, false)",
     "gemm_tn": r"gemm_tn_kernel<\w+, false", "gemm_tn_multi": r"gemm_tn_multi_kernel", "attn_fwd": r"attn_fwd_kernel", "attn_bwd": r"attn_bwd_kernel",
     "layernorm_fwd": r"ln_fwd_kernel", "layernorm_bwd": r"ln_bwd_kernel",
 }
@@ -174,9 +174,22 @@ def cpu_baseline(timeout_s=300, workload="train"):
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:
-        return {"value": None, "unit": "tokens/s" if workload == "train" else "images/s", "cores": os.cpu_count(), "kind": "port",
+        return {"value": None, "unit": "images/s" if workload == "vq" else "tokens/s", "cores": os.cpu_count(), "kind": "port",
                 "reference_available": os.path.isdir(REFERENCE_TREE),
                 "sample": f"CPU leg did not finish within {timeout_s}s ({type(e).__name__})"}
+
+
+def extra_record(argv, timeout_s):
+    """One more workload as a sub-record of the headline line: this script re-run with ``argv`` in a child process."""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", *argv], capture_output=True, text=True, timeout=timeout_s)
+        rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        rec["wall_s"] = round(time.perf_counter() - t0, 1)
+        return rec
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300], "argv": argv, "wall_s": round(time.perf_counter() - t0, 1)}
 
 
 def _cpu_model_name():
@@ -242,6 +255,65 @@ def cpu_baseline_vq_worker(batch=8, steps=3):
             "reference_available": os.path.isdir(REFERENCE_TREE),
             "sample": f"oracle fp32 PyTorch port of VQ.encode (ViT-B/16 + 16384 x 32 cosine codebook), batch {batch} 224^2 images, median of "
                       f"{steps} passes after 1 warm-up, {t:.2f} s/batch", "cpu": _cpu_model_name()}
+
+
+def cpu_baseline_mod21_worker(batch=1, steps=2):
+    """BASELINE configs[3] on the host cores: the oracle port of 4M-L mod21 (24 + 24 blocks, 1.27 G parameters, 19 input / 17 target
+    modalities, 256 + 256 tokens), forward + backward + AdamW, batch 1.  (The unmodified upstream model where its tree exists.)"""
+    from oracle import fourm_oracle as O
+    threads = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = O.named_cfg("large", O.mod21_specs())
+    sd = O.seeded_state_dict(cfg, seed=0, learned_pos=O.MOD21_LEARNED_POS)
+    kind = "port"
+    md = O.synthetic_mod_dict(cfg, batch, 256, 256, seed=0)
+    if os.path.isdir(REFERENCE_TREE):
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import ref_stubs
+        ref_stubs.install()
+        sys.path[:] = [p for p in sys.path if os.path.abspath(p) != os.path.join(ROOT, "ml-4m_amd")]
+        for name in [n for n in sys.modules if n == "fourm" or n.startswith("fourm.")]:
+            del sys.modules[name]
+        sys.path.insert(0, REFERENCE_TREE)
+        from tests.golden.make_golden import upstream_model, clone_mod_dict
+        model = upstream_model(cfg, True, False, O.MOD21_LEARNED_POS)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+        kind = "reference"
+
+        def one():
+            loss, _ = model(clone_mod_dict(md), 256, 256)
+            loss.sum().backward()
+            opt.step(); opt.zero_grad()
+    else:
+        def is_buffer(k):
+            return ("pos_emb" in k and not any(k.startswith(f"{side}_embeddings.{m}.") for side in ("encoder", "decoder") for m in O.MOD21_LEARNED_POS)) \
+                or ("norm" in k and k.endswith(".bias"))
+        P = {k: v.clone().requires_grad_(v.is_floating_point() and not is_buffer(k)) for k, v in sd.items()}
+        for m in cfg.mods:
+            if m.in_enc and m.in_dec:
+                P[f"decoder_embeddings.{m.name}.mod_emb"] = P[f"encoder_embeddings.{m.name}.mod_emb"]
+            if m.in_dec:
+                P[f"decoder_embeddings.{m.name}.to_logits.weight"] = P[f"decoder_embeddings.{m.name}.token_emb.weight"]
+        leaves = list({id(v): v for v in P.values() if v.requires_grad}.values())
+        opt = torch.optim.AdamW(leaves, lr=1e-4, betas=(0.9, 0.95), weight_decay=0.05)
+        order = [m.name for m in cfg.mods if m.in_dec]
+
+        def one():
+            loss, _ = O.fourm_forward(P, cfg, md, 256, 256, order)
+            loss.sum().backward()
+            opt.step(); opt.zero_grad()
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        one()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": batch * 512 / t, "unit": "tokens/s", "cores": threads, "host_cores": os.cpu_count(), "kind": kind,
+            "reference_available": kind == "reference",
+            "sample": f"{'unmodified upstream FourM' if kind == 'reference' else 'oracle fp32 PyTorch port'}, 4M-L mod21, batch {batch}, 256+256 tokens, "
+                      f"fwd+bwd+AdamW, median of {steps} steps after 1 warm-up, {t:.2f} s/step", "cpu": _cpu_model_name()}
 
 
 def cpu_baseline_worker(batch=8, steps=3):
@@ -365,7 +437,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="train", choices=["train", "vq"], help="train = the headline 4M train step; vq = BASELINE "
+    ap.add_argument("--workload", default="train", choices=["train", "vq", "train21"], help="train = the headline 4M train step; vq = BASELINE "
                     "configs[4]: RGB VQ tokenizer (ViT-B/16, 224^2 -> 14 x 14 codes, 16384 x 32 codebook) encode + quantize, batch 64")
     ap.add_argument("--mods", default="mod7", choices=sorted(MODS), help="mod7 = BASELINE configs[1] (4M-B, batch 256, 128+128 tokens); "
                     "mod21 = configs[3] (4M-L, 19 / 17 modalities, batch 64, 256+256 tokens)")
@@ -377,10 +449,14 @@ def main():
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test hook: several ranks on one GPU)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
+    ap.add_argument("--no-extras", action="store_true", help="headline record only (default for non-default workloads): no extra.vq / extra.mod21 sub-records")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     a.user_batch = a.batch
+    # the sub-records of BASELINE configs[3] / [4] ride on the DEFAULT invocation only (N = 1, mod7, no size overrides)
+    a.extras = not a.no_extras and a.workload == "train" and a.mods == "mod7" and a.batch is None and a.model is None and not a.pmc_worker \
+        and not a.cpu_baseline_worker and a.gpus == 1 and a.dist_backend == "nccl" and not a.no_cpu_baseline
     dflt = {"mod7": ("fm_base_12e_12d_swiglu_nobias", 256, 128), "mod21": ("fm_large_24e_24d_swiglu_nobias", 64, 256)}[a.mods]
     a.model = a.model or dflt[0]
     a.batch = a.batch or dflt[1]
@@ -388,6 +464,8 @@ def main():
     if a.cpu_baseline_worker:
         if a.workload == "vq":
             print(json.dumps(cpu_baseline_vq_worker()))
+        elif a.workload == "train21":
+            print(json.dumps(cpu_baseline_mod21_worker()))
         elif os.path.isdir(REFERENCE_TREE):
             print(json.dumps(cpu_baseline_reference_worker()))
         else:
@@ -494,8 +572,9 @@ def main():
     if rank == 0 and not a.no_kernel_profile:
         agg = prof.summary()
         tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
-        symbol = {"gemm_nt": "gemm_nt_kernel<128,256,2,4,{{32|64}},3,EPI={epi},GROUPED=false,PP=true,PERSIST=true>  (csrc/gemm.hip; "
-                             "K-step 32 for K < 1536, 64 above)",
+        symbol = {"gemm_nt": "FAMILY of two template instantiations, gemm_nt3_kernel<TW=192|256, EPI={epi}, SPLIT=true>  (csrc/gemm_nt3.hip: lock-step "
+                             "256 x 256 / 192 x 256 tiles; 192-wide where N % 192 == 0 and 256-wide tiles would not fill whole rounds of 256 CUs) - every "
+                             "dense bf16 Linear of the trunk, forward and dX",
                   "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,64,3,PP=true>  (csrc/gemm.hip)",
                   "gemm_tn_multi": "gemm_tn_multi_kernel<MASKED=false>  (csrc/gemm.hip; all dW GEMMs of a layer per launch)",
                   "attn_fwd": "attn_fwd_kernel<true,MASK>", "attn_bwd": "attn_bwd_kernel<true,MASK>",
@@ -514,6 +593,14 @@ def main():
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, **common}
+        # the roofline entry above is a kernel FAMILY when it is gemm_nt; the largest SINGLE symbol of the step is the dW list kernel
+        if "gemm_tn_multi" in agg and agg["gemm_tn_multi"]["ms"] > 0:
+            t = agg["gemm_tn_multi"]
+            tf = t["flops"] / (t["ms"] * 1e-3) / 1e12
+            out["roofline"]["largest_single_symbol"] = {"kernel": symbol["gemm_tn_multi"], "ms_per_step": t["ms"] / 2, "launches_per_step": t["n"] // 2,
+                                                        "achieved": tf, "frac": tf / BF16_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        out["roofline"]["peak_note"] = ("peak = the dense bf16 MFMA figure of MI355X_MICROARCH.md (2.5 PFLOP/s at 2.4 GHz); on random bf16 operands the chip sustains "
+                                        "1.79-1.89 PFLOP/s at ~1.72 GHz (profiles/r03_ubench.txt): frac x 1.35 is the fraction of what a pure MFMA loop reaches")
         out["kernel_breakdown_ms_per_step"] = {k: round(v["ms"] / 2, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         out["kernel_tflops"] = {k: round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) for k, v in agg.items() if v["flops"] > 0 and v["ms"] > 0}
         if os.environ.get("BENCH_SHAPE_TABLE"):      # per-shape table of the timed launches (tuning aid), off the JSON line
@@ -521,9 +608,16 @@ def main():
                 f.write("\n".join(prof.shape_table(2)) + "\n")
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.mods == "mod7":
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
         print(json.dumps(out), file=sys.stderr)      # the GPU result is safe on stderr before the CPU leg starts
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(workload="train" if a.mods == "mod7" else "train21")
+    if rank == 0 and world == 1 and a.extras:
+        # BASELINE configs[4] and configs[3] on the same record (child processes, bounded; the headline keys above are not touched)
+        del model, opt, batches
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        out["extra"] = {"vq": extra_record(["--workload", "vq", "--steps", "10", "--warmup", "3"], 300),
+                        "mod21": extra_record(["--mods", "mod21", "--steps", "5", "--warmup", "2"], 600)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

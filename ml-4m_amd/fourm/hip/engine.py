@@ -127,6 +127,8 @@ def fill_mod_desc(md, d, emb, is_dec: bool, mod_id: int, head_index: int = 0, ra
 
 
 class FourMEngine:
+    _pending = None            # (engines built without this __init__ - the tokenizer's - start with no deferred residual)
+
     def __init__(self, model):
         from fourm.models.fm_utils import GatedMlp, NormAttention, act_name
         self.model = model
