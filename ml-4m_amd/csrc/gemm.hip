@@ -817,6 +817,7 @@ struct TNJob {
 struct TNMultiArgs {
     TNJob job[FM_TN_MAX_JOBS];
     int n_jobs, tiles, tail_rr, banded;
+    int hybrid;             // round-robin tails with rem > ntail: one whole tail per tail workgroup, the other rem - ntail tails walked by all of them
 };
 
 // TA = 128, KB = 64: 64 x 64 wave tiles, 144 KB of LDS;  TA = 256, KB = 32: 128 x 64 wave tiles (8 accumulators per wave), 96 KB - per MFMA
@@ -1103,13 +1104,18 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
     // Banded cut (contiguous mode): the first `rem` tail workgroups take ONE band [q, q + lb) of "their" tile each - they start
     // together on neighbouring tiles over the same rows, so they share operand panels in L2 like the mains - and only the remaining
     // ntail - rem workgroups walk what is left ([q + lb, kt) of every tile) as contiguous runs.
-    const int nband = a.banded ? rem : 0, nwalk = ntail - nband;
-    auto q2_of = [&](int j) { return a.job[j].q + (a.banded ? a.job[j].lb : 0); };
+    // Hybrid cut (round-robin mode with more tails than tail workgroups, e.g. a 4M-B decoder layer: 144 tiles, 112 tail workgroups):
+    // tail workgroup j takes the WHOLE tail of tile j (aligned with its neighbours, like the mains) and the tails of the other
+    // rem - ntail tiles are walked by ALL tail workgroups as contiguous runs - instead of 32 of them taking a second whole tail
+    // (makespan 691 k-tiles against a mean of 576).
+    const int nband = a.hybrid ? 0 : (a.banded ? rem : 0), nwalk = ntail - nband;
+    const int walk_T0 = a.hybrid ? T0 + ntail : T0;                         // first tile of the walked region
+    auto q2_of = [&](int j) { return a.job[j].q + ((a.banded && !a.hybrid) ? a.job[j].lb : 0); };
     long long u0 = 0, u1 = 0;
-    if (rem > 0 && w >= rem + nband && !a.tail_rr) {
+    if (rem > 0 && w >= rem + nband && (!a.tail_rr || a.hybrid)) {
         long long Lsum = 0;
         for (int j = 0; j < a.n_jobs; ++j) {
-            const int lo = max(a.job[j].tile_start, T0), hi = a.job[j].tile_start + a.job[j].tiles;
+            const int lo = max(a.job[j].tile_start, walk_T0), hi = a.job[j].tile_start + a.job[j].tiles;
             if (hi > lo) Lsum += (long long)(hi - lo) * (a.job[j].kt - q2_of(j));
         }
         u0 = Lsum * (w - rem - nband) / nwalk; u1 = Lsum * (w - rem - nband + 1) / nwalk;
@@ -1126,14 +1132,14 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
             tile = T0 + w; t1 = q_of(job_of(tile)); phase = 3; have = true;
         } else if (phase == 4) {
             tile = T0 + (w - rem); const int j = job_of(tile); t0 = q_of(j); t1 = t0 + a.job[j].lb; phase = 3; have = true;
-        } else if (phase == 2 && a.tail_rr) {
+        } else if (phase == 2 && a.tail_rr && !(a.hybrid && f > 0)) {
             const int sgm = (w - rem) + f * ntail;          // f counts this tail's segments here
             if (sgm >= rem) phase = 3;
             else { tile = T0 + sgm; const int j = job_of(tile); t0 = q_of(j); t1 = a.job[j].kt; ++f; have = true; }
-        } else if (phase == 2) {
+        } else if (phase == 2) {                            // (hybrid: after the one whole tail, this workgroup's share of the walk)
             if (tj >= a.n_jobs) phase = 3;
             else {
-                const int lo = max(a.job[tj].tile_start, T0), hi = a.job[tj].tile_start + a.job[tj].tiles;
+                const int lo = max(a.job[tj].tile_start, walk_T0), hi = a.job[tj].tile_start + a.job[tj].tiles;
                 const int q = q2_of(tj), left = a.job[tj].kt - q;
                 bool advance = true;
                 if (hi > lo && left > 0) {
@@ -1447,6 +1453,8 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         const double cb = ls ? 16.0 : 32.0;
         static const bool band_off = [] { const char* e = getenv("FOURM_TN_BANDS"); return e && atoi(e) == 0; }();
         a.banded = !a.tail_rr && rem > 0 && ntail > rem && !band_off;
+        static const bool hybrid_off = [] { const char* e = getenv("FOURM_TN_HYBRID"); return e && atoi(e) == 0; }();
+        a.hybrid = a.tail_rr && rem > ntail && ntail > 0 && !hybrid_off;
         for (int i = 0; i < n_jobs; ++i) {
             TNJob& j = a.job[i];
             j.lb = 0;
@@ -1459,7 +1467,10 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
                 j.q = j.lb = (int)q;
                 continue;
             }
-            if (a.tail_rr) {      // the busiest tail workgroup has n = ceil(rem / ntail) tails:  q + c = n (kt - q + c)
+            if (a.hybrid) {       // main: q + c;  tail: one whole tail + its share of the other rem - ntail:  (kt - q) rem / ntail + 2 c
+                const double r = (double)rem / ntail;
+                j.q = (int)((j.kt * r + c) / (1.0 + r));
+            } else if (a.tail_rr) {      // the busiest tail workgroup has n = ceil(rem / ntail) tails:  q + c = n (kt - q + c)
                 const int n = (rem + ntail - 1) / ntail;
                 double left = (j.kt - (n - 1) * c) / (n + 1.0);
                 j.q = j.kt - (left > 0 ? (int)left : 0);

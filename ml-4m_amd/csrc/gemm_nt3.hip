@@ -67,9 +67,22 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
     uint32_t woff[PW], xoff[PX];
     __amdgpu_buffer_rsrc_t rs_w = rsrc_of(a.W), rs_w2 = rsrc_of(a.W2 ? a.W2 : a.W), rs_x = rsrc_of(a.X);
     (void)rs_w2;
+    // Tile order.  Consecutive ids run on one XCD (xcd_remap) with the W tiles fastest: the X tile is shared in that XCD's L2.  When all
+    // of W does not fit the 4 MB L2 next to the streaming X tiles (SwiGLU: 6.3 MB of fc1 | fc3; qkv: 3.5 MB) every round re-fetches it
+    // from the Infinity Cache (FETCH_SIZE 3-14 x the operands, profiles/r02_lab_nt_fetch.txt).  group_w > 0: an XCD walks its X range
+    // once per GROUP of group_w W tiles - the group stays resident, the X range is streamed n_tiles_w / group_w times instead.
+    const int gw = a.group_w;
+    const bool grouped_order = gw > 0 && total % 8 == 0 && a.n_tiles_x % 8 == 0 && a.n_tiles_w % gw == 0;
     auto tile_origin = [&](int j, int& n0, int& m0) {
         const int tile = xcd_remap((int)blockIdx.x + j * (int)gridDim.x, total);
-        n0 = (tile % a.n_tiles_w) * NPT; m0 = (tile / a.n_tiles_w) * TX;      // W tiles fastest: the X tile is shared in the XCD's L2
+        int tw = tile % a.n_tiles_w, tx = tile / a.n_tiles_w;
+        if (grouped_order) {
+            const int per_xcd = total / 8, xr = a.n_tiles_x / 8;
+            const int xcd = tile / per_xcd, l = tile % per_xcd;
+            const int grp = l / (xr * gw), rem = l % (xr * gw);
+            tx = xcd * xr + rem / gw; tw = grp * gw + rem % gw;
+        }
+        n0 = tw * NPT; m0 = tx * TX;
     };
     auto set_sources = [&](int j) __attribute__((always_inline)) {
         int n0, m0;
@@ -420,6 +433,7 @@ int launch_nt3(NTArgs a, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (a.N + NPT - 1) / NPT;
     a.n_tiles_x = (a.M + 255) / 256;
+    a.group_w = (a.lab >> 12) & 15;              // experiment (fm_lab_set 3, bits 12-15): W tiles per resident group
     int grid = a.n_tiles_w * a.n_tiles_x;
     const int cus = fm_grid_cus();
     if (grid > cus) grid = cus;

@@ -30,7 +30,9 @@ def test_engine_job_lists():
     mx, avg, banded, rr = M.check(enc, 256, True)
     assert banded and mx < 1.05 * avg                       # encoder layer: bands + walkers, balanced within 5 %
     mx, avg, banded, rr = M.check(dec, 256, True)
-    assert rr and mx < 1.25 * avg                           # decoder layer: round-robin tails (known 20 % imbalance)
+    assert rr and mx < 1.05 * avg                           # decoder layer: one whole tail per tail workgroup + a walk over the other 32 tails
+    mx0, avg0, _, _ = M.check(dec, 256, True, hybrid_on=False)
+    assert mx0 > 1.15 * avg0                                # (plain round-robin: 32 tail workgroups take a second whole tail)
     for lst in (enc, dec):
         mx, avg, _, _ = M.check(lst, 256, "ls")                # the lock-step configuration
         assert mx < 1.25 * avg

@@ -6,7 +6,7 @@ import random
 import sys
 
 
-def plan(jobs, cus, big=True, bands=True):
+def plan(jobs, cus, big=True, bands=True, hybrid_on=True):
     """jobs: list of (N, K, R).  Mirrors the host code.  big: True = 256 x 256 tiles with K-step 32, False = 128 x 256 / 64,
     "ls" = the lock-step form (256 x 256 tiles, K-step 64: fm_set_gemm_tn_config(4))."""
     ls = big == "ls"
@@ -29,6 +29,7 @@ def plan(jobs, cus, big=True, bands=True):
     c = (12.0 if tail_rr else 64.0) if ls else (24.0 if tail_rr else 128.0) if big else 8.0
     cb = 16.0 if ls else 32.0
     banded = (not tail_rr) and rem > 0 and ntail > rem and bands
+    hybrid = tail_rr and rem > ntail and ntail > 0 and hybrid_on
     for j in J:
         j["lb"] = 0
         if rem == 0:
@@ -42,7 +43,10 @@ def plan(jobs, cus, big=True, bands=True):
                 q = j["kt"] // 2          # C: integer division of kt by 2 converted to double
             j["q"] = j["lb"] = int(q)
             continue
-        if tail_rr:
+        if hybrid:
+            r = rem / ntail
+            j["q"] = int((j["kt"] * r + c) / (1.0 + r))
+        elif tail_rr:
             n = (rem + ntail - 1) // ntail
             left = (j["kt"] - (n - 1) * c) / (n + 1.0)
             j["q"] = j["kt"] - (int(left) if left > 0 else 0)
@@ -50,10 +54,10 @@ def plan(jobs, cus, big=True, bands=True):
             r = rem / ntail
             j["q"] = int((j["kt"] * r + r * c) / (1.0 + r))
         j["q"] = min(max(j["q"], 0), j["kt"])
-    return J, tiles, grid, tail_rr, banded
+    return J, tiles, grid, tail_rr, banded, hybrid
 
 
-def segments(J, tiles, G, tail_rr, banded, w, limit=100000):
+def segments(J, tiles, G, tail_rr, banded, w, limit=100000, hybrid=False):
     """The device loop of workgroup w (logical index).  Yields (tile, t0, t1); raises on non-termination."""
     n_jobs = len(J)
 
@@ -66,14 +70,15 @@ def segments(J, tiles, G, tail_rr, banded, w, limit=100000):
     T0 = full * G
     rem = tiles - T0
     ntail = G - rem
-    nband = rem if banded else 0
+    nband = 0 if hybrid else (rem if banded else 0)
     nwalk = ntail - nband
-    q2 = lambda j: J[j]["q"] + (J[j]["lb"] if banded else 0)
+    walk_T0 = T0 + ntail if hybrid else T0
+    q2 = lambda j: J[j]["q"] + (J[j]["lb"] if (banded and not hybrid) else 0)
     u0 = u1 = 0
-    if rem > 0 and w >= rem + nband and not tail_rr:
+    if rem > 0 and w >= rem + nband and (not tail_rr or hybrid):
         Lsum = 0
         for j in range(n_jobs):
-            lo, hi = max(J[j]["tile_start"], T0), J[j]["tile_start"] + J[j]["tiles"]
+            lo, hi = max(J[j]["tile_start"], walk_T0), J[j]["tile_start"] + J[j]["tiles"]
             if hi > lo:
                 Lsum += (hi - lo) * (J[j]["kt"] - q2(j))
         u0, u1 = Lsum * (w - rem - nband) // nwalk, Lsum * (w - rem - nband + 1) // nwalk
@@ -94,7 +99,7 @@ def segments(J, tiles, G, tail_rr, banded, w, limit=100000):
             tile = T0 + w; t1 = J[job_of(tile)]["q"]; phase = 3; have = True
         elif phase == 4:
             tile = T0 + (w - rem); j = job_of(tile); t0 = J[j]["q"]; t1 = t0 + J[j]["lb"]; phase = 3; have = True
-        elif phase == 2 and tail_rr:
+        elif phase == 2 and tail_rr and not (hybrid and f > 0):
             sgm = (w - rem) + f * ntail
             if sgm >= rem:
                 phase = 3
@@ -104,7 +109,7 @@ def segments(J, tiles, G, tail_rr, banded, w, limit=100000):
             if tj >= n_jobs:
                 phase = 3
             else:
-                lo, hi = max(J[tj]["tile_start"], T0), J[tj]["tile_start"] + J[tj]["tiles"]
+                lo, hi = max(J[tj]["tile_start"], walk_T0), J[tj]["tile_start"] + J[tj]["tiles"]
                 q = q2(tj); left = J[tj]["kt"] - q
                 advance = True
                 if hi > lo and left > 0:
@@ -127,13 +132,13 @@ def segments(J, tiles, G, tail_rr, banded, w, limit=100000):
             yield tile, t0, t1
 
 
-def check(jobs, cus, big, bands=True):
-    J, tiles, G, rr, banded = plan(jobs, cus, big, bands)
+def check(jobs, cus, big, bands=True, hybrid_on=True):
+    J, tiles, G, rr, banded, hybrid = plan(jobs, cus, big, bands, hybrid_on)
     cover = {}
     load = []
     for w in range(G):
         tot = 0
-        for tile, t0, t1 in segments(J, tiles, G, rr, banded, w):
+        for tile, t0, t1 in segments(J, tiles, G, rr, banded, w, hybrid=hybrid):
             assert 0 <= tile < tiles and 0 <= t0 < t1, (tile, t0, t1)
             for k in range(t0, t1):
                 key = (tile, k)
