@@ -25,7 +25,9 @@ def tie(P, cfg, share):
     return P
 
 
-@pytest.mark.parametrize("name", list(CASES))
+# (cases marked `big` — batch 256 — take minutes and tens of GB through the CPU oracle; their fixtures are compared with the HIP
+#  path in tests/test_b256_golden_gpu.py and with the oracle's integer selection in test_big_fixture_selection_is_exact below)
+@pytest.mark.parametrize("name", [n for n in CASES if not CASES[n].get("big")])
 def test_oracle_matches_upstream_fixture(name):
     g = load(name)
     case = build_case(name)
@@ -76,6 +78,29 @@ def test_oracle_matches_upstream_fixture(name):
         logits = O.fourm_forward(P, cfg, md, case["N"], case["M"], order, return_logits=True)
     for k, v in logits.items():
         assert float(v.double().norm()) == pytest.approx(float(g[f"logits_fro/{k}"]), rel=1e-5)
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if CASES[n].get("big")])
+def test_big_fixture_selection_is_exact(name):
+    """Batch-256 fixture: checksums, and the oracle's token selection alone (fm.py:343-449; integers and gathered rows) — the
+    trunk at this size is left to the GPU test."""
+    g = load(name)
+    case = build_case(name)
+    cfg, sd, md = case["cfg"], case["sd"], case["mod_dict"]
+    assert sum(float(v.double().abs().sum()) for v in sd.values()) == pytest.approx(float(g["meta/weight_checksum"]), rel=1e-9)
+    assert sum(float(t.double().abs().sum()) for d in md.values() for t in d.values()) == pytest.approx(float(g["meta/input_checksum"]), rel=1e-9)
+    P = tie(dict(sd), cfg, case["share_embedding"])
+    with torch.no_grad():
+        enc = O.select_encoder(P, cfg, md, case["N"], O._Num(False))
+        dec = O.select_decoder(P, cfg, md, case["M"], g["meta/order"].tolist())
+    assert np.array_equal(enc["mask"].numpy(), g["enc/mask"])
+    assert np.array_equal(enc["mod_mask"].numpy(), g["enc/mod_mask"])
+    assert np.array_equal(dec["mask"].numpy(), g["dec/mask"])
+    assert np.array_equal(dec["mod_mask"].numpy(), g["dec/mod_mask"])
+    assert np.array_equal(dec["target_ids"].numpy(), g["dec/target_ids"])
+    assert np.array_equal(np.packbits(dec["attn_mask"].numpy(), axis=-1), g["dec/attn_mask"])
+    np.testing.assert_allclose(enc["tokens"].sum(-1).numpy(), g["enc/tokens_rowsum"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dec["emb"].sum(-1).numpy(), g["dec/emb_rowsum"], rtol=1e-5, atol=1e-5)
 
 
 def test_partition_equals_float_argsort():

@@ -1,21 +1,32 @@
 #!/bin/bash
-# Round-end measurement set on one MI355X: full GPU suite (parity log), the default bench line, rocprofv3 kernel stats of the bench
-# command, the VQ bench line.  Everything lands under gpurun_out/ (copy what is to be judged into profiles/).
+# Round-end measurement set on one MI355X: smoke, full GPU suite (parity log), the default bench line (headline + extra.vq + extra.mod21),
+# rocprofv3 kernel stats of the bench command, lab tables of the GEMM kernels.  Everything lands under gpurun_out/ (copy what is to be
+# judged into profiles/).
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out; rm -f gpurun_out/parity.jsonl
 export TMPDIR=/tmp
 ROOT=$(pwd)
+export LD_LIBRARY_PATH=$ROOT/ml-4m_amd/fourm/_lib:$LD_LIBRARY_PATH
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 1500 python -m pytest tests -v -m gpu -x --tb=short > gpurun_out/final_pytest_full.txt 2>&1     # (-v into a file: a cut-off run still shows how far it got)
-grep -v Warning gpurun_out/final_pytest_full.txt | tail -12 | cut -c1-300 > gpurun_out/final_pytest.txt
-tail -3 gpurun_out/final_pytest.txt
+if [ -z "$SKIP_TESTS" ]; then
+  timeout 1500 python -m pytest tests -v -m gpu -x --tb=short > gpurun_out/final_pytest_full.txt 2>&1     # (-v into a file: a cut-off run still shows how far it got)
+  grep -v Warning gpurun_out/final_pytest_full.txt | tail -12 | cut -c1-300 > gpurun_out/final_pytest.txt
+  tail -3 gpurun_out/final_pytest.txt
+fi
 BENCH_SHAPE_TABLE=gpurun_out/final_shape_table.txt timeout 900 python bench.py 2> gpurun_out/final_bench.err | tail -1 > gpurun_out/final_bench.json
-cut -c1-600 gpurun_out/final_bench.json
-rm -rf gpurun_out/prof_r02
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_r02 -o trace -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-traffic > $ROOT/gpurun_out/final_bench_under_rocprof.json 2> $ROOT/gpurun_out/prof_r02.err)
-f=$(find gpurun_out/prof_r02 -name "*kernel_stats.csv" | head -1)
+cut -c1-400 gpurun_out/final_bench.json
+rm -rf gpurun_out/prof_final
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_final -o trace -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-traffic --no-extras > $ROOT/gpurun_out/final_bench_under_rocprof.json 2> $ROOT/gpurun_out/prof_final.err)
+f=$(find gpurun_out/prof_final -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/final_kernel_stats.csv
-rm -rf gpurun_out/prof_r02
+rm -rf gpurun_out/prof_final
 head -12 gpurun_out/final_kernel_stats.csv | cut -c1-160
-timeout 600 python bench.py --workload vq 2> gpurun_out/final_bench_vq.err | tail -1 > gpurun_out/final_bench_vq.json
-cut -c1-400 gpurun_out/final_bench_vq.json
+{ echo "# tools/gemm_lab nt 265,268,1001,1002,1003: round-2 automatic choice (265), round-2 256x256 ping-pong (268), gemm_nt3 256-wide / 192-wide / by shape (the default)";
+  timeout 200 tools/bin/gemm_lab nt 265,268,1001,1002,1003;
+  echo "# the same with experiment flags on gemm_nt3 (by shape): 1013 no wait for the DMA, 1023 no main-loop DMA, 1043 no stores, 1063 no DMA + no stores";
+  timeout 200 tools/bin/gemm_lab nt 1003,1013,1023,1043,1063 | sed "s/\[c[0-9]*: [0-9]* of [0-9]* halfwords differ from c[0-9]*\]//g";
+  echo "# T(K) at fixed M, N (operands with leading dimension 6144)";
+  timeout 200 tools/bin/gemm_lab ksweep 266,1001,1002;
+  echo "# all dW GEMMs of a layer: one fm_gemm_tn launch each vs ONE fm_gemm_tn_multi launch";
+  timeout 100 tools/bin/gemm_lab tnmulti 32768 1; } > gpurun_out/final_lab_nt3.txt 2>&1
+tail -4 gpurun_out/final_lab_nt3.txt

@@ -238,7 +238,12 @@ int main(int argc, char** argv) {
         std::vector<Shape> dec = enc; dec.push_back({768, 768}); dec.push_back({768, 768}); dec.push_back({1536, 768});
         const int Rm = argc > 2 ? atoi(argv[2]) : R;
         const int multi_cfg = argc > 3 ? atoi(argv[3]) : 1;      // fm_set_gemm_tn_config for the one-launch form (2 = 256 x 256 tiles)
-        for (auto* layer : {&enc, &dec}) {
+        const int layers_per_list = argc > 4 ? atoi(argv[4]) : 1; // > 1: the dW GEMMs of several layers in ONE list (distinct operands)
+        std::vector<Shape> enc_n, dec_n;
+        for (int l = 0; l < layers_per_list; ++l) { enc_n.insert(enc_n.end(), enc.begin(), enc.end()); dec_n.insert(dec_n.end(), dec.begin(), dec.end()); }
+        if (layers_per_list > 1) printf("(%d layers per list: divide the times by %d)\n", layers_per_list, layers_per_list);
+        for (auto* layer : {&enc_n, &dec_n}) {
+            if ((int)layer->size() > FM_TN_MAX_JOBS) continue;
             std::vector<fm_gemm_tn_job> jobs; std::vector<fm_gemm_tn_args> args; std::vector<void*> outs, outs2;
             double flops = 0;
             for (auto& sh : *layer) {
@@ -272,7 +277,7 @@ int main(int argc, char** argv) {
                 fm_set_gemm_tn_config(1);
             }
             printf("%s layer (%zu dW GEMMs, R=%d): separate %7.1f us %5.0f TF | one launch %7.1f us %5.0f TF | rel diff %.2e\n",
-                   layer == &enc ? "encoder" : "decoder", jobs.size(), Rm, t1, flops / t1 / 1e6, t2, flops / t2 / 1e6, worst);
+                   layer == &enc_n ? "encoder" : "decoder", jobs.size(), Rm, t1, flops / t1 / 1e6, t2, flops / t2 / 1e6, worst);
             for (size_t i = 0; i < jobs.size(); ++i) { CK(hipFree((void*)jobs[i].A)); CK(hipFree((void*)jobs[i].B)); CK(hipFree(outs[i])); CK(hipFree(outs2[i])); }
         }
     }
