@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 3
+#define FM_ABI_VERSION 4
 int fm_abi_version(void);
 const char* fm_last_error(void);
 
@@ -416,6 +416,41 @@ int fm_unpack_image_u8(const void* src, void* dst, int B, int H, int W, int C, c
 int fm_unpack_ids_u16(const void* src, int64_t* dst, int64_t n, void* stream);
 int fm_unpack_mask_bits(const void* bits, void* dst, int B, int L, void* stream);
 int fm_decoder_attention_from_target(const void* target_mask, int32_t* decoder_attention_mask, int B, int L, void* stream);
+
+/* Token budgets of a batch (UnifiedMasking.input_token_budget / target_token_budget, fourm/data/masking.py:181-234), one sample per
+ * thread.  The caller draws:  main_draws f32 (B, T, M) - the Dirichlet sample of try t;  extra_draws f32 (B, T, E, M) - the
+ * sample_n(diff) draws of try t (the first diff = n - sum(floor(p * n)) rows are used, E >= M covers every case).
+ *   budget = floor(p * n) + bincount(argmax(extra[:diff])), clamped to max_tokens[m]; the first try with budget >= min_tokens everywhere is
+ *   taken, else the last one (tries (B), optional: the number of tries consumed).
+ * Target budgets: pass input_budget int32 (B, M) and is_img uint8 (M): the clamp becomes max(min_tokens, max_tokens - input_budget) for
+ * image-like modalities (:218-219).  Input budgets: input_budget = NULL.  M <= 64. */
+int fm_token_budgets(const void* main_draws, const void* extra_draws, const int32_t* num_tokens, const int32_t* min_tokens,
+                     const int32_t* max_tokens, const void* is_img, const int32_t* input_budget, int B, int T, int E, int M,
+                     int32_t* budget, int32_t* tries, void* stream);
+
+/* Span masking of sequence modalities (fourm/data/masking.py: sequence_mask :345-445 after tokenisation, sequence_token_mask :268-343,
+ * sequence_emb_mask_span :448-516; simple_span_masking :58-91, chunk_span_masking :94-127), one wave per sample.
+ *   ids (B, ld_ids) int32 with len (B): the token ids upstream has after tokenising and appending [EOS] (vocab_offset is added, :286);
+ *   unit (B, ld_ids) or NULL: index of the chunk a token belongs to (chunk_span_masking: one mask decision per chunk, truncation by whole
+ *     chunks; chunks must be non-empty);  NULL = one decision per token (truncation to max_tokens tokens);
+ *   noise f32 (B, T, ld_noise): row t = the torch.rand vector of try t, indexed by token (or chunk);  keep_prob f64 (B): the first keep
+ *     probability (sample_uniform / 1.0 / random.choice), multiplied by 0.9 per retry while the input is over its budget (:405-408); a unit
+ *     is kept iff noise <= (float)keep_prob;  after T tries everything is masked (the limit keep_prob -> 0);
+ *   input_budget (B);  target_budget (B) or NULL (= None; an entry < 0 = None for that sample);  r_choice (B) or NULL: the integer that
+ *     replaces np.random.randint (taken modulo its argument, :425);  sentinel_ids[k] = sentinel_to_id[k].
+ * Outputs, each (B, 2 * (max_tokens + 1)): tensor int32 (pad_id where empty), input_mask / target_mask uint8 (1 = masked out),
+ * decoder_attention_mask int32;  tries (B) optional: draws consumed, -1 = more spans than sentinel ids (upstream raises KeyError).
+ * Embedding mode (emb != NULL; sequence_emb_mask_span): emb f32 (B, emb_rows, emb_dim) with len (B); ids / unit / tensor / target_budget
+ * unused; outputs are (B, max_tokens): input_mask, target_mask (all 1), decoder_attention_mask (all 0), src int32 (the source row of every
+ * position, -1 = zero row) and emb_out f32 (B, max_tokens, emb_dim). */
+typedef struct fm_span_mask_args {
+    const int32_t* ids; const int32_t* len; const int32_t* unit; const void* noise; const double* keep_prob; const int32_t* r_choice;
+    const int32_t* input_budget; const int32_t* target_budget; const int32_t* sentinel_ids;
+    const void* emb; void* emb_out; int32_t* src;
+    int32_t* tensor; void* input_mask; void* target_mask; int32_t* decoder_attention_mask; int32_t* tries;
+    int32_t B, ld_ids, T, ld_noise, n_sentinels, max_tokens, vocab_offset, pad_id, emb_rows, emb_dim;
+} fm_span_mask_args;
+int fm_span_mask(const fm_span_mask_args* p, void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def _load():
 lib = _load()
 lib.fm_last_error.restype = C.c_char_p
 lib.fm_abi_version.restype = C.c_int
-ABI_VERSION = 3
+ABI_VERSION = 4
 if lib.fm_abi_version() != ABI_VERSION:
     raise FourmHipUnavailable(f"libfourm_hip.so ABI {lib.fm_abi_version()} != expected {ABI_VERSION}; rebuild")
 
@@ -91,6 +91,14 @@ class GemmF32Args(C.Structure):
                 ("M", i32), ("N", i32), ("K", i32), ("ldo", i32), ("ldo2", i32), ("ldr", i32), ("Hp", i32), ("epilogue", i32),
                 ("accumulate", i32), ("max_N", i32), ("seg_rows", i32), ("n_groups", i32),
                 ("groups", vp), ("tile_group", vp), ("seg_start", vp), ("seg_count", vp)]
+
+
+class SpanMaskArgs(C.Structure):
+    _fields_ = [("ids", vp), ("len", vp), ("unit", vp), ("noise", vp), ("keep_prob", vp), ("r_choice", vp), ("input_budget", vp), ("target_budget", vp),
+                ("sentinel_ids", vp), ("emb", vp), ("emb_out", vp), ("src", vp), ("tensor", vp), ("input_mask", vp), ("target_mask", vp),
+                ("decoder_attention_mask", vp), ("tries", vp),
+                ("B", i32), ("ld_ids", i32), ("T", i32), ("ld_noise", i32), ("n_sentinels", i32), ("max_tokens", i32), ("vocab_offset", i32), ("pad_id", i32),
+                ("emb_rows", i32), ("emb_dim", i32)]
 
 
 class AdamWJob(C.Structure):
@@ -184,12 +192,14 @@ lib.fm_set_gemm_nt_config.argtypes = [C.c_int]
 vq_code_stats = _sig("fm_vq_code_stats", vp, i32, vp, i32, i32, i32, vp, vp, vp)
 vq_ema_update = _sig("fm_vq_ema_update", vp, vp, vp, vp, i32, i32, f32, vp)
 image_mask = _sig("fm_image_mask", vp, vp, vp, i32, i32, vp, vp, vp, vp)
+token_budgets = _sig("fm_token_budgets", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp)
+span_mask = _sig("fm_span_mask", P(SpanMaskArgs), vp)
 guidance_combine = _sig("fm_guidance_combine", vp, i32, i32, vp, i32, i32, f32, vp, i32, i32, i32, i32, vp)
 unpack_image_u8 = _sig("fm_unpack_image_u8", vp, vp, i32, i32, i32, i32, P(C.c_float), P(C.c_float), vp)
 unpack_ids_u16 = _sig("fm_unpack_ids_u16", vp, vp, i64, vp)
 unpack_mask_bits = _sig("fm_unpack_mask_bits", vp, vp, i32, i32, vp)
 decoder_attention_from_target = _sig("fm_decoder_attention_from_target", vp, vp, i32, i32, vp)
-EXPORTS = ["fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_add_bf16_f32", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
+EXPORTS = ["fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_token_budgets", "fm_span_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_add_bf16_f32", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_fwd_res", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",

@@ -132,3 +132,221 @@ def test_compact_h2d_round_trip():
             got = out[name][k].cpu()
             assert got.dtype == v.dtype and got.shape == v.shape, (name, k, got.dtype, v.dtype)
             assert torch.equal(got, v), (name, k)
+
+
+# ---- token budgets and sequence span masking (second slice of f3) -------------------------------------------------------------------------
+import numpy as np  # noqa: E402
+
+from oracle import masking_oracle as MO  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden", "masking.npz")
+T_SEQ = 32
+
+
+def _gold():
+    g = np.load(GOLD, allow_pickle=False)
+    assert int(g["meta/t_seq"]) == T_SEQ
+    return g
+
+
+def _seq_noise(c, width, checksum):
+    """Noise rows of fixture case c, regenerated from the seed the generator used (tests/golden/make_golden_masking.py: seq_noise)."""
+    nz = np.random.default_rng(5000 + c).random((T_SEQ, width), dtype=np.float32)
+    assert float(nz.astype(np.float64).sum()) == pytest.approx(float(checksum), rel=1e-12), "numpy's random stream differs from the generating environment"
+    return nz
+
+
+def _sentinels(g):
+    ids = g["meta/sentinel_ids"]
+    return {k: int(v) for k, v in enumerate(ids)}, int(g["meta/pad_id"])
+
+
+def _seq_case(g, c):
+    n = int(g["seq/len"][c])
+    ids = g["seq/ids"][c, :n].tolist()
+    unit = g["seq/unit"][c, :n].tolist() if bool(g["seq/chunked"][c]) else None
+    kt = int(g["seq/tgt_budget"][c])
+    return dict(ids=ids, unit=unit, max_tokens=int(g["seq/max_tokens"][c]), kin=int(g["seq/in_budget"][c]), kt=None if kt < 0 else kt, kp=float(g["seq/kp"][c]),
+                noise=_seq_noise(c, int(g["seq/noise_width"][c]), g["seq/noise_sum"][c]), r=int(g["seq/r"][c]), voff=int(g["seq/voff"][c]), L=int(g["seq/out_len"][c]))
+
+
+def test_budget_oracle_matches_upstream_fixture():
+    g = _gold()
+    for c in range(len(g["bud/n"])):
+        b, tries = MO.token_budget(g["bud/main"][c], g["bud/extra"][c], int(g["bud/n"][c]), g["bud/min"][c], g["bud/max"][c])
+        assert np.array_equal(b, g["bud/out"][c]) and tries == int(g["bud/tries"][c]), c
+        if bool(g["bud/is_target"][c]):
+            assert np.array_equal(MO.max_tokens_remaining(g["bud/is_img"], g["bud/max_tokens"], g["bud/min"][c], g["bud/in_budget"][c]), g["bud/max"][c])
+    assert {1, 2, 6} <= set(g["bud/tries"].tolist())
+
+
+def test_span_oracle_matches_upstream_fixture():
+    g = _gold()
+    s2i, pad = _sentinels(g)
+    kinds = set()
+    for c in range(len(g["seq/len"])):
+        k = _seq_case(g, c)
+        o = MO.sequence_mask(k["ids"], k["max_tokens"], k["kin"], k["kt"], k["kp"], k["noise"], k["r"], s2i, pad, unit_of=k["unit"], vocab_offset=k["voff"])
+        assert np.array_equal(o["tensor"], g["seq/tensor"][c, :k["L"]]), c
+        assert np.array_equal(o["input_mask"], g["seq/input_mask"][c, :k["L"]]) and np.array_equal(o["target_mask"], g["seq/target_mask"][c, :k["L"]]), c
+        assert np.array_equal(o["decoder_attention_mask"], g["seq/dam"][c, :k["L"]]) and o["tries"] == int(g["seq/tries"][c]), c
+        kinds.add((k["unit"] is not None, k["kt"] is None, k["kin"] == 0, o["tries"] > 1))
+    assert len(kinds) >= 8
+    for i in range(int(g["meta/n_emb"])):
+        emb = g[f"emb{i}/emb"]
+        nz = _seq_noise(100 + i, emb.shape[0], g[f"emb{i}/noise"])
+        o = MO.sequence_emb_mask(emb, int(g[f"emb{i}/max_tokens"]), int(g[f"emb{i}/in_budget"]), float(g[f"emb{i}/kp"]), nz, s2i)
+        assert np.array_equal(o["tensor"], g[f"emb{i}/tensor"]) and np.array_equal(o["input_mask"], g[f"emb{i}/input_mask"]), i
+
+
+def test_span_oracle_round_trip():
+    """Property (any size): merging the target spans back into the input at their sentinels restores the sequence (what upstream's
+    merge_span_masking, text_tokenizer.py:127-137, does at generation time)."""
+    rng = np.random.default_rng(3)
+    s2i = {k: 1000 + k for k in range(200)}
+    sent = set(s2i.values())
+    for _ in range(50):
+        n = int(rng.integers(1, 200))
+        seq = rng.integers(0, 900, n).tolist()
+        inp, tgt = MO.span_masking(seq, list(range(n)), rng.random(n, dtype=np.float32), float(rng.random()), s2i)
+        spans, cur = {}, None
+        for t in tgt:
+            if t in sent:
+                cur = t; spans[cur] = []
+            else:
+                spans[cur].append(t)
+        merged = [x for t in inp for x in (spans[t] if t in sent else [t])]
+        assert merged == seq
+
+
+@pytest.mark.gpu
+def test_token_budget_kernel_bit_exact():
+    from fourm.data.masking import token_budgets_batched
+    g = _gold()
+    dev = "cuda"
+    is_t = g["bud/is_target"]
+    for target in (False, True):
+        sel = np.nonzero(is_t == target)[0]
+        main, extra = torch.from_numpy(g["bud/main"][sel]).to(dev), torch.from_numpy(g["bud/extra"][sel]).to(dev)
+        # (min_tokens differs between fixture cases: one launch per distinct vector)
+        for mn in {tuple(g["bud/min"][c]) for c in sel}:
+            rows = [i for i, c in enumerate(sel) if tuple(g["bud/min"][c]) == mn]
+            cs = sel[rows]
+            out, tries = token_budgets_batched(main[rows], extra[rows], torch.from_numpy(g["bud/n"][cs]).to(dev), list(mn), g["bud/max_tokens"].tolist(),
+                                               is_img=g["bud/is_img"] if target else None,
+                                               input_budget=torch.from_numpy(g["bud/in_budget"][cs]).to(dev) if target else None)
+            assert np.array_equal(out.cpu().numpy(), g["bud/out"][cs]), (target, mn)
+            assert np.array_equal(tries.cpu().numpy(), g["bud/tries"][cs])
+    # seeded random draws at the benched batch size: kernel == oracle
+    gen = torch.Generator().manual_seed(5)
+    B, T, M = 256, 5, 21
+    alphas = torch.rand(M, generator=gen) * 2 + 0.05
+    d = torch.distributions.Dirichlet(alphas)
+    torch.manual_seed(11)
+    main, extra = d.sample((B, T)), d.sample((B, T, M))
+    n = torch.randint(1, 257, (B,), generator=gen)
+    mn, mx = torch.randint(0, 4, (M,), generator=gen), torch.randint(8, 257, (M,), generator=gen)
+    out, tries = token_budgets_batched(main.to(dev), extra.to(dev), n.to(dev), mn, mx)
+    for b in range(B):
+        ob, ot = MO.token_budget(main[b].numpy(), extra[b].numpy(), int(n[b]), mn.numpy(), mx.numpy())
+        assert np.array_equal(out[b].cpu().numpy(), ob) and int(tries[b]) == ot, b
+    assert int(out.sum(1).max()) <= 256 and bool((out.cpu() <= mx[None]).all())
+
+
+@pytest.mark.gpu
+def test_span_mask_kernel_matches_upstream_fixture():
+    from fourm.data.masking import sequence_emb_mask_batched, sequence_mask_batched
+    g = _gold()
+    s2i, pad = _sentinels(g)
+    sent = g["meta/sentinel_ids"]
+    dev = "cuda"
+    for c in range(len(g["seq/len"])):
+        k = _seq_case(g, c)
+        ids = torch.tensor([k["ids"] + [7] * 3], dtype=torch.int32, device=dev)                 # (row wider than the sequence: len decides)
+        unit = None if k["unit"] is None else torch.tensor([k["unit"] + [999] * 3], dtype=torch.int32, device=dev)
+        o = sequence_mask_batched(ids, [len(k["ids"])], k["max_tokens"], [k["kin"]], None if k["kt"] is None else [k["kt"]], [k["kp"]],
+                                  torch.from_numpy(k["noise"])[None].to(dev), sent, pad, unit=unit, r_choice=[k["r"]], vocab_offset=k["voff"])
+        L_ = k["L"]
+        assert np.array_equal(o["tensor"][0].cpu().numpy(), g["seq/tensor"][c, :L_]), c
+        assert np.array_equal(o["input_mask"][0].cpu().numpy(), g["seq/input_mask"][c, :L_]), c
+        assert np.array_equal(o["target_mask"][0].cpu().numpy(), g["seq/target_mask"][c, :L_]), c
+        assert np.array_equal(o["decoder_attention_mask"][0].cpu().numpy(), g["seq/dam"][c, :L_]), c
+        assert int(o["tries"][0]) == int(g["seq/tries"][c]), c
+    for i in range(int(g["meta/n_emb"])):
+        emb = g[f"emb{i}/emb"]
+        nz = _seq_noise(100 + i, emb.shape[0], g[f"emb{i}/noise"])
+        o = sequence_emb_mask_batched(torch.from_numpy(emb)[None].to(dev), int(g[f"emb{i}/max_tokens"]), [int(g[f"emb{i}/in_budget"])], [float(g[f"emb{i}/kp"])],
+                                      torch.from_numpy(nz)[None].to(dev), sent)
+        assert np.array_equal(o["tensor"][0].cpu().numpy(), g[f"emb{i}/tensor"]) and np.array_equal(o["input_mask"][0].cpu().numpy(), g[f"emb{i}/input_mask"]), i
+        assert bool(o["target_mask"].all()) and int(o["decoder_attention_mask"].abs().sum()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunked", [False, True])
+def test_span_mask_kernel_batch_bit_exact(chunked):
+    """A ragged batch at the benched batch size (empty-ish rows, rows longer than max_tokens, zero budgets, no target budget): kernel == oracle."""
+    from fourm.data.masking import sequence_mask_batched
+    rng = np.random.default_rng(17 + chunked)
+    B, W, MT, T = 256, 300, 256, 24
+    s2i = {k: 4 + k for k in range(200)}
+    sent = np.array([s2i[k] for k in range(200)], dtype=np.int32)
+    lens = rng.integers(1, W + 1, B); lens[0], lens[1] = 1, W
+    ids = rng.integers(204, 30000, (B, W)).astype(np.int32)
+    ids[5, 3] = 10                                                   # a data token that IS a sentinel id: recognised by value, as upstream
+    unit = None
+    if chunked:
+        unit = np.cumsum(rng.random((B, W)) < 0.3, axis=1).astype(np.int32)
+        unit -= unit[:, :1]
+    kin = rng.integers(0, 129, B); kin[2] = 0
+    kt = rng.integers(0, 129, B); kt[3] = -1
+    kp = rng.random(B); kp[4] = 1.0; kp[6] = 0.0
+    noise = rng.random((B, T, MT), dtype=np.float32)
+    r = rng.integers(0, 1 << 30, B).astype(np.int32)
+    dev = "cuda"
+    o = sequence_mask_batched(torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev), MT, torch.from_numpy(kin).to(dev), torch.from_numpy(kt).to(dev),
+                              torch.from_numpy(kp).to(dev), torch.from_numpy(noise).to(dev), sent, 0, unit=None if unit is None else torch.from_numpy(unit).to(dev),
+                              r_choice=torch.from_numpy(r).to(dev))
+    got = {k: v.cpu().numpy() for k, v in o.items()}
+    for b in range(B):
+        n = int(lens[b])
+        e = MO.sequence_mask(ids[b, :n].tolist(), MT, int(kin[b]), None if kt[b] < 0 else int(kt[b]), float(kp[b]), noise[b], int(r[b]), s2i, 0,
+                             unit_of=None if unit is None else unit[b, :n].tolist())
+        for k in ("tensor", "input_mask", "target_mask", "decoder_attention_mask"):
+            assert np.array_equal(got[k][b], e[k]), (b, k)
+        assert int(got["tries"][b]) == e["tries"], b
+    # size-independent properties: inputs within budget, targets within budget, the two regions disjoint
+    n_in, n_tg = (~got["input_mask"]).sum(1), (~got["target_mask"]).sum(1)
+    assert bool((n_in <= kin).all()) and bool((n_tg[kt >= 0] <= kt[kt >= 0]).all()) and not bool((~got["input_mask"] & ~got["target_mask"]).any())
+
+
+@pytest.mark.gpu
+def test_device_unified_masking_contract():
+    """DeviceUnifiedMasking over a 4M-style modality_info: shapes / dtypes of the loader contract, budgets respected, and the
+    model consumes the result."""
+    from fourm.data.masking import DeviceUnifiedMasking
+    mk = lambda typ, mx, ia, ta, **kw: dict(type=typ, max_tokens=mx, min_tokens=0, input_alphas=ia, target_alphas=ta, **kw)
+    info = {"tok_rgb@224": mk("img", 196, [1.0, 0.5], [1.0, 0.0]), "tok_depth@224": mk("img", 196, [1.0, 0.5], [1.0, 1.0]),
+            "caption": mk("seq", 256, [1.0, 5.0], [1.0, 1.0], keep=["random", "all"]), "det": mk("seq", 256, [1.0, 0.05], [1.0, 1.0], keep=["random", "binary"]),
+            "tok_global": mk("seq_token", 16, [0.5, 0.0], [0.5, 1.0], vocab_offset=300), "t5_caption": mk("seq_emb", 77, [0.2, 5.0], [0.0, 0.0])}
+    s2i = {k: 4 + k for k in range(200)}
+    B, dev = 64, "cuda"
+    um = DeviceUnifiedMasking(info, None, input_tokens_range=128, target_tokens_range=(64, 128), max_tries=20, device=dev, sentinel_to_id=s2i, pad_id=0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: torch.randint(204, 30000, s, device=dev, generator=g, dtype=torch.int32)
+    md = {"tok_rgb": torch.randint(0, 16384, (B, 14, 14), device=dev, generator=g), "tok_depth@224": torch.randint(0, 8192, (B, 14, 14), device=dev, generator=g),
+          "caption": {"ids": rnd(B, 80), "len": torch.randint(1, 81, (B,), device=dev, generator=g, dtype=torch.int32)},
+          "det": {"ids": rnd(B, 120), "len": torch.full((B,), 120, dtype=torch.int32, device=dev), "unit": (torch.arange(120, device=dev) // 5).int()[None].repeat(B, 1)},
+          "tok_global": torch.randint(0, 8192, (B, 16), device=dev, generator=g, dtype=torch.int32), "t5_caption": torch.randn(B, 77, 32, device=dev, generator=g)}
+    out = um(md, generator=g)
+    assert list(out) == list(info)
+    n_in = sum((~out[k]["input_mask"]).flatten(1).sum(1) for k in out)
+    n_tg = sum((~out[k]["target_mask"]).flatten(1).sum(1) for k in out)
+    assert int(n_in.max()) <= 128 and int(n_tg.max()) <= 128 and int(n_in.sum()) > 0 and int(n_tg.sum()) > 0
+    for k, v in out.items():
+        Lk = {"img": 196, "seq": 514, "seq_token": 34, "seq_emb": 77}[info[k]["type"]]
+        assert v["input_mask"].shape == (B, Lk) and v["input_mask"].dtype == torch.bool and v["decoder_attention_mask"].dtype == torch.int32, k
+        assert bool((v["tries"] > 0).all()) if "tries" in v else True
+    assert out["t5_caption"]["tensor"].shape == (B, 77, 32) and out["caption"]["tensor"].dtype == torch.int32
+    out2 = um(md, generator=torch.Generator(device=dev).manual_seed(0))
+    out3 = um(md, generator=torch.Generator(device=dev).manual_seed(0))       # same seed, same draws: the whole pipeline is a function of the generator
+    assert all(torch.equal(out2[k][f], out3[k][f]) for k in out2 for f in ("input_mask", "target_mask", "decoder_attention_mask"))

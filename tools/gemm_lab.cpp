@@ -138,6 +138,29 @@ int main(int argc, char** argv) {
             fm_lab_set(0, 0); fm_lab_set(1, 0);
             CK(hipFree(W)); CK(hipFree(X)); CK(hipFree(out)); if (res) CK(hipFree(res));
         }
+    } else if (mode == "pmc") {
+        // counter runs (rocprofv3 --pmc, GEMM_LAB_NOWARM=1): exactly 5 launches per (case, configuration), case-major, so that the
+        // dispatches can be told apart by their order; prints the order it ran
+        std::vector<int> cfgs;
+        if (argc > 2) { char* t = strtok(argv[2], ","); while (t) { cfgs.push_back(atoi(t)); t = strtok(nullptr, ","); } }
+        else cfgs = {1003};
+        NTCase cases[] = {{"qkv_N2304_K768", 2304, 768, FM_EPI_BF16}, {"proj_N768_K768", 768, 768, FM_EPI_BF16}, {"dXfc2_N2048_K768", 2048, 768, FM_EPI_BF16},
+                          {"dXfc13_N768_K4096", 768, 4096, FM_EPI_BF16}, {"swiglu_N2x2048_K768", 2048, 768, FM_EPI_SWIGLU}};
+        for (auto& c : cases) {
+            void* W = dev_rand_bf16((size_t)c.N * c.K, 1), *W2 = dev_rand_bf16((size_t)c.N * c.K, 2), *X = dev_rand_bf16((size_t)R * c.K, 3);
+            void* out = dev_zero((size_t)R * c.N * 2);
+            void* out2 = c.epi == FM_EPI_SWIGLU ? dev_zero((size_t)R * c.N * 2 * 2) : nullptr;
+            fm_gemm_nt_args a{};
+            a.W = W; a.W2 = c.epi == FM_EPI_SWIGLU ? W2 : nullptr; a.X = X; a.out = out; a.out2 = out2;
+            a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.ldo2 = 2 * c.N; a.Hp = c.N; a.epilogue = c.epi;
+            for (int cfg : cfgs) {
+                set_cfg(cfg);
+                for (int i = 0; i < 5; ++i) if (fm_gemm_nt(&a, 0) != 0) { printf("cfg%d: %s\n", cfg, fm_last_error()); return 1; }
+                CK(hipDeviceSynchronize());
+                printf("%s c%d\n", c.name, cfg);
+            }
+            CK(hipFree(W)); CK(hipFree(W2)); CK(hipFree(X)); CK(hipFree(out)); if (out2) CK(hipFree(out2));
+        }
     } else if (mode == "ksweep") {
         // T(K) = fixed + slope * K at fixed M, N: separates per-tile costs from the main-loop rate
         std::vector<int> cfgs = {265, 266, 267};
