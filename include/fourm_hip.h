@@ -395,6 +395,22 @@ int fm_vq_code_stats(const void* z, int ldz, const int64_t* tokens, int R, int D
  * embed = embed * decay + target * (1 - decay), target = l2norm(sums / bins) where bins > 0, l2norm(embed) elsewhere. */
 int fm_vq_ema_update(const void* bins, const void* sums, void* embed, void* cluster_size, int K, int D, float decay, void* stream);
 
+/* Tokenizer training path (fourm/vq/vqvae.py:454-481 VQVAE, vq/models/vit_models.py:504-648 ViTDecoder,
+ * vq/quantizers/quantize_lucid.py:533-541).
+ *   fm_vq_unpatchify: rows f32 (B * G, ld_rows) with features ordered (c, py, px) -> img f32 (B, C, H, W)  (the rearrange behind
+ *       ViTDecoder.out_proj, vit_models.py:640-643; the inverse of fm_vq_patchify)
+ *   fm_vq_latent_grad: the quantizer's backward and commitment value.  z f32 (R, ldz) latents, tokens (R), embed f32 (K, D);
+ *       dquant f32 (R, ld_dquant) or NULL: gradient w.r.t. the quantised rows (straight-through estimator);  grad_loss: DEVICE f32
+ *       scalar d(objective)/d(code_loss) or NULL;  dz (optional) = dquant + grad_loss * w * 2 (z - embed[token]) / (R D);
+ *       commit_value (optional, f32 scalar the caller zeroed) += w * mean((z - embed[token])^2).  D <= 64.
+ *   fm_tanh_bwd_f32: dx = dy * (1 - t * t) on f32 (R, N) tiles of row stride ld (Mlp with act_layer = Tanh, vit_models.py:494-496)
+ *   fm_embed_rows_f32: out[r] = table[idx[r]] (f32 rows; F.embedding) */
+int fm_vq_unpatchify(const void* rows, int ld_rows, void* img, int B, int C, int H, int W, int P, void* stream);
+int fm_vq_latent_grad(const void* z, int ldz, const void* embed, const int64_t* tokens, const void* dquant, int ld_dquant, const void* grad_loss,
+                      float commitment_weight, void* dz, int ld_dz, void* commit_value, int R, int D, void* stream);
+int fm_tanh_bwd_f32(const void* dy, const void* t, void* dx, int R, int N, int ld, void* stream);
+int fm_embed_rows_f32(const void* table, const int64_t* idx, void* out, int ld_out, int R, int D, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Data side: input / target masks of an image-like modality (UnifiedMasking.image_mask, fourm/data/masking.py:237-266)
  * noise: f32 (B, L) uniform draws (the caller's RNG); input_budget / target_budget: int32 (B) (target_budget NULL = "None":

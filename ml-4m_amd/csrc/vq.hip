@@ -201,3 +201,101 @@ extern "C" int fm_vq_ema_update(const void* bins, const void* sums, void* embed,
     FM_CHECK_LAUNCH("fm_vq_ema_update");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Tokenizer training path: image assembly behind the decoder's output projection, the quantizer's gradient, the
+// tanh "post MLP" backward.  [vq/models/vit_models.py:640-648; vq/quantizers/quantize_lucid.py:533-541]
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// img[b][c][gy*P + py][gx*P + px] = rows[(b*G + g)][c*P*P + py*P + px]      ('b (nh nw) (c ph pw) -> b c (nh ph) (nw pw)')
+__global__ __launch_bounds__(256) void vq_unpatchify_kernel(const float* __restrict__ rows, int ld, float* __restrict__ img, int B, int C, int H, int W, int P) {
+    const int gw = W / P;
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int x = (int)(e % W), y = (int)((e / W) % H), c = (int)((e / ((size_t)W * H)) % C), b = (int)(e / ((size_t)W * H * C));
+        const int g = (y / P) * gw + x / P, f = (c * P + y % P) * P + x % P;
+        img[e] = rows[((size_t)b * (H / P) * gw + g) * ld + f];
+    }
+}
+
+// Gradient that reaches the latents z (R, D) f32 through the quantizer in training mode:
+//   quantize = x + (q - x).detach()          -> d z  = d quantize                      (straight through, :533-534)
+//   loss += w * mse(q.detach(), x)            -> d z += g_loss * w * 2 (z - q) / (R D)  (:539-541), q = embed[token]
+// dq: gradient w.r.t. the quantised rows (R, ldq) f32; also returns the VALUE of the commitment term (atomic sum of squares / (R D)).
+__global__ __launch_bounds__(256) void vq_latent_grad_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ embed, const long long* __restrict__ tokens,
+                                                             const float* __restrict__ dq, int lddq, const float* __restrict__ g_loss, float weight,
+                                                             float* __restrict__ dz, int lddz, float* __restrict__ commit, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float gl = g_loss ? g_loss[0] : 0.f;
+    const float coef = gl * weight * 2.0f / ((float)R * (float)D);
+    float sq = 0.f;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        if (lane < D) {
+            const float diff = z[(size_t)r * ldz + lane] - embed[(size_t)tokens[r] * D + lane];
+            sq += diff * diff;
+            if (dz) dz[(size_t)r * lddz + lane] = (dq ? dq[(size_t)r * lddq + lane] : 0.f) + coef * diff;
+        }
+    }
+    if (commit) {
+        sq = wave_sum(sq);
+        if (lane == 0 && sq != 0.f) unsafeAtomicAdd(commit, sq * weight / ((float)R * (float)D));
+    }
+}
+
+// dx = dy * (1 - t^2), t = tanh(pre) as saved by the forward (f32, row stride ld)
+__global__ __launch_bounds__(256) void tanh_bwd_f32_kernel(const float* __restrict__ dy, const float* __restrict__ t, float* __restrict__ dx, int R, int N, int ld) {
+    const size_t total = (size_t)R * N;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t i = (e / N) * ld + e % N;
+        const float tv = t[i];
+        dx[i] = dy[i] * (1.0f - tv * tv);
+    }
+}
+
+// rows[r][:] = table[idx[r]][:]   (f32; the quantised vectors as GEMM operand rows)
+__global__ __launch_bounds__(256) void embed_rows_f32_kernel(const float* __restrict__ table, const long long* __restrict__ idx, float* __restrict__ out, int ldo, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4)
+        for (int d = lane; d < D; d += 64) out[(size_t)r * ldo + d] = table[(size_t)idx[r] * D + d];
+}
+
+}  // namespace
+
+extern "C" int fm_vq_unpatchify(const void* rows, int ld_rows, void* img, int B, int C, int H, int W, int P, void* stream) {
+    FM_CHECK_ARG(rows && img && B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0 && ld_rows >= C * P * P, "fm_vq_unpatchify: bad argument");
+    size_t blocks = ((size_t)B * C * H * W + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(vq_unpatchify_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)rows, ld_rows, (float*)img, B, C, H, W, P);
+    FM_CHECK_LAUNCH("fm_vq_unpatchify");
+    return 0;
+}
+
+extern "C" int fm_vq_latent_grad(const void* z, int ldz, const void* embed, const int64_t* tokens, const void* dquant, int ld_dquant, const void* grad_loss,
+                                 float commitment_weight, void* dz, int ld_dz, void* commit_value, int R, int D, void* stream) {
+    FM_CHECK_ARG(z && embed && tokens && R > 0 && D > 0 && D <= 64 && (dz || commit_value), "fm_vq_latent_grad: bad argument (D <= 64)");
+    int grid = (R + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(vq_latent_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)z, ldz, (const float*)embed, (const long long*)tokens,
+                       (const float*)dquant, ld_dquant, (const float*)grad_loss, commitment_weight, (float*)dz, ld_dz, (float*)commit_value, R, D);
+    FM_CHECK_LAUNCH("fm_vq_latent_grad");
+    return 0;
+}
+
+extern "C" int fm_tanh_bwd_f32(const void* dy, const void* t, void* dx, int R, int N, int ld, void* stream) {
+    FM_CHECK_ARG(dy && t && dx && R > 0 && N > 0 && ld >= N, "fm_tanh_bwd_f32: bad argument");
+    size_t blocks = ((size_t)R * N + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(tanh_bwd_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (const float*)t, (float*)dx, R, N, ld);
+    FM_CHECK_LAUNCH("fm_tanh_bwd_f32");
+    return 0;
+}
+
+extern "C" int fm_embed_rows_f32(const void* table, const int64_t* idx, void* out, int ld_out, int R, int D, void* stream) {
+    FM_CHECK_ARG(table && idx && out && R > 0 && D > 0 && ld_out >= D, "fm_embed_rows_f32: bad argument");
+    int grid = (R + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(embed_rows_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)table, (const long long*)idx, (float*)out, ld_out, R, D);
+    FM_CHECK_LAUNCH("fm_embed_rows_f32");
+    return 0;
+}

@@ -30,16 +30,39 @@ class _VitEngine(FourMEngine):
         self.ws, self.shadows, self._shadow_table, self._ctx, self.reducer = None, {}, None, None, None
         self.flat_params = self.flat_grads = None
         self._cache, self._dw_jobs = {}, None
+        self._grads = {}                     # id(param) -> fp32 accumulator (the tokenizer has no flat store: few, large tensors)
 
     @property
     def device(self):
-        return self.model.proj.weight.device
+        return self.model.blocks[0].norm1.weight.device
+
+    # gradients of tokenizer training: one fp32 buffer per parameter, attached as ``param.grad`` after the backward
+    def grad_view(self, p):
+        g = self._grads.get(id(p))
+        if g is None or g.device != p.device:
+            g = self._grads[id(p)] = torch.zeros(p.shape, dtype=torch.float32, device=p.device)
+        return g
+
+    def open_window(self, params):
+        """torch semantics: gradients accumulate until the trainer clears them.  A parameter whose ``.grad`` is no longer the buffer this
+        engine attached (zero_grad(set_to_none=True), or never attached) starts from zero."""
+        for p in params:
+            if p.requires_grad:
+                g = self.grad_view(p)
+                if p.grad is not g:
+                    g.zero_()
+
+    def attach(self, params):
+        for p in params:
+            if p.requires_grad:
+                p.grad = self.grad_view(p)
 
 
 def _engine(enc) -> _VitEngine:
     eng = getattr(enc, "_hip_engine", None)
-    if eng is None or eng.device != enc.proj.weight.device:
-        if not enc.proj.weight.is_cuda:
+    dev = enc.blocks[0].norm1.weight.device
+    if eng is None or eng.device != dev:
+        if dev.type != "cuda":
             raise RuntimeError("the tokenizer computes on an MI355X through libfourm_hip.so; move it to the GPU first")
         eng = _VitEngine(enc)
         object.__setattr__(enc, "_hip_engine", eng)
@@ -47,8 +70,54 @@ def _engine(enc) -> _VitEngine:
     return eng
 
 
-def _tokens(enc, x):
-    """(B, C, H, W) -> fp32 residual stream (Rp, D) after the last block (+ post MLP), plus (B, n_h, n_w)."""
+def _pos_rows(eng, vit, B, nh, nw, Rp):
+    """Position table tiled over the batch: (Rp, D) f32, the residual operand of the GEMM that opens the stack."""
+    pe = vit.pos_emb
+    key = ("pos", B, nh, nw, pe._version, pe.data_ptr())
+    pos = eng._cache.get(key)
+    if pos is None:
+        t = pe.detach()
+        if t.shape[-2:] != (nh, nw):
+            t = F.interpolate(t, size=(nh, nw), mode="bicubic", align_corners=False)
+        pos = torch.zeros(Rp, eng.D, dtype=torch.float32, device=t.device)
+        pos[:B * nh * nw] = t[0].permute(1, 2, 0).reshape(nh * nw, eng.D).repeat(B, 1)
+        eng._cache = {k: v for k, v in eng._cache.items() if not (isinstance(k, tuple) and k[0] == "pos")}
+        eng._cache[key] = pos
+    return pos
+
+
+def _blocks_fwd(eng, vit, stream, B, G, st, prefix):
+    none = dict(mask_kind=L.MASK_NONE)
+    for i, blk in enumerate(vit.blocks):
+        sv = {} if st is not None else None
+        stream = eng.encoder_block_fwd(blk, stream, B, G, none, sv, f"{prefix}{i}" if st is not None else f"{prefix}{i % 2}")
+        if st is not None:
+            st["layers"].append(sv)
+    return stream
+
+
+def _post_mlp_fwd(eng, vit, stream, R, st, prefix):
+    """x.float() + fc2(tanh(fc1(norm_mlp(x.float()))))  with autocast DISABLED upstream (vit_models.py:494-496): fp32 operands on the
+    fp32 matrix cores (fm_gemm_f32: v_mfma_f32_32x32x2_f32, exact fp32) - no bf16 rounding in this tail."""
+    ws, f32, D, Rp = eng.ws, torch.float32, eng.D, stream.shape[0]
+    n = ws.get(prefix + ".n", (Rp, D), f32)
+    mu = rs = None
+    if st is not None:
+        mu, rs = ws.get(prefix + ".mu", (Rp,), f32), ws.get(prefix + ".rs", (Rp,), f32)
+    ops.layernorm_fwd(stream, vit.norm_mlp.weight, vit.norm_mlp.bias, n, mu, rs, eps=vit.norm_mlp.eps, R=R)
+    hid = vit.post_mlp.fc1.weight.shape[0]
+    t = ws.get(prefix + ".t", (Rp, hid), f32)
+    ops.gemm_nt(n, vit.post_mlp.fc1.weight.detach(), t, epilogue=L.EPI_TANH, bias=vit.post_mlp.fc1.bias, M=R, N=hid, K=D)
+    out = ws.get(prefix + ".post", (Rp, D), f32)
+    ops.gemm_nt(t, vit.post_mlp.fc2.weight.detach(), out, epilogue=L.EPI_RESIDUAL, res=stream, bias=vit.post_mlp.fc2.bias, M=R, N=D, K=hid)
+    if st is not None:
+        st["post"] = dict(x=stream, n=n, t=t, mu=mu, rs=rs)
+    return out
+
+
+def _tokens(enc, x, st=None):
+    """(B, C, H, W) -> fp32 residual stream (Rp, D) after the last block (+ post MLP), plus (B, n_h, n_w).
+    ``st`` (a dict) keeps what the backward needs (tokenizer training)."""
     eng = _engine(enc)
     ws, D = eng.ws, eng.D
     B, C, Hh, Ww = x.shape
@@ -61,33 +130,14 @@ def _tokens(enc, x):
     feat = C * P * P
     patches = ws.get("vq.patches", (Rp, ru(feat, 64)), torch.bfloat16)
     L.check(L.vq_patchify(ops._p(x), ops._p(patches), patches.stride(0), B, C, Hh, Ww, P, ops._stream()))
-    # position table tiled over the batch (residual operand of the projection GEMM)
-    key = ("pos", B, nh, nw, enc.pos_emb._version, enc.pos_emb.data_ptr())
-    pos = eng._cache.get(key)
-    if pos is None:
-        pe = enc.pos_emb
-        if pe.shape[-2:] != (nh, nw):
-            pe = F.interpolate(pe, size=(nh, nw), mode="bicubic", align_corners=False)
-        pos = torch.zeros(Rp, D, dtype=torch.float32, device=x.device)
-        pos[:R] = pe[0].permute(1, 2, 0).reshape(G, D).repeat(B, 1)
-        eng._cache = {key: pos}
+    pos = _pos_rows(eng, enc, B, nh, nw, Rp)
     stream = ws.get("vq.x0", (Rp, D), torch.float32)
     ops.gemm_nt(patches, eng.w(enc.proj.weight), stream, epilogue=L.EPI_RESIDUAL, res=pos, bias=enc.proj.bias, M=R, N=D, K=ru(feat, 64))
-    none = dict(mask_kind=L.MASK_NONE)
-    for i, blk in enumerate(enc.blocks):
-        stream = eng.encoder_block_fwd(blk, stream, B, G, none, None, f"vit{i % 2}")
+    if st is not None:
+        st.update(layers=[], patches=patches)
+    stream = _blocks_fwd(eng, enc, stream, B, G, st, "enc" if st is not None else "vit")
     if hasattr(enc, "post_mlp"):
-        # x.float() + fc2(tanh(fc1(norm_mlp(x.float()))))  with autocast DISABLED upstream (vit_models.py:494-496): fp32 operands
-        # on the fp32 matrix cores (fm_gemm_f32: v_mfma_f32_32x32x2_f32, exact fp32) - no bf16 rounding in this tail
-        f32 = torch.float32
-        n = ws.get("vq.n", (Rp, D), f32)
-        ops.layernorm_fwd(stream, enc.norm_mlp.weight, enc.norm_mlp.bias, n, eps=enc.norm_mlp.eps, R=R)
-        hid = enc.post_mlp.fc1.weight.shape[0]
-        t = ws.get("vq.t", (Rp, hid), f32)
-        ops.gemm_nt(n, enc.post_mlp.fc1.weight.detach(), t, epilogue=L.EPI_TANH, bias=enc.post_mlp.fc1.bias, M=R, N=hid, K=D)
-        out = ws.get("vq.post", (Rp, D), f32)
-        ops.gemm_nt(t, enc.post_mlp.fc2.weight.detach(), out, epilogue=L.EPI_RESIDUAL, res=stream, bias=enc.post_mlp.fc2.bias, M=R, N=D, K=hid)
-        stream = out
+        stream = _post_mlp_fwd(eng, enc, stream, R, st, "vq")
     return eng, stream, (B, nh, nw)
 
 
@@ -97,16 +147,9 @@ def encoder_forward(enc, x):
     return stream[: B * nh * nw].view(B, nh, nw, eng.D).permute(0, 3, 1, 2).contiguous()
 
 
-@torch.no_grad()
-def vq_encode(vq, x):
-    enc = vq.encoder
-    eng, stream, (B, nh, nw) = _tokens(enc, x)
-    ws, D, Ld = eng.ws, eng.D, vq.latent_dim
-    G, R = nh * nw, B * nh * nw
-    # 1x1 convolution to the latent dimension: fp32 like the codebook search that follows (the tokenization script runs without
-    # autocast, save_vq_tokens.py; 0.2 % of the FLOPs)
-    z = ws.get("vq.z", (stream.shape[0], Ld), torch.float32)
-    ops.gemm_nt(stream, vq.quant_proj.weight.detach().reshape(Ld, D), z, epilogue=L.EPI_F32, bias=vq.quant_proj.bias, M=R, N=Ld, K=D)
+def _assign(vq, eng, z, R, G, B, nh, nw, want_quant):
+    """Cosine-similarity nearest code of every latent row: tokens (B, nh, nw) int64 [+ quant (B, latent_dim, nh, nw) f32]."""
+    ws, Ld = eng.ws, vq.latent_dim
     cb = vq.quantize._codebook
     K = cb.embed.shape[0]
     # ONE buffer of l2-normalised codes, recomputed in place when the codebook changed (in training mode every encode() moves the
@@ -122,11 +165,222 @@ def vq_encode(vq, x):
     splits = max(1, min(16, K // 1024))
     wv = ws.get("vq.wv", (R, splits), torch.float32)
     wi = ws.get("vq.wi", (R, splits), torch.int32)
-    tokens = torch.empty(B, nh, nw, dtype=torch.int64, device=x.device)
-    quant = torch.empty(B, Ld, nh, nw, dtype=torch.float32, device=x.device)
+    tokens = torch.empty(B, nh, nw, dtype=torch.int64, device=z.device)
+    quant = torch.empty(B, Ld, nh, nw, dtype=torch.float32, device=z.device) if want_quant else None
     # cosine similarity normalises the latents (quantize_lucid.py:394-395); norm_latents only moves that
     # normalisation in front of the (training-time) commitment loss
     L.check(L.vq_assign(ops._p(z), z.stride(0), ops._p(en), ops._p(cb.embed), K, Ld, R, G, 1, ops._p(wv), ops._p(wi), splits,
                         ops._p(tokens), ops._p(quant), ops._stream()))
+    return (tokens, quant) if want_quant else tokens
+
+
+@torch.no_grad()
+def vq_encode(vq, x):
+    enc = vq.encoder
+    eng, stream, (B, nh, nw) = _tokens(enc, x)
+    ws, D, Ld = eng.ws, eng.D, vq.latent_dim
+    G, R = nh * nw, B * nh * nw
+    # 1x1 convolution to the latent dimension: fp32 like the codebook search that follows (the tokenization script runs without
+    # autocast, save_vq_tokens.py; 0.2 % of the FLOPs)
+    z = ws.get("vq.z", (stream.shape[0], Ld), torch.float32)
+    ops.gemm_nt(stream, vq.quant_proj.weight.detach().reshape(Ld, D), z, epilogue=L.EPI_F32, bias=vq.quant_proj.bias, M=R, N=Ld, K=D)
+    tokens, quant = _assign(vq, eng, z, R, G, B, nh, nw, True)
     vq._last_latents = z[:R].view(B, G, Ld)
     return quant, torch.zeros(1, device=x.device), tokens
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# detokenizer (ViTDecoder) and the gradient path of tokenizer training
+#   upstream: VQVAE.decode_quant / forward (vq/vqvae.py:454-481), ViTDecoder.forward (vq/models/vit_models.py:617-648),
+#             VectorQuantize.forward training branch (vq/quantizers/quantize_lucid.py:533-541)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _quant_rows(vq, tokens, dev):
+    """embed[tokens] as GEMM operand rows (R, latent_dim) f32."""
+    cb = vq.quantize._codebook
+    t = tokens.reshape(-1).contiguous()
+    rows = torch.empty(t.numel(), cb.embed.shape[1], dtype=torch.float32, device=dev)
+    L.check(L.embed_rows_f32(ops._p(cb.embed), ops._p(t), ops._p(rows), rows.stride(0), t.numel(), cb.embed.shape[1], ops._stream()))
+    return rows
+
+
+def _decode_rows(vq, q_rows, B, nh, nw, st=None):
+    """Quantised rows (R, latent_dim) f32 -> image (B, C, H, W) f32 through post_quant_proj, the decoder blocks and out_proj."""
+    dec = vq.decoder
+    if not getattr(dec, "patch_proj", True) or hasattr(dec, "out_conv"):
+        raise NotImplementedError("ViTDecoder with patch_proj=False / out_conv=True has no HIP path")
+    eng = _engine(dec)
+    ws, D, Ld = eng.ws, eng.D, vq.latent_dim
+    G, R = nh * nw, B * nh * nw
+    Rp = ru(R, 128)
+    f32 = torch.float32
+    pos = _pos_rows(eng, dec, B, nh, nw, Rp)
+    stream = ws.get("dec.x0", (Rp, D), f32)
+    pq = vq.post_quant_proj
+    # 1x1 convolution latent_dim -> decoder width, fp32 like the quantizer in front of it (K = 32: 0.1 % of the FLOPs), + position table
+    ops.gemm_nt(q_rows, pq.weight.detach().reshape(D, Ld), stream, epilogue=L.EPI_RESIDUAL, res=pos, bias=pq.bias, M=R, N=D, K=Ld)
+    if st is not None:
+        st.update(layers=[], q_rows=q_rows)
+    stream = _blocks_fwd(eng, dec, stream, B, G, st, "dec" if st is not None else "vit")
+    if hasattr(dec, "post_mlp"):
+        stream = _post_mlp_fwd(eng, dec, stream, R, st, "decpost")
+    P, C = dec.P_H, dec.out_channels
+    Fo = C * P * P
+    xb = ws.get("dec.xb", (Rp, D), torch.bfloat16)                      # out_proj runs under autocast: bf16 operands, fp32 result
+    ops.f32_to_bf16(stream, xb)
+    rows = ws.get("dec.rows", (Rp, Fo), f32)
+    ops.gemm_nt(xb, eng.w(dec.out_proj.weight), rows, epilogue=L.EPI_F32, bias=dec.out_proj.bias, M=R, N=Fo, K=D)
+    img = torch.empty(B, C, nh * P, nw * P, dtype=f32, device=q_rows.device)
+    L.check(L.vq_unpatchify(ops._p(rows), rows.stride(0), ops._p(img), B, C, nh * P, nw * P, P, ops._stream()))
+    if st is not None:
+        st.update(xb=xb, x_final=stream)
+    return img
+
+
+@torch.no_grad()
+def vqvae_decode_quant(vq, quant):
+    """(B, latent_dim, h, w) -> (B, C, H, W)   [vqvae.py:454-465]"""
+    B, Ld, nh, nw = quant.shape
+    rows = quant.detach().float().permute(0, 2, 3, 1).reshape(B * nh * nw, Ld).contiguous()
+    return _decode_rows(vq, rows, B, nh, nw)
+
+
+@torch.no_grad()
+def vqvae_decode_tokens(vq, tokens):
+    B, nh, nw = tokens.shape
+    return _decode_rows(vq, _quant_rows(vq, tokens, tokens.device), B, nh, nw)
+
+
+def _post_mlp_bwd(eng, vit, sp, g, g_bf, R):
+    """Backward of x + fc2(tanh(fc1(norm_mlp(x)))) in fp32.  g (Rp, D) f32: in = d(out), out = d(x); g_bf receives the bf16 copy."""
+    ws, f32, D = eng.ws, torch.float32, eng.D
+    fc1, fc2 = vit.post_mlp.fc1, vit.post_mlp.fc2
+    hid = fc1.weight.shape[0]
+    if fc2.weight.requires_grad:
+        ops.gemm_tn(g, sp["t"], eng.grad_view(fc2.weight), N=D, K=hid, R=R)
+        ops.colsum(g, eng.grad_view(fc2.bias), D, R=R)
+    dt = ws.get("bwd.post.dt", tuple(sp["t"].shape), f32)
+    ops.gemm_nt(g, fc2.weight.detach().t(), dt, epilogue=L.EPI_F32, M=R, N=hid, K=D)
+    L.check(L.tanh_bwd_f32(ops._p(dt), ops._p(sp["t"]), ops._p(dt), R, hid, dt.stride(0), ops._stream()))
+    if fc1.weight.requires_grad:
+        ops.gemm_tn(dt, sp["n"], eng.grad_view(fc1.weight), N=hid, K=D, R=R)
+        ops.colsum(dt, eng.grad_view(fc1.bias), hid, R=R)
+    dn = ws.get("bwd.post.dn", tuple(g.shape), f32)
+    ops.gemm_nt(dt, fc1.weight.detach().t(), dn, epilogue=L.EPI_F32, M=R, N=D, K=hid)
+    nm = vit.norm_mlp
+    # (the fp32 LayerNorm backward writes its second copy in fp32 too - it serves the verification mode: convert separately)
+    ops.layernorm_bwd(dn, sp["x"], nm.weight, sp["mu"], sp["rs"], g, dres=g, dw=eng._g(nm.weight), db=eng._g(nm.bias), R=R)
+    ops.f32_to_bf16(g, g_bf)
+
+
+def _blocks_bwd(eng, vit, st, g, g_bf, B, G):
+    none = dict(mask_kind=L.MASK_NONE)
+    for i in reversed(range(len(vit.blocks))):
+        eng.encoder_block_bwd(vit.blocks[i], st["layers"][i], g, g_bf, B, G, none)
+
+
+def vqvae_train_forward(vq, x):
+    """Training forward of the VQ-VAE: returns (dec (B, C, H, W) f32, code_loss (1,) f32, saved state)."""
+    enc = vq.encoder
+    trainable_enc = any(p.requires_grad for p in enc.parameters()) or vq.quant_proj.weight.requires_grad
+    st = dict(enc={} if trainable_enc else None, dec={})
+    if enc.pos_emb.requires_grad or vq.decoder.pos_emb.requires_grad:
+        raise NotImplementedError("learnable position embeddings have no gradient kernel (learnable_pos_emb=False upstream default)")
+    eng, stream, (B, nh, nw) = _tokens(enc, x, st["enc"])
+    ws, D, Ld = eng.ws, eng.D, vq.latent_dim
+    G, R = nh * nw, B * nh * nw
+    z = ws.get("vq.z", (stream.shape[0], Ld), torch.float32)
+    ops.gemm_nt(stream, vq.quant_proj.weight.detach().reshape(Ld, D), z, epilogue=L.EPI_F32, bias=vq.quant_proj.bias, M=R, N=Ld, K=D)
+    if vq.quantize.norm_latents:
+        raise NotImplementedError("norm_latents=True: the l2-normalisation in front of the commitment loss has no backward kernel")
+    tokens = _assign(vq, eng, z, R, G, B, nh, nw, None)
+    q_rows = _quant_rows(vq, tokens, x.device)
+    cw = float(vq.quantize.commitment_weight)
+    code_loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+    cb = vq.quantize._codebook
+    if cw > 0:
+        L.check(L.vq_latent_grad(ops._p(z), z.stride(0), ops._p(cb.embed), ops._p(tokens.reshape(-1)), None, 0, None, cw, None, 0,
+                                 ops._p(code_loss), R, Ld, ops._stream()))
+    dec = _decode_rows(vq, q_rows, B, nh, nw, st["dec"])
+    st.update(z=z, tokens=tokens, x_enc_final=stream, dims=(B, nh, nw), embed_at_forward=cb.embed.clone() if vq.quantize.training else cb.embed)
+    if vq.quantize.training:
+        cb.ema_update_(z[:R], tokens)                      # after the code assignment, as upstream (quantize_lucid.py:409-426)
+    return dec, code_loss, st
+
+
+def vqvae_train_backward(vq, st, g_dec, g_loss):
+    """d(objective)/d(dec) (B, C, H, W) and d(objective)/d(code_loss) -> parameter gradients (accumulated, then attached as .grad)."""
+    dec, enc = vq.decoder, vq.encoder
+    B, nh, nw = st["dims"]
+    G, R = nh * nw, B * nh * nw
+    de = _engine(dec)
+    params = [p for p in vq.parameters()]
+    de.open_window(list(dec.parameters()) + list(vq.post_quant_proj.parameters()))
+    ws, D, Ld, f32, bf = de.ws, de.D, vq.latent_dim, torch.float32, torch.bfloat16
+    Rp = ru(R, 128)
+    sd = st["dec"]
+    P, C = dec.P_H, dec.out_channels
+    Fo = C * P * P
+    # ---- out_proj ------------------------------------------------------------------------------------------------------------------
+    drow = ws.get("bwd.drow", (Rp, ru(Fo, 64)), bf)
+    gd = (g_dec if g_dec is not None else torch.zeros(B, C, nh * P, nw * P, device=sd["xb"].device)).float().contiguous()
+    L.check(L.vq_patchify(ops._p(gd), ops._p(drow), drow.stride(0), B, C, nh * P, nw * P, P, ops._stream()))
+    de._dW(drow, sd["xb"], dec.out_proj, R, n_cols=Fo)
+    g_bf = ws.get("bwd.g_bf", (Rp, D), bf)
+    g = ws.get("bwd.g", (Rp, D), f32)
+    ops.gemm_nt(drow, de.wt(dec.out_proj.weight), g_bf, M=R, N=D, K=ru(Fo, 64))
+    ops.bf16_to_f32_scaled(g_bf, g)
+    if hasattr(dec, "post_mlp"):
+        _post_mlp_bwd(de, dec, sd["post"], g, g_bf, R)
+    _blocks_bwd(de, dec, sd, g, g_bf, B, G)
+    # ---- post_quant_proj (fp32) --------------------------------------------------------------------------------------------------------
+    pq = vq.post_quant_proj
+    if pq.weight.requires_grad:
+        ops.gemm_tn(g, sd["q_rows"], de.grad_view(pq.weight).view(D, Ld), N=D, K=Ld, R=R)
+        ops.colsum(g, de.grad_view(pq.bias), D, R=R)
+    de.attach(list(dec.parameters()) + list(pq.parameters()))
+    se = st["enc"]
+    if se is None:
+        return
+    ee = _engine(enc)
+    ee.open_window(list(enc.parameters()) + list(vq.quant_proj.parameters()))
+    ews, De = ee.ws, ee.D
+    dq = ws.get("bwd.dq", (Rp, Ld), f32)
+    ops.gemm_nt(g, pq.weight.detach().reshape(D, Ld).t(), dq, epilogue=L.EPI_F32, M=R, N=Ld, K=D)
+    # ---- quantizer: straight-through + commitment term (against the codebook the forward used) ---------------------------------------
+    z, tokens = st["z"], st["tokens"]
+    dz = ews.get("bwd.dz", tuple(z.shape), f32)
+    gl = None if g_loss is None else g_loss.reshape(1).float().contiguous()
+    L.check(L.vq_latent_grad(ops._p(z), z.stride(0), ops._p(st["embed_at_forward"]), ops._p(tokens.reshape(-1)), ops._p(dq), dq.stride(0), ops._p(gl),
+                             float(vq.quantize.commitment_weight), ops._p(dz), dz.stride(0), None, R, Ld, ops._stream()))
+    # ---- quant_proj (fp32) -------------------------------------------------------------------------------------------------------------
+    qp = vq.quant_proj
+    xf = st["x_enc_final"]
+    if qp.weight.requires_grad:
+        ops.gemm_tn(dz, xf, ee.grad_view(qp.weight).view(Ld, De), N=Ld, K=De, R=R)
+        ops.colsum(dz, ee.grad_view(qp.bias), Ld, R=R)
+    ge = ews.get("bwd.g", (xf.shape[0], De), f32)
+    ge_bf = ews.get("bwd.g_bf", (xf.shape[0], De), bf)
+    ops.gemm_nt(dz, qp.weight.detach().reshape(Ld, De).t(), ge, epilogue=L.EPI_F32, M=R, N=De, K=Ld)
+    if hasattr(enc, "post_mlp"):
+        _post_mlp_bwd(ee, enc, se["post"], ge, ge_bf, R)
+    else:
+        ops.f32_to_bf16(ge, ge_bf)
+    _blocks_bwd(ee, enc, se, ge, ge_bf, B, G)
+    ee._dW(ge_bf, se["patches"], enc.proj, R)
+    ee.attach(list(enc.parameters()) + list(qp.parameters()))
+
+
+class VQVAEStep(torch.autograd.Function):
+    """Bridges the hand-written backward into autograd: ``dec, code_loss = VQVAE.forward(x)`` are leaves of the caller's loss graph."""
+
+    @staticmethod
+    def forward(ctx, anchor, vq, x):
+        dec, code_loss, st = vqvae_train_forward(vq, x)
+        ctx.vq, ctx.st = vq, st
+        return dec, code_loss
+
+    @staticmethod
+    def backward(ctx, g_dec, g_loss):
+        vqvae_train_backward(ctx.vq, ctx.st, g_dec, g_loss)
+        ctx.st = None
+        return None, None, None

@@ -1,7 +1,8 @@
 """``VQ``: tokenizer front half (image -> ViT encoder -> 1x1 projection -> nearest code), API of upstream
 ``fourm/vq/vqvae.py`` (``VQ`` :39-331: constructor arguments, ``encode`` / ``tokenize`` / ``tokens_to_embedding``,
-state_dict keys).  Forward only: in training mode ``encode`` also runs the quantizer's EMA codebook update; decoders, diffusion and the
-gradient path of tokenizer training are out of scope.
+state_dict keys), and ``VQVAE`` (:396-495): the ViT decoder behind the codebook (``decode_quant`` / ``decode_tokens`` / ``autoencode``)
+and the gradient path of tokenizer training (``forward`` in training mode returns autograd-connected ``dec, code_loss``; the backward is
+hand-written, fourm/vq/engine.py).  The diffusion decoders (DiVAE, VQControlNet: UNet + schedulers from ``diffusers``) are out of scope.
 
 Precision = upstream's autocast arithmetic: the 12 ViT blocks with bf16 GEMM operands (fp32 accumulate, fp32 residual /
 LayerNorm / softmax); the tanh post-MLP, the 1x1 projection and the codebook search in exact fp32 (upstream disables
@@ -81,13 +82,16 @@ class VQ(nn.Module, PyTorchModelHubMixin):
     def prepare_input(self, x: torch.Tensor) -> torch.Tensor:
         return x
 
-    @torch.no_grad()
     def encode(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.LongTensor]:
-        """(quant (B, latent_dim, h, w) f32, code_loss (1,) zeros, tokens (B, h, w) int64)   [vqvae.py:302-318]"""
+        """(quant (B, latent_dim, h, w) f32, code_loss (1,), tokens (B, h, w) int64)   [vqvae.py:302-318]"""
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("VQ.encode has no gradient path by itself (upstream trains the tokenizer through VQVAE.forward): use "
+                                      "VQVAE.forward, run under torch.no_grad(), freeze the parameters or call .eval()")
+        with torch.no_grad():
+            return self._encode(x)
+
+    def _encode(self, x):
         from .engine import vq_encode
-        if self.training and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("the gradient path of tokenizer training (commitment loss into the encoder) is out of scope; "
-                                      "freeze the parameters (the EMA codebook update still runs in training mode) or call .eval()")
         quant, loss, tokens = vq_encode(self, self.prepare_input(x))
         if self.training and self.quantize.training:
             # upstream's training-mode quantizer: EMA codebook update + the commitment term's VALUE (quantize_lucid.py:409-426, :540-548)
@@ -107,6 +111,60 @@ class VQ(nn.Module, PyTorchModelHubMixin):
 
     def forward(self, x: torch.Tensor):
         return self.encode(x)
+
+
+class VQVAE(VQ):
+    """Encoder + discrete bottleneck + ViT decoder (upstream ``VQVAE``, vqvae.py:396-495): same constructor, state_dict keys
+    (``decoder.*``, ``post_quant_proj.*``) and methods.  In training mode ``forward`` is differentiable: ``dec`` and ``code_loss`` carry a
+    hand-written backward (straight-through estimator + commitment term into the encoder, vq/quantizers/quantize_lucid.py:533-541)."""
+
+    def __init__(self, dec_type: str = "vit_b_dec", out_conv: bool = False, image_size_dec: int = None, patch_size_dec: int = None,
+                 config: Optional[Dict[str, Any]] = None, *args, **kwargs):
+        if config is not None:
+            self.__init__(**copy.deepcopy(config))
+            return
+        ckpt_path = kwargs.get("ckpt_path", None)                 # (loaded once the decoder exists)
+        kwargs["ckpt_path"] = None
+        super().__init__(*args, **kwargs)
+        self.ckpt_path = ckpt_path
+        if "vit" not in dec_type or not hasattr(vit_models, dec_type):
+            raise NotImplementedError(f"{dec_type} not implemented.")
+        self.dec_type, self.out_conv = dec_type, out_conv
+        self.decoder = getattr(vit_models, dec_type)(out_channels=self.n_channels, patch_size=patch_size_dec or self.patch_size,
+                                                     resolution=image_size_dec or self.image_size, out_conv=out_conv, post_mlp=self.post_mlp,
+                                                     patch_proj=self.patch_proj)
+        self.dec_dim = self.decoder.dim_tokens
+        self.post_quant_proj = torch.nn.Conv2d(self.latent_dim, self.dec_dim, 1)
+        if self.ckpt_path is not None:
+            self.init_from_ckpt(self.ckpt_path, ignore_keys=self.ignore_keys)
+
+    @torch.no_grad()
+    def decode_quant(self, quant: torch.Tensor, **kwargs) -> torch.Tensor:
+        from .engine import vqvae_decode_quant
+        return vqvae_decode_quant(self, quant)
+
+    @torch.no_grad()
+    def decode_tokens(self, tokens: torch.LongTensor, **kwargs) -> torch.Tensor:
+        from .engine import vqvae_decode_tokens
+        return vqvae_decode_tokens(self, tokens)
+
+    def forward(self, x: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(dec (B, C, H, W), code_loss (1,))   [vqvae.py:467-481]"""
+        from .engine import VQVAEStep, vqvae_train_forward
+        x = self.prepare_input(x)
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if needs_grad:
+            return VQVAEStep.apply(self.post_quant_proj.weight, self, x)
+        with torch.no_grad():
+            dec, code_loss, _ = vqvae_train_forward(self, x) if self.training else (*self._eval_forward(x), None)
+        return dec, code_loss
+
+    def _eval_forward(self, x):
+        quant, code_loss, tokens = self.encode(x)
+        return self.decode_tokens(tokens), code_loss
+
+    def autoencode(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
+        return self.forward(x)[0]
 
 
 # names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)

@@ -6,8 +6,12 @@ fourm_oracle.py for the rules).  Functional fp32 PyTorch restatement of
     VectorQuantize.forward ... fourm/vq/quantizers/quantize_lucid.py:504-568 (eval branch)
     CosineSimCodebook.forward  fourm/vq/quantizers/quantize_lucid.py:388-407
 
-Parity status: PINNED by tests/golden/make_golden_vq.py against the unmodified upstream ``VQ`` (same seeded
-weights and images): tokens identical, latents to 1e-5."""
+    VQVAE.forward ............ fourm/vq/vqvae.py:454-481 (training branch of the quantizer: quantize_lucid.py:533-541)
+    ViTDecoder.forward ....... fourm/vq/models/vit_models.py:617-648
+
+Parity status: PINNED by tests/golden/make_golden_vq.py against the unmodified upstream ``VQ`` / ``VQVAE`` (same seeded
+weights and images): tokens identical, latents to 1e-5; VQVAE reconstruction, code loss and every parameter gradient (torch autograd
+through this restatement vs autograd through upstream) to 1e-5."""
 import math
 from dataclasses import dataclass
 from typing import Dict
@@ -80,6 +84,28 @@ def synthetic_images(cfg: VQCfg, batch: int, seed: int = 0) -> Tensor:
     return torch.rand(batch, cfg.channels, cfg.image, cfg.image, generator=g) * 2 - 1
 
 
+def vit_stack(P, pre0, t, dim, depth, heads, eps, post_mlp, num, tail):
+    """The transformer blocks (+ tanh post-MLP) shared by ViTEncoder and ViTDecoder (Block :243-246; :494-496 / :635-636)."""
+    B = t.shape[0]
+    hd = dim // heads
+    for i in range(depth):
+        pre = f"{pre0}.blocks.{i}"
+        h = num.layer_norm(t, P[pre + ".norm1.weight"], P[pre + ".norm1.bias"], eps)
+        qkv = num.linear(h, P[pre + ".attn.qkv.weight"], P[pre + ".attn.qkv.bias"])
+        q, k, v = [a.reshape(B, -1, heads, hd).transpose(1, 2) for a in qkv.chunk(3, -1)]
+        s = num.r(num.r(num.r(q) @ num.r(k).transpose(-1, -2)) * hd ** -0.5)
+        o = num.r(num.r(torch.softmax(s, -1)) @ num.r(v)).transpose(1, 2).reshape(B, -1, dim)
+        t = t + num.linear(o, P[pre + ".attn.proj.weight"], P[pre + ".attn.proj.bias"])
+        h = num.layer_norm(t, P[pre + ".norm2.weight"], P[pre + ".norm2.bias"], eps)
+        h = num.act(num.linear(h, P[pre + ".mlp.fc1.weight"], P[pre + ".mlp.fc1.bias"]), "gelu")
+        t = t + num.linear(h, P[pre + ".mlp.fc2.weight"], P[pre + ".mlp.fc2.bias"])
+    if post_mlp:
+        h = tail.layer_norm(t, P[pre0 + ".norm_mlp.weight"], P[pre0 + ".norm_mlp.bias"], eps)
+        h = tail.r(torch.tanh(tail.linear(h, P[pre0 + ".post_mlp.fc1.weight"], P[pre0 + ".post_mlp.fc1.bias"])))
+        t = t + tail.linear(h, P[pre0 + ".post_mlp.fc2.weight"], P[pre0 + ".post_mlp.fc2.bias"])
+    return t
+
+
 def vq_encode(P: Dict[str, Tensor], cfg: VQCfg, x: Tensor, emulate_bf16: bool = False):
     """Returns (quant (B, L, h, w), tokens (B, h, w) int64, latents z (B, h*w, L) before normalisation).
     ``emulate_bf16`` rounds at upstream's autocast points: the patch projection and the 12 blocks.  The post-MLP (autocast
@@ -91,22 +117,7 @@ def vq_encode(P: Dict[str, Tensor], cfg: VQCfg, x: Tensor, emulate_bf16: bool = 
     patches = x.reshape(B, C, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * p * p)
     t = num.linear(patches, P["encoder.proj.weight"].reshape(cfg.dim, -1), P["encoder.proj.bias"])
     t = t + P["encoder.pos_emb"][0].permute(1, 2, 0).reshape(g * g, cfg.dim)
-    hd = cfg.dim // cfg.heads
-    for i in range(cfg.depth):
-        pre = f"encoder.blocks.{i}"
-        h = num.layer_norm(t, P[pre + ".norm1.weight"], P[pre + ".norm1.bias"], cfg.eps)
-        qkv = num.linear(h, P[pre + ".attn.qkv.weight"], P[pre + ".attn.qkv.bias"])
-        q, k, v = [a.reshape(B, -1, cfg.heads, hd).transpose(1, 2) for a in qkv.chunk(3, -1)]
-        s = num.r(num.r(num.r(q) @ num.r(k).transpose(-1, -2)) * hd ** -0.5)
-        o = num.r(num.r(torch.softmax(s, -1)) @ num.r(v)).transpose(1, 2).reshape(B, -1, cfg.dim)
-        t = t + num.linear(o, P[pre + ".attn.proj.weight"], P[pre + ".attn.proj.bias"])
-        h = num.layer_norm(t, P[pre + ".norm2.weight"], P[pre + ".norm2.bias"], cfg.eps)
-        h = num.act(num.linear(h, P[pre + ".mlp.fc1.weight"], P[pre + ".mlp.fc1.bias"]), "gelu")
-        t = t + num.linear(h, P[pre + ".mlp.fc2.weight"], P[pre + ".mlp.fc2.bias"])
-    if cfg.post_mlp:
-        h = tail.layer_norm(t, P["encoder.norm_mlp.weight"], P["encoder.norm_mlp.bias"], cfg.eps)
-        h = tail.r(torch.tanh(tail.linear(h, P["encoder.post_mlp.fc1.weight"], P["encoder.post_mlp.fc1.bias"])))
-        t = t + tail.linear(h, P["encoder.post_mlp.fc2.weight"], P["encoder.post_mlp.fc2.bias"])
+    t = vit_stack(P, "encoder", t, cfg.dim, cfg.depth, cfg.heads, cfg.eps, cfg.post_mlp, num, tail)
     wq = P["quant_proj.weight"].reshape(cfg.latent, cfg.dim)
     z = tail.r(t) @ tail.r(wq).t() + P["quant_proj.bias"]
     tokens, quant = assign_codes(z, P["quantize._codebook.embed"])
@@ -151,3 +162,60 @@ def codebook_ema_update(embed: Tensor, cluster_size: Tensor, z: Tensor, ind: Ten
         if bool(dead.any()):
             new_embed[dead] = replace_rows
     return new_embed, cluster
+
+
+# ---- VQ-VAE: decoder + training-mode quantizer ---------------------------------------------------------------------
+DEC_DIMS = {"vit_s_dec": (512, 8, 8), "vit_b_dec": (768, 12, 12), "vit_l_dec": (1024, 24, 16)}
+
+
+def seeded_vqvae_state_dict(cfg: VQCfg, dec_type: str, seed: int = 0) -> Dict[str, Tensor]:
+    """Encoder / quantizer as seeded_vq_state_dict + ``decoder.*`` and ``post_quant_proj.*`` in upstream's state_dict layout."""
+    sd = seeded_vq_state_dict(cfg, seed)
+    D, depth, _ = DEC_DIMS[dec_type]
+    Hd, g = int(D * cfg.mlp_ratio), cfg.grid
+
+    def lin(pre, o, i):
+        sd[pre + ".weight"] = seeded_tensor(pre + ".weight", (o, i), 1.0 / math.sqrt(i), seed)
+        sd[pre + ".bias"] = seeded_tensor(pre + ".bias", (o,), 0.02, seed)
+
+    def norm(pre):
+        sd[pre + ".weight"] = 1.0 + seeded_tensor(pre + ".weight", (D,), 0.1, seed)
+        sd[pre + ".bias"] = seeded_tensor(pre + ".bias", (D,), 0.05, seed)
+    sd["decoder.pos_emb"] = sincos_2d(g, g, D).reshape(g, g, D).permute(2, 0, 1)[None].contiguous()
+    for i in range(depth):
+        p = f"decoder.blocks.{i}"
+        norm(p + ".norm1"); norm(p + ".norm2")
+        lin(p + ".attn.qkv", 3 * D, D); lin(p + ".attn.proj", D, D)
+        lin(p + ".mlp.fc1", Hd, D); lin(p + ".mlp.fc2", D, Hd)
+    if cfg.post_mlp:
+        norm("decoder.norm_mlp")
+        lin("decoder.post_mlp.fc1", Hd, D); lin("decoder.post_mlp.fc2", D, Hd)
+    lin("decoder.out_proj", cfg.channels * cfg.patch * cfg.patch, D)
+    sd["post_quant_proj.weight"] = seeded_tensor("post_quant_proj.weight", (D, cfg.latent, 1, 1), 1.0 / math.sqrt(cfg.latent), seed)
+    sd["post_quant_proj.bias"] = seeded_tensor("post_quant_proj.bias", (D,), 0.02, seed)
+    return sd
+
+
+def vqvae_decode(P, cfg: VQCfg, dec_type: str, quant: Tensor, emulate_bf16: bool = False) -> Tensor:
+    """quant (B, L, h, w) -> image (B, C, H, W)   [VQVAE.decode_quant :454-465, ViTDecoder.forward :617-648]"""
+    num, tail = _Num(emulate_bf16), _Num(False)
+    D, depth, heads = DEC_DIMS[dec_type]
+    B, Ld, g, _ = quant.shape
+    t = quant.permute(0, 2, 3, 1).reshape(B, g * g, Ld) @ P["post_quant_proj.weight"].reshape(D, Ld).t() + P["post_quant_proj.bias"]
+    t = t + P["decoder.pos_emb"][0].permute(1, 2, 0).reshape(g * g, D)
+    t = vit_stack(P, "decoder", t, D, depth, heads, cfg.eps, cfg.post_mlp, num, tail)
+    rows = num.linear(t, P["decoder.out_proj.weight"], P["decoder.out_proj.bias"]).float()
+    p, C = cfg.patch, cfg.channels
+    return rows.reshape(B, g, g, C, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B, C, g * p, g * p)
+
+
+def vqvae_forward(P, cfg: VQCfg, dec_type: str, x: Tensor, commitment_weight: float = 1.0, emulate_bf16: bool = False):
+    """Training-mode ``VQVAE.forward``: (dec, code_loss (1,), tokens).  Differentiable w.r.t. P: the quantised code passes its gradient
+    straight to the latents (quantize = z + (q - z).detach()) and code_loss = w * mse(q.detach(), z)   [quantize_lucid.py:533-541]."""
+    _, tokens, z = vq_encode(P, cfg, x, emulate_bf16)
+    B, g = x.shape[0], x.shape[2] // cfg.patch
+    q = P["quantize._codebook.embed"][tokens.reshape(B, -1)].detach()
+    quant = z + (q - z).detach()
+    code_loss = (F.mse_loss(q, z) * commitment_weight).reshape(1)
+    dec = vqvae_decode(P, cfg, dec_type, quant.reshape(B, g, g, cfg.latent).permute(0, 3, 1, 2), emulate_bf16)
+    return dec, code_loss, tokens

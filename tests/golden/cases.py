@@ -86,3 +86,9 @@ VQ_CASES = {
     "vq_small": dict(enc_type="vit_s_enc", image=64, patch=16, codebook=512, post_mlp=True, batch=3, seed=2),
     "vq_rgb224": dict(enc_type="vit_b_enc", image=224, patch=16, codebook=16384, post_mlp=True, batch=2, seed=0),
 }
+
+# VQ-VAE (decoder + tokenizer training step)
+VQVAE_CASES = {
+    "vqvae_small": dict(enc_type="vit_s_enc", dec_type="vit_s_dec", image=64, patch=16, codebook=512, post_mlp=True, batch=3, seed=2, commitment_weight=1.0),
+    "vqvae_b224": dict(enc_type="vit_b_enc", dec_type="vit_b_dec", image=224, patch=16, codebook=16384, post_mlp=False, batch=2, seed=5, commitment_weight=0.25),
+}
