@@ -152,6 +152,8 @@ def _assign(vq, eng, z, R, G, B, nh, nw, want_quant):
     ws, Ld = eng.ws, vq.latent_dim
     cb = vq.quantize._codebook
     K = cb.embed.shape[0]
+    if not bool(cb.initted):                                 # kmeans_init=True: the first batch initialises the codebook (quantize_lucid.py:394)
+        cb.init_embed_(z[:R])
     # ONE buffer of l2-normalised codes, recomputed in place when the codebook changed (in training mode every encode() moves the
     # codebook: a cache keyed on its version would keep every past copy alive)
     stamp = (cb.embed._version, cb.embed.data_ptr(), getattr(cb, "epoch", 0), tuple(cb.embed.shape))

@@ -1,7 +1,8 @@
 """Codebook containers in the upstream layout (``fourm/vq/quantizers/quantize_lucid.py``: ``CosineSimCodebook``
 :303-428, ``VectorQuantize`` :432-568): nearest code by cosine similarity, ``quantize = embed[index]``, and in training mode the
-EMA codebook update with dead-code replacement (``CosineSimCodebook.ema_update_``: fm_vq_code_stats + fm_vq_ema_update).  The
-gradient path of tokenizer training (commitment loss into the encoder, decoders) is out of scope."""
+EMA codebook update with dead-code replacement (``CosineSimCodebook.ema_update_``: fm_vq_code_stats + fm_vq_ema_update) and the k-means
+codebook initialisation (``init_embed_``, upstream ``kmeans`` :137-167).  The straight-through / commitment gradient of tokenizer training
+lives in fourm/vq/engine.py (fm_vq_latent_grad)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -13,7 +14,7 @@ class CosineSimCodebook(nn.Module):
         super().__init__()
         if learnable_codebook or sample_codebook_temp:
             raise NotImplementedError("learnable / sampled codebooks are not implemented")
-        self.decay, self.codebook_size, self.eps = decay, codebook_size, eps
+        self.decay, self.codebook_size, self.eps, self.kmeans_iters = decay, codebook_size, eps, kmeans_iters
         self.threshold_ema_dead_code, self.code_replacement_policy, self.use_ddp = threshold_ema_dead_code, code_replacement_policy, use_ddp
         self.epoch = 0                       # bumped by every in-place codebook update (derived copies are keyed on it)
         if kmeans_init:
@@ -27,6 +28,53 @@ class CosineSimCodebook(nn.Module):
         self.register_buffer("embed", embed)
 
 
+    def _assign(self, z, normalized_codes):
+        """tokens (R) int64 = argmax_c <l2norm(z[r]), normalized_codes[c]> (first maximum), through fm_vq_assign."""
+        from fourm.hip import _lib as L, ops
+        K, D = normalized_codes.shape
+        R = z.shape[0]
+        splits = max(1, min(16, K // 1024))
+        wv = torch.empty(R, splits, dtype=torch.float32, device=z.device)
+        wi = torch.empty(R, splits, dtype=torch.int32, device=z.device)
+        tokens = torch.empty(R, dtype=torch.int64, device=z.device)
+        L.check(L.vq_assign(ops._p(z), z.stride(0), ops._p(normalized_codes), ops._p(normalized_codes), K, D, R, 1, 1, ops._p(wv), ops._p(wi), splits,
+                            ops._p(tokens), None, ops._stream()))
+        return tokens
+
+    @torch.no_grad()
+    def init_embed_(self, z, generator=None, init_index=None):
+        """k-means initialisation of the codebook from the first batch of latents (upstream ``init_embed_`` :330-341 -> ``kmeans`` :137-167
+        with cosine similarity): means = K random l2-normalised latents, then ``kmeans_iters`` rounds of  assign (argmax of the cosine) ->
+        per-cluster mean -> l2norm, empty clusters keeping their mean.  Each round is the three kernels of the training step
+        (fm_vq_assign, fm_vq_code_stats, fm_vq_ema_update with decay 0).  z: f32 (R, d) raw latents."""
+        import torch.distributed as dist
+        from fourm.hip import _lib as L, ops
+        if bool(self.initted):
+            return
+        multi = self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        z = z.reshape(-1, z.shape[-1]).float().contiguous()
+        K, D = self.embed.shape
+        R = z.shape[0]
+        if init_index is None:
+            if multi:
+                raise NotImplementedError("distributed sampling of the initial means (sample_vectors_distributed) is not implemented: pass init_index")
+            init_index = torch.randperm(R, device=z.device, generator=generator)[:K] if R >= K else torch.randint(0, R, (K,), device=z.device, generator=generator)
+        zn = torch.empty_like(z)
+        L.check(L.l2norm_rows(ops._p(z), z.stride(0), ops._p(zn), zn.stride(0), R, D, ops._stream()))
+        idx = init_index.to(device=z.device, dtype=torch.int64).contiguous()
+        L.check(L.embed_rows_f32(ops._p(zn), ops._p(idx), ops._p(self.embed), self.embed.stride(0), K, D, ops._stream()))
+        bins = torch.empty(K, dtype=torch.float32, device=z.device)
+        sums = torch.empty(K, D, dtype=torch.float32, device=z.device)
+        for _ in range(self.kmeans_iters):
+            tokens = self._assign(z, self.embed)                          # (the means are unit vectors from the first round on)
+            L.check(L.vq_code_stats(ops._p(z), z.stride(0), ops._p(tokens), R, D, K, ops._p(bins), ops._p(sums), ops._stream()))
+            if multi:
+                dist.all_reduce(bins)
+                dist.all_reduce(sums)
+            L.check(L.vq_ema_update(ops._p(bins), ops._p(sums), ops._p(self.embed), ops._p(self.cluster_size), K, D, 0.0, ops._stream()))
+        self.initted.fill_(1.0)
+        self.epoch += 1
+
     @torch.no_grad()
     def ema_update_(self, z, tokens, generator=None):
         """Training-mode branch of upstream ``forward`` after the code assignment (quantize_lucid.py:409-426): per-code counts and
@@ -36,7 +84,7 @@ class CosineSimCodebook(nn.Module):
         import torch.distributed as dist
         from fourm.hip import _lib as L, ops
         if not bool(self.initted):
-            raise NotImplementedError("k-means codebook initialisation is not implemented (load or initialise the codebook first)")
+            raise RuntimeError("the codebook is not initialised: init_embed_ runs in front of the first code assignment")
         z = z.reshape(-1, z.shape[-1])
         if z.dtype != torch.float32 or z.stride(1) != 1:
             z = z.float().contiguous()

@@ -219,3 +219,19 @@ def vqvae_forward(P, cfg: VQCfg, dec_type: str, x: Tensor, commitment_weight: fl
     code_loss = (F.mse_loss(q, z) * commitment_weight).reshape(1)
     dec = vqvae_decode(P, cfg, dec_type, quant.reshape(B, g, g, cfg.latent).permute(0, 3, 1, 2), emulate_bf16)
     return dec, code_loss, tokens
+
+
+def kmeans_cosine(samples: Tensor, init_index: Tensor, num_iters: int = 10):
+    """Upstream ``kmeans`` (quantize_lucid.py:137-167) with use_cosine_sim=True and the sampled initial means made explicit
+    (``means = samples[init_index]`` for sample_fn).  samples: l2-normalised rows.  Returns (means (K, d), bins (K) int64)."""
+    means = samples[init_index]
+    K, d = means.shape
+    bins = None
+    for _ in range(num_iters):
+        buckets = (samples @ means.t()).argmax(-1)
+        bins = torch.bincount(buckets, minlength=K)
+        zero = bins == 0
+        new = torch.zeros(K, d, dtype=samples.dtype).scatter_add_(0, buckets[:, None].expand(-1, d), samples)
+        new = F.normalize(new / bins.masked_fill(zero, 1)[:, None], p=2, dim=-1)
+        means = torch.where(zero[:, None], means, new)
+    return means, bins

@@ -178,3 +178,76 @@ def test_training_mode_encode_updates_the_codebook():
         for p in vq.parameters():
             p.requires_grad = True
         vq.train().encode(x.cuda())
+
+
+# ---- k-means codebook initialisation (kmeans_init=True) ---------------------------------------------------------------------------------
+def _clustered(K, per, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    centres = torch.nn.functional.normalize(torch.randn(K, d, generator=g), dim=-1)
+    pts = centres.repeat_interleave(per, 0) + 0.02 * torch.randn(K * per, d, generator=g)
+    pts = pts * (0.5 + torch.rand(K * per, 1, generator=g))             # raw latents: arbitrary norms
+    perm = torch.randperm(K * per, generator=g)
+    return pts[perm].contiguous()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not on this machine")
+def test_kmeans_oracle_matches_upstream():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r'''
+import sys, os
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, ROOT)
+import ref_stubs; ref_stubs.install()
+import torch
+from fourm.vq.quantizers.quantize_lucid import kmeans, l2norm
+from oracle import vq_oracle as V
+from tests.test_vq import _clustered
+for K, per, seed in ((16, 20, 0), (64, 3, 1), (8, 2, 2)):
+    x = l2norm(_clustered(K, per, 32, seed))
+    idx = torch.randperm(x.shape[0], generator=torch.Generator().manual_seed(seed))[:K + 3]
+    ref, rb = kmeans(x, K + 3, 10, use_cosine_sim=True, sample_fn=lambda s, n: s[idx])
+    got, gb = V.kmeans_cosine(x, idx, 10)
+    assert torch.equal(rb, gb) and torch.allclose(ref, got, atol=1e-6), (K, per)
+    print("ok")
+'''
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    p = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + child], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert p.stdout.count("ok") == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,per", [(64, 12), (2048, 4)])
+def test_kmeans_init_matches_oracle(K, per):
+    from fourm.vq.quantizers.quantize_lucid import CosineSimCodebook
+    z = _clustered(K, per, 32, seed=K)
+    cb = CosineSimCodebook(dim=32, codebook_size=K, kmeans_init=True, kmeans_iters=10).cuda()
+    assert not bool(cb.initted) and float(cb.embed.abs().sum()) == 0.0
+    idx = torch.randperm(z.shape[0], generator=torch.Generator().manual_seed(3))[:K]
+    cb.init_embed_(z.cuda(), init_index=idx)
+    means, bins = V.kmeans_cosine(torch.nn.functional.normalize(z, dim=-1), idx, 10)
+    assert bool(cb.initted)
+    assert torch.equal(cb.cluster_size.cpu().long(), bins)                          # well separated clusters: the same partition
+    assert float((cb.embed.cpu() - means).abs().max()) < 5e-6
+    cb.init_embed_(torch.zeros_like(z).cuda())                                      # initialised: a second call is a no-op
+    assert float((cb.embed.cpu() - means).abs().max()) < 5e-6
+
+
+@pytest.mark.gpu
+def test_kmeans_init_inside_encode():
+    """kmeans_init=True end to end: the first training-mode encode initialises the codebook from its own latents, then assigns."""
+    from fourm.vq import VQ
+    c, cfg, sd, x, g = case("vq_small")
+    vq = VQ(image_size=cfg.image, enc_type=c["enc_type"], patch_size=cfg.patch, post_mlp=cfg.post_mlp, codebook_size=32, latent_dim=cfg.latent,
+            norm_codes=True, sync_codebook=False, kmeans_init=True, threshold_ema_dead_code=0)
+    vq.load_state_dict({k: v for k, v in sd.items() if not k.startswith("quantize.")}, strict=False)
+    for p in vq.parameters():
+        p.requires_grad = False
+    vq = vq.cuda().train()
+    torch.manual_seed(0)
+    quant, loss, tokens = vq.encode(x.cuda())
+    cbk = vq.quantize._codebook
+    assert bool(cbk.initted) and int(tokens.max()) < 32 and float(loss) > 0
+    assert torch.allclose(cbk.embed.norm(dim=-1).cpu(), torch.ones(32), atol=1e-4)
+    assert len(tokens.unique()) > 8                                                 # 48 latents spread over the 32 initial means
