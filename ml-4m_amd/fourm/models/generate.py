@@ -251,12 +251,20 @@ class GenerationSampler(nn.Module):
 
     @torch.no_grad()
     def guided_maskgit_step_batched(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, conditioning=(), guidance_scale=1.0,
-                                    seed=None, generator=None, uniforms=None):
-        """MaskGIT step on logits_uncond + (logits_cond - logits_uncond) * guidance_scale (fp32), generate.py:665-703."""
+                                    seed=None, generator=None, uniforms=None, write_all_predictions=False):
+        """MaskGIT step on logits_uncond + (logits_cond - logits_uncond) * guidance_scale (fp32), generate.py:665-703.
+        ``write_all_predictions`` (generate_iter's visualisation mode, :696-697): every decoded position shows its current sample in
+        ``tensor``; only the ``num_select`` most confident ones are committed in the masks."""
         if seed is not None:
             generator = torch.Generator(device=self.model.mask_token.device).manual_seed(seed)
         logits, mod_pos = self._guided_logits(mod_dict, target_mod, list(conditioning), guidance_scale)
-        return self._sample_and_commit(mod_dict, target_mod, logits, mod_pos, num_select, temperature, top_k, top_p, generator, uniforms)
+        mod_dict = self._sample_and_commit(mod_dict, target_mod, logits, mod_pos, num_select, temperature, top_k, top_p, generator, uniforms)
+        if write_all_predictions:
+            t = mod_dict[target_mod]["tensor"]
+            flat = t.reshape(t.shape[0], -1)
+            # upstream's literal statement: tensor[:, mod_pos] = all_samples (for B > 1 every row receives the last row's samples)
+            flat[:, self.last_step["mod_pos"].long()] = self.last_step["samples"].to(flat.dtype)
+        return mod_dict
 
     @torch.no_grad()
     def guided_roar_step_batched(self, mod_dict, target_mod, num_select, temperature, top_k, top_p, conditioning=(), guidance_scale=1.0,
@@ -575,36 +583,83 @@ class GenerationSampler(nn.Module):
     # ------------------------------------------------------------------------------------------------------------------------
     # chained schedules  (generate.py:1029-1096)
     # ------------------------------------------------------------------------------------------------------------------------
+    def _schedule_step(self, mod_dict, info, step, top_k, top_p, text_tokenizer, verbose, seed, show_all=False):
+        target, temp = info["target_domain"], info["temperature"]
+        scale, cond = info.get("cfg_scale", 1.0), list(info.get("cfg_cond_domains", []))
+        seed_i = seed + step if seed is not None else None
+        guided = scale != 1.0 and len(cond) > 0
+        kind = self.model.modality_info[target]["type"]
+        if verbose:
+            print(f"[generate] step {step}: {target} {info.get('scheme', 'autoregressive')} temperature {temp}")
+        if kind == "img":
+            scheme, k = info["scheme"].lower(), info["num_tokens"]
+            if scheme not in ("maskgit", "roar"):
+                raise ValueError("Invalid sampling scheme")
+            if guided and scheme == "maskgit":
+                return self.guided_maskgit_step_batched(mod_dict, target, k, temp, top_k, top_p, conditioning=cond, guidance_scale=scale, seed=seed_i,
+                                                        write_all_predictions=show_all)
+            if guided:
+                return self.guided_roar_step_batched(mod_dict, target, k, temp, top_k, top_p, conditioning=cond, guidance_scale=scale, seed=seed_i)
+            fn = self.maskgit_step_batched if scheme == "maskgit" else self.roar_step_batched
+            return fn(mod_dict, target, k, temp, top_k, top_p, seed=seed_i)
+        if kind in ("seq", "seq_token"):
+            if guided:
+                return self.guided_autoregressive_step_batched(mod_dict, target, temp, top_k, top_p, text_tokenizer=text_tokenizer,
+                                                               conditioning=cond, guidance_scale=scale, seed=seed_i)
+            return self.autoregressive_step_batched(mod_dict, target, temp, top_k, top_p, text_tokenizer=text_tokenizer, seed=seed_i)
+        raise ValueError("Invalid schedule")
+
+    @staticmethod
+    def _copy_mod_dict(mod_dict):
+        return {m: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for m, d in mod_dict.items()}
+
     def generate(self, mod_dict, schedule, top_k=0.0, top_p=0.0, text_tokenizer=None, verbose=False, seed=None):
         """Run a generation schedule: a list of {target_domain, scheme, num_tokens, temperature, cfg_scale, cfg_cond_domains} steps
         (built by upstream's fourm/utils/generation.py build_chained_generation_schedules).  Works on a copy of ``mod_dict``."""
-        mod_dict = {m: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for m, d in mod_dict.items()}
+        mod_dict = self._copy_mod_dict(mod_dict)
         for step, info in enumerate(schedule):
-            target, temp = info["target_domain"], info["temperature"]
-            scale, cond = info.get("cfg_scale", 1.0), list(info.get("cfg_cond_domains", []))
-            seed_i = seed + step if seed is not None else None
-            guided = scale != 1.0 and len(cond) > 0
-            kind = self.model.modality_info[target]["type"]
-            if verbose:
-                print(f"[generate] step {step}: {target} {info.get('scheme', 'autoregressive')} temperature {temp}")
-            if kind == "img":
-                scheme, k = info["scheme"].lower(), info["num_tokens"]
-                if scheme not in ("maskgit", "roar"):
-                    raise ValueError("Invalid sampling scheme")
-                if guided:
-                    fn = self.guided_maskgit_step_batched if scheme == "maskgit" else self.guided_roar_step_batched
-                    mod_dict = fn(mod_dict, target, k, temp, top_k, top_p, conditioning=cond, guidance_scale=scale, seed=seed_i)
-                else:
-                    fn = self.maskgit_step_batched if scheme == "maskgit" else self.roar_step_batched
-                    mod_dict = fn(mod_dict, target, k, temp, top_k, top_p, seed=seed_i)
-            elif kind in ("seq", "seq_token"):
-                if guided:
-                    mod_dict = self.guided_autoregressive_step_batched(mod_dict, target, temp, top_k, top_p, text_tokenizer=text_tokenizer,
-                                                                       conditioning=cond, guidance_scale=scale, seed=seed_i)
-                else:
-                    mod_dict = self.autoregressive_step_batched(mod_dict, target, temp, top_k, top_p, text_tokenizer=text_tokenizer, seed=seed_i)
-            else:
-                raise ValueError("Invalid schedule")
+            mod_dict = self._schedule_step(mod_dict, info, step, top_k, top_p, text_tokenizer, verbose, seed)
+        return mod_dict
+
+    @torch.no_grad()
+    def generate_iter(self, mod_dict, schedule, top_k=0.0, top_p=0.0, text_tokenizer=None, verbose=False, seed=None):
+        """``generate`` as an iterator (generate.py:1099-1161): yields the working mod_dict after every schedule step (the SAME dict object,
+        updated in place, as upstream); guided MaskGIT steps show every current prediction in ``tensor`` (write_all_predictions)."""
+        mod_dict = self._copy_mod_dict(mod_dict)
+        for step, info in enumerate(schedule):
+            mod_dict = self._schedule_step(mod_dict, info, step, top_k, top_p, text_tokenizer, verbose, seed, show_all=True)
+            yield mod_dict
+
+    @torch.no_grad()
+    def generate_sam_dense(self, mod_dict, schedule, text_tokenizer, batch_size=16, key="sam_instance", top_k=0.0, top_p=0.0, seed=None,
+                           verbose=False):
+        """Dense SAM-instance prediction (generate.py:1230-1272): the single input is repeated ``batch_size`` times, the ``key`` sequence
+        modality is generated on every copy (different samples), and the generated sequences are merged back at their sentinels and
+        concatenated into ONE sequence that replaces ``mod_dict[key]``."""
+        first = next(iter(mod_dict.values()))["tensor"]
+        device = first.device
+        mod_dict = self._copy_mod_dict(mod_dict)
+        expanded = {}
+        for m, d in mod_dict.items():                                   # expand_to_batch (utils/generation.py:185-195)
+            expanded[m] = {}
+            for k, v in d.items():
+                if k in ("tensor", "input_mask", "target_mask", "decoder_attention_mask", "mask_valid") and torch.is_tensor(v):
+                    if v.shape[0] == 1:
+                        v = v.expand(batch_size, *v.shape[1:]).contiguous()
+                    elif v.shape[0] != batch_size:
+                        raise ValueError(f"Invalid batch size: {v.shape[0]} instead of {batch_size}")
+                expanded[m][k] = v
+        schedule = [s for s in schedule if s["target_domain"] == key]
+        out = self.generate(expanded, schedule, text_tokenizer=text_tokenizer, verbose=verbose, seed=seed, top_p=top_p, top_k=top_k)
+        sentinels = set(self.sentinel_ids(text_tokenizer))
+        merged = []
+        tens, im, tm = out[key]["tensor"].cpu(), out[key]["input_mask"].cpu(), out[key]["target_mask"].cpu()
+        for i in range(batch_size):
+            merged.extend(self.merge_span_masking(tens[i][im[i] == 0].tolist(), tens[i][tm[i] == 0].tolist(), sentinels))
+        seq = torch.tensor(merged, device=device).unsqueeze(0)
+        mod_dict[key] = {"tensor": seq, "input_mask": torch.zeros(seq.shape, dtype=torch.bool, device=device),
+                         "target_mask": torch.ones(seq.shape, dtype=torch.bool, device=device),
+                         "decoder_attention_mask": torch.zeros(seq.shape, dtype=torch.bool, device=device)}
         return mod_dict
 
 

@@ -318,3 +318,76 @@ def test_autoregressive_kv_cache(case_name, target):
     outg2 = smp.autoregressive_generate(fresh(), target, 0.9, 40, 0.0, use_eos=False, uniforms=u.cuda(), conditioning=[cond_mod], guidance_scale=3.0,
                                         use_graphs=True)
     assert torch.equal(outg2, outg)
+
+
+class _Tok:
+    """Stand-in for tokenizers.Tokenizer: the vocabulary lookups generation needs ([S_k], [EOS], [PAD])."""
+
+    def __init__(self, n_sent=20, base=4):
+        self.vocab = {"[PAD]": 0, "[EOS]": 3, **{f"[S_{k}]": base + k for k in range(n_sent)}}
+
+    def get_vocab(self):
+        return dict(self.vocab)
+
+    def token_to_id(self, t):
+        return self.vocab.get(t)
+
+
+def test_generate_iter_and_sam_dense():
+    """generate_iter yields after every schedule step and ends where generate ends (same seeds); guided MaskGIT steps expose every
+    current prediction (write_all_predictions); generate_sam_dense merges the per-copy sequences into one (generate.py:1099-1161, :1230-1272)."""
+    case = build_case("micro_swiglu")
+    cfg = case["cfg"]
+    model = build_hip_model(cfg, case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    model.load_state_dict(case["sd"], strict=True)
+    model = model.cuda().eval()
+    target = "tok_a@32"
+    spec = cfg.mod(target)
+    md = gen_mod_dict(cfg, 1, target)
+    dev_md = {k: {a: b.cuda() for a, b in v.items()} for k, v in md.items()}
+    smp = sampler(model)
+    n = spec.n_pos
+    sched = [dict(target_domain=target, scheme="maskgit", num_tokens=k, temperature=1.0) for k in (n // 4, n // 4, n - 2 * (n // 4))]
+    final = smp.generate(dev_md, sched, top_k=0, top_p=0.9, seed=5)
+    seen = []
+    for i, cur in enumerate(smp.generate_iter(dev_md, sched, top_k=0, top_p=0.9, seed=5)):
+        seen.append(int((~cur[target]["input_mask"]).sum()))
+    assert seen == [n // 4, 2 * (n // 4), n] and torch.equal(cur[target]["tensor"], final[target]["tensor"])
+    assert bool(dev_md[target]["input_mask"].all())                                  # the caller's dict is untouched
+    # guided step in iterator mode: all positions carry a prediction, the masks commit only num_tokens of them
+    cond = [m.name for m in cfg.mods if m.in_enc and m.name != target][:1]
+    gs = [dict(target_domain=target, scheme="maskgit", num_tokens=3, temperature=1.0, cfg_scale=2.0, cfg_cond_domains=cond)]
+    plain = smp.generate(dev_md, gs, seed=9)
+    shown = next(iter(smp.generate_iter(dev_md, gs, seed=9)))
+    assert torch.equal(shown[target]["input_mask"], plain[target]["input_mask"]) and int((~shown[target]["input_mask"]).sum()) == 3
+    committed = ~plain[target]["input_mask"].reshape(1, -1)
+    a, b = shown[target]["tensor"].reshape(1, -1), plain[target]["tensor"].reshape(1, -1)
+    assert torch.equal(a[committed], b[committed])
+    assert a.shape[1] == n and torch.equal(a.long(), smp.last_step["samples"].long().reshape(1, -1))      # every position shows its sample
+    # dense sequence prediction: 4 copies of one sample, one merged sequence back
+    seq = next(m.name for m in cfg.mods if m.kind == "seq" and m.in_dec)
+    tok = _Tok()
+    md2 = O.synthetic_mod_dict(cfg, 1, 20, 0, seed=3, no_target=tuple(m.name for m in cfg.mods))
+    for name, d in md2.items():
+        d["target_mask"][:] = True
+    t = md2[seq]
+    L_ = t["tensor"].reshape(1, -1).shape[1]
+    t["tensor"] = torch.randint(30, cfg.mod(seq).vocab, t["tensor"].shape, dtype=t["tensor"].dtype)
+    t["tensor"].reshape(1, -1)[0, 2] = tok.vocab["[S_1]"]                           # input: two tokens, one sentinel
+    t["input_mask"][:] = True; t["input_mask"].reshape(1, -1)[0, :3] = False
+    t["tensor"].reshape(1, -1)[0, 3] = tok.vocab["[S_1]"]                           # the decoder continues from the sentinel
+    t["target_mask"][:] = True; t["target_mask"].reshape(1, -1)[0, 3:min(L_, 9)] = False
+    dev2 = {k: {a_: b_.cuda() for a_, b_ in v.items()} for k, v in md2.items()}
+    s2 = [dict(target_domain=seq, temperature=1.0), dict(target_domain=target, scheme="maskgit", num_tokens=2, temperature=1.0)]
+    out = smp.generate_sam_dense(dev2, s2, tok, batch_size=4, key=seq, top_k=50, seed=1)
+    o = out[seq]
+    assert o["tensor"].shape[0] == 1 and o["tensor"].dim() == 2 and not bool(o["input_mask"].any()) and bool(o["target_mask"].all())
+    ref = smp.generate({k: {a_: (b_.expand(4, *b_.shape[1:]).contiguous() if torch.is_tensor(b_) else b_) for a_, b_ in v.items()} for k, v in dev2.items()},
+                       s2[:1], text_tokenizer=tok, top_k=50, seed=1)
+    sent = smp.sentinel_ids(tok)
+    want = []
+    for i in range(4):
+        r = ref[seq]
+        want += smp.merge_span_masking(r["tensor"][i][r["input_mask"][i] == 0].tolist(), r["tensor"][i][r["target_mask"][i] == 0].tolist(), sent)
+    assert o["tensor"][0].tolist() == want and len(want) >= 4 * 2
+    assert torch.equal(out[target]["tensor"], dev2[target]["tensor"])               # other modalities pass through
