@@ -166,6 +166,10 @@ class FourMEngine:
         self._pending = None       # (stream buffer still to be written, residual input, bf16 delta): see _residual / _ln
         self.reducer = None        # fourm.parallel.GradReducer when gradients are exchanged (data parallel)
 
+    @property
+    def checkpointing(self):
+        return bool(getattr(self.model, "use_act_checkpoint", False))
+
     # ------------------------------------------------------------------------------------------
     # flat parameter / gradient stores
     # ------------------------------------------------------------------------------------------
@@ -563,7 +567,7 @@ class FourMEngine:
         ops.attn_fwd(q_in, k_in, kv[:, D:], o, B, self.H, M, N, self.scale, stat_m=sm, stat_l=sl, **mask)
         self._residual(o, attn.proj, x_res, x_out, Rq, D, D, defer=True)
 
-    def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag, defer_out=False):
+    def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag, defer_out=False, out_name=None):
         """x_in (Rp, D) f32 -> new (Rp, D) f32 buffer.  [upstream Block.forward, fm_utils.py:331-334]
         defer_out (trunk loops only): the block's last residual sum is left to the LayerNorm that consumes the returned buffer next."""
         R, Rp, D = B * N, x_in.shape[0], self.D
@@ -572,13 +576,13 @@ class FourMEngine:
         x_mid = self._buf(sv, tag, "x_mid", (Rp, D), f32)
         self._self_attn_fwd(blk.attn, h1, x_in, x_mid, B, N, R, Rp, mask, sv, tag)
         h2 = self._ln(blk.norm2, x_mid, self._buf(sv, tag, "h2", (Rp, D), bf), R, sv, "n2", tag)
-        x_out = self.ws.get(tag + ".x_out", (Rp, D), f32) if sv is not None else self.ws.get("scratch.x_out" + tag[-1:], (Rp, D), f32)
+        x_out = self.ws.get(out_name or (tag + ".x_out" if sv is not None else "scratch.x_out" + tag[-1:]), (Rp, D), f32)
         self._mlp_fwd(blk.mlp, h2, x_mid, x_out, R, Rp, sv, tag, defer=defer_out)
         if sv is not None:
             sv["x_in"] = x_in
         return x_out
 
-    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag, defer_out=False):
+    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag, defer_out=False, out_name=None):
         """[upstream DecoderBlock.forward, fm_utils.py:362-366]"""
         Rq, Rqp, Rc, Rcp, D = B * M, y_in.shape[0], B * N, ctx.shape[0], self.D
         bf, f32 = self.adt, torch.float32
@@ -590,7 +594,7 @@ class FourMEngine:
         y2 = self._buf(sv, tag, "y2", (Rqp, D), f32)
         self._cross_attn_fwd(blk.cross_attn, hq, hc, y1, y2, B, M, N, Rq, Rqp, Rc, Rcp, xa_mask, sv, tag)
         h2 = self._ln(blk.norm2, y2, self._buf(sv, tag, "h2", (Rqp, D), bf), Rq, sv, "n2", tag)
-        y_out = self.ws.get(tag + ".y_out", (Rqp, D), f32) if sv is not None else self.ws.get("scratch.y_out" + tag[-1:], (Rqp, D), f32)
+        y_out = self.ws.get(out_name or (tag + ".y_out" if sv is not None else "scratch.y_out" + tag[-1:]), (Rqp, D), f32)
         self._mlp_fwd(blk.mlp, h2, y2, y_out, Rq, Rqp, sv, tag, defer=defer_out)
         if sv is not None:
             sv["y_in"] = y_in
@@ -620,7 +624,12 @@ class FourMEngine:
         B, N = enc["B"], enc["Nt"]
         emask = self.keypad(enc["mask"])
         x = enc["x0"]
+        ckpt = save and self.checkpointing
         for i, blk in enumerate(m.encoder):
+            if ckpt:      # activation checkpointing (fm.py:103-113, use_act_checkpoint): keep the block's INPUT only, recompute in the backward
+                st["enc_layers"].append(dict(ckpt_in=x))
+                x = self.encoder_block_fwd(blk, x, B, N, emask, None, f"enc{i % 2}", defer_out=True, out_name=f"enc{i}.x_out")
+                continue
             sv = {} if save else None
             x = self.encoder_block_fwd(blk, x, B, N, emask, sv, f"enc{i}" if save else f"enc{i % 2}", defer_out=True)   # next: norm1 / encoder_norm
             if save:
@@ -643,6 +652,11 @@ class FourMEngine:
         y = dec["x0"]
         smask = self.decoder_mask(dec["cs"], dec["mod_pre"]) if "cs" in dec else dec["sa_mask"]
         for i, blk in enumerate(m.decoder):
+            if save and self.checkpointing:
+                st["dec_layers"].append(dict(ckpt_in=y))
+                y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, None, f"dec{i % 2}", defer_out=i + 1 < len(m.decoder),
+                                           out_name=f"dec{i}.y_out")
+                continue
             sv = {} if save else None
             y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, sv, f"dec{i}" if save else f"dec{i % 2}",
                                        defer_out=i + 1 < len(m.decoder))           # next: the following block's norm1
@@ -943,7 +957,11 @@ class FourMEngine:
         dctx_bf = ws.get("bwd.dctx_bf", (Rcp, D), bf)
         dctx.zero_()
         for i in reversed(range(len(m.decoder))):
-            self.decoder_block_bwd(m.decoder[i], st["dec_layers"][i], g, g_bf, dctx, dctx_bf, st["ctx"], B, Mt, N, st["smask"], st["emask"])
+            sv = st["dec_layers"][i]
+            if "ckpt_in" in sv:       # recompute this block's activations from its saved input (one shared set of buffers)
+                y_in, sv = sv["ckpt_in"], {}
+                self.decoder_block_fwd(m.decoder[i], y_in, st["ctx"], B, Mt, N, st["smask"], st["emask"], sv, "ckpt", out_name="ckpt.out")
+            self.decoder_block_bwd(m.decoder[i], sv, g, g_bf, dctx, dctx_bf, st["ctx"], B, Mt, N, st["smask"], st["emask"])
             self._stage(f"dec{i}")
         self._embed_bwd(dec, g, None, True)
         self._stage("dec_emb")
@@ -959,7 +977,11 @@ class FourMEngine:
         self._ln_bwd(m.encoder_norm, dxn, st["x_final"], top, "en", ge, ge_bf, Rc, dres=None)
         self._stage("ctx")
         for i in reversed(range(len(m.encoder))):
-            self.encoder_block_bwd(m.encoder[i], st["enc_layers"][i], ge, ge_bf, B, N, st["emask"])
+            sv = st["enc_layers"][i]
+            if "ckpt_in" in sv:
+                x_in, sv = sv["ckpt_in"], {}
+                self.encoder_block_fwd(m.encoder[i], x_in, B, N, st["emask"], sv, "ckpt", out_name="ckpt.out")
+            self.encoder_block_bwd(m.encoder[i], sv, ge, ge_bf, B, N, st["emask"])
             self._stage(f"enc{i}")
         # d(x0) -> token tables / projections / embeddings; d(ctx) also reaches the encoder embeddings
         for n in enc["names"]:

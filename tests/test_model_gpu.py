@@ -444,3 +444,26 @@ def test_residual_stream_error_follows_the_autocast_curve(name):
     # no block adds more than the whole curve's final level (a jump = a biased kernel entering at that block)
     jumps = [e_hip[i] - e_hip[i - 1] for i in range(1, len(e_hip))]
     assert max(jumps) < 0.5 * e_ref[-1] + 2e-4, (max(jumps), e_ref[-1], list(zip(names, e_hip)))
+
+
+@pytest.mark.parametrize("name", ["micro_swiglu", "ti_mod7"])
+def test_activation_checkpointing(name):
+    """use_act_checkpoint=True (fm.py:103-113): only block inputs are kept, every block's activations are recomputed in the backward.
+    Same loss bit for bit, the same gradients (up to the atomics' summation order), a smaller workspace."""
+    res = {}
+    for ckpt in (False, True):
+        g, case, model = setup(name)
+        model.use_act_checkpoint = ckpt
+        random.seed(case["order_seed"])
+        loss, _ = model(to_device(case["mod_dict"]), case["N"], case["M"], loss_type=case["loss_type"])
+        loss.backward()
+        torch.cuda.synchronize()
+        eng = model._engine
+        res[ckpt] = (float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, eng.ws.nbytes(),
+                     sum(1 for k in eng.ws.bufs if ".h1" in str(k)))
+    assert res[True][0] == res[False][0]
+    assert set(res[True][1]) == set(res[False][1])
+    for n, gr in res[False][1].items():
+        assert rel(res[True][1][n], gr) < 2e-5 or float(gr.norm()) < 1e-9, (n, rel(res[True][1][n], gr))
+    assert res[True][2] < 0.8 * res[False][2], (res[True][2], res[False][2])
+    record("model.activation_checkpointing", case=name, workspace_bytes=res[False][2], workspace_bytes_checkpointed=res[True][2])
