@@ -295,6 +295,11 @@ int fm_f32_to_bf16(const void* src, void* dst, int64_t n, void* stream);
 int fm_bf16_to_f32_scaled(const void* src, void* dst, int64_t n, float scale, void* stream);
 /* out = x + delta over n contiguous elements (x, out f32; delta bf16): the residual add of fm_utils.py:332-333 on its own */
 int fm_add_bf16_f32(const void* x, const void* delta, void* out, int64_t n, void* stream);
+/* Stochastic depth (DropPath, fourm/models/fm_utils.py:64-87): x[r][:] *= scale[r / rows_per_sample] in place on a bf16 (R, N) tile of
+ * row stride ld (scale f32 per sample = mask / keep_prob).  The forward scales a residual branch's output, the backward the bf16
+ * gradient copy that enters the branch.  N, ld multiples of 8. */
+int fm_scale_rows_bf16(void* x, int ld, const void* scale, int rows_per_sample, int R, int N, void* stream);
+
 /* torch.optim.AdamW update on a contiguous fp32 range (fourm/utils/optim_factory.py:239-240);
  * grad_mult: optional device scalar multiplied into the gradient (clipping).
  * hyper: optional DEVICE float[4] = {lr, weight_decay, 1 - beta1^step, sqrt(1 - beta2^step)} that overrides the scalar arguments:

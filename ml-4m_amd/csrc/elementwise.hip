@@ -473,3 +473,32 @@ extern "C" int fm_f32_to_bf16(const void* src, void* dst, int64_t n, void* strea
     FM_CHECK_LAUNCH("fm_f32_to_bf16");
     return 0;
 }
+
+// ---- stochastic depth (DropPath, fm_utils.py:64-87): x[r][:] *= scale[r / rows_per_sample] on a bf16 (R, N) tile in place --------------
+namespace {
+__global__ __launch_bounds__(256) void scale_rows_bf16_kernel(bf16_t* __restrict__ x, int ld, const float* __restrict__ scale, int rows_per_sample, int R, int N) {
+    const int nv = N / 8;                                   // 16-byte pieces per row (N % 8 == 0)
+    const size_t total = (size_t)R * nv;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e / nv), c = (int)(e % nv);
+        const float s = scale[r / rows_per_sample];
+        uint4* p = (uint4*)(x + (size_t)r * ld + c * 8);
+        uint4 v = *p;
+        uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (uint32_t)f2bf(bf2f((bf16_t)(w[i] & 0xffff)) * s) | ((uint32_t)f2bf(bf2f((bf16_t)(w[i] >> 16)) * s) << 16);
+        *p = v;
+    }
+}
+}  // namespace
+
+extern "C" int fm_scale_rows_bf16(void* x, int ld, const void* scale, int rows_per_sample, int R, int N, void* stream) {
+    FM_CHECK_ARG(x && scale && R > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0 && rows_per_sample > 0 && (((uintptr_t)x) & 15) == 0,
+                 "fm_scale_rows_bf16: bad argument (N, ld multiples of 8; 16-byte aligned)");
+    size_t blocks = ((size_t)R * (N / 8) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(scale_rows_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld, (const float*)scale, rows_per_sample, R, N);
+    FM_CHECK_LAUNCH("fm_scale_rows_bf16");
+    return 0;
+}

@@ -128,6 +128,8 @@ def fill_mod_desc(md, d, emb, is_dec: bool, mod_id: int, head_index: int = 0, ra
 
 class FourMEngine:
     _pending = None            # (engines built without this __init__ - the tokenizer's - start with no deferred residual)
+    _drop_now = None           # (per-sample DropPath scale, rows per sample) of the residual branch being computed
+    drop_uniforms = None       # tests: an iterator of (B,) uniform tensors replacing torch.rand in DropPath
 
     def __init__(self, model):
         from fourm.models.fm_utils import GatedMlp, NormAttention, act_name
@@ -481,14 +483,32 @@ class FourMEngine:
         return y
 
     def _residual(self, a, lin, x_res, x_out, R, N, K, defer):
-        """x_out = x_res + a W^T (+ bias): fused in the GEMM epilogue, or (defer) a bf16 GEMM whose sum is owed to the next _ln(x_out)."""
-        if defer and DEFER_RESIDUAL and not self.fp32:
+        """x_out = x_res + a W^T (+ bias): fused in the GEMM epilogue, or (defer) a bf16 GEMM whose sum is owed to the next _ln(x_out).
+        With stochastic depth active (self._drop_now = (per-sample scale, rows per sample)) the branch output is scaled first."""
+        drop = self._drop_now
+        if drop is not None and self.fp32:
+            raise NotImplementedError("drop_path in the fp32 verification mode")
+        if drop is not None or (defer and DEFER_RESIDUAL and not self.fp32):
             self._settle()
             delta = self.ws.get("fwd.delta", (x_out.shape[0], N), self.adt)
             ops.gemm_nt(a, self.w(lin.weight), delta, bias=lin.bias, M=R, N=N, K=K)
+            if drop is not None:
+                ops.scale_rows_bf16(delta, drop[0], drop[1], R, N)
             self._pending = (x_out, x_res, delta, R)
+            if not (defer and DEFER_RESIDUAL):
+                self._settle()
         else:
             ops.gemm_nt(a, self.w(lin.weight), x_out, epilogue=L.EPI_RESIDUAL, res=x_res, bias=lin.bias, M=R, N=N, K=K)
+
+    def _drop_scales(self, blk, B, n, sv, dp):
+        """Per-branch DropPath scales of one block: ``dp`` when given (checkpoint recompute), freshly drawn in training mode, else None."""
+        from fourm.models.fm_utils import DropPath
+        if dp is None and isinstance(getattr(blk, "drop_path", None), DropPath) and self.model.training:
+            dp = [blk.drop_path.sample_scale(B, self.device, None if self.drop_uniforms is None else next(self.drop_uniforms)) for _ in range(n)]
+        if sv is not None and dp is not None:
+            sv["dp"] = dp
+        self._last_dp = dp
+        return dp
 
     def _settle(self):
         """A deferred residual sum nobody normalised (a caller outside the trunk loops wants the stream itself): write it now."""
@@ -567,35 +587,44 @@ class FourMEngine:
         ops.attn_fwd(q_in, k_in, kv[:, D:], o, B, self.H, M, N, self.scale, stat_m=sm, stat_l=sl, **mask)
         self._residual(o, attn.proj, x_res, x_out, Rq, D, D, defer=True)
 
-    def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag, defer_out=False, out_name=None):
+    def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag, defer_out=False, out_name=None, dp=None):
         """x_in (Rp, D) f32 -> new (Rp, D) f32 buffer.  [upstream Block.forward, fm_utils.py:331-334]
         defer_out (trunk loops only): the block's last residual sum is left to the LayerNorm that consumes the returned buffer next."""
         R, Rp, D = B * N, x_in.shape[0], self.D
         bf, f32 = self.adt, torch.float32
+        dp = self._drop_scales(blk, B, 2, sv, dp)
         h1 = self._ln(blk.norm1, x_in, self._buf(sv, tag, "h1", (Rp, D), bf), R, sv, "n1", tag)
         x_mid = self._buf(sv, tag, "x_mid", (Rp, D), f32)
+        self._drop_now = (dp[0], N) if dp else None
         self._self_attn_fwd(blk.attn, h1, x_in, x_mid, B, N, R, Rp, mask, sv, tag)
         h2 = self._ln(blk.norm2, x_mid, self._buf(sv, tag, "h2", (Rp, D), bf), R, sv, "n2", tag)
         x_out = self.ws.get(out_name or (tag + ".x_out" if sv is not None else "scratch.x_out" + tag[-1:]), (Rp, D), f32)
+        self._drop_now = (dp[1], N) if dp else None
         self._mlp_fwd(blk.mlp, h2, x_mid, x_out, R, Rp, sv, tag, defer=defer_out)
+        self._drop_now = None
         if sv is not None:
             sv["x_in"] = x_in
         return x_out
 
-    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag, defer_out=False, out_name=None):
+    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag, defer_out=False, out_name=None, dp=None):
         """[upstream DecoderBlock.forward, fm_utils.py:362-366]"""
         Rq, Rqp, Rc, Rcp, D = B * M, y_in.shape[0], B * N, ctx.shape[0], self.D
         bf, f32 = self.adt, torch.float32
+        dp = self._drop_scales(blk, B, 3, sv, dp)
         h1 = self._ln(blk.norm1, y_in, self._buf(sv, tag, "h1", (Rqp, D), bf), Rq, sv, "n1", tag)
         y1 = self._buf(sv, tag, "y1", (Rqp, D), f32)
+        self._drop_now = (dp[0], M) if dp else None
         self._self_attn_fwd(blk.self_attn, h1, y_in, y1, B, M, Rq, Rqp, sa_mask, sv, tag)
+        self._drop_now = (dp[1], M) if dp else None
         hq = self._ln(blk.query_norm, y1, self._buf(sv, tag, "hq", (Rqp, D), bf), Rq, sv, "nq", tag)
         hc = self._ln(blk.context_norm, ctx, self._buf(sv, tag, "hc", (Rcp, D), bf), Rc, sv, "nc", tag)
         y2 = self._buf(sv, tag, "y2", (Rqp, D), f32)
         self._cross_attn_fwd(blk.cross_attn, hq, hc, y1, y2, B, M, N, Rq, Rqp, Rc, Rcp, xa_mask, sv, tag)
         h2 = self._ln(blk.norm2, y2, self._buf(sv, tag, "h2", (Rqp, D), bf), Rq, sv, "n2", tag)
         y_out = self.ws.get(out_name or (tag + ".y_out" if sv is not None else "scratch.y_out" + tag[-1:]), (Rqp, D), f32)
+        self._drop_now = (dp[2], M) if dp else None
         self._mlp_fwd(blk.mlp, h2, y2, y_out, Rq, Rqp, sv, tag, defer=defer_out)
+        self._drop_now = None
         if sv is not None:
             sv["y_in"] = y_in
         return y_out
@@ -629,6 +658,7 @@ class FourMEngine:
             if ckpt:      # activation checkpointing (fm.py:103-113, use_act_checkpoint): keep the block's INPUT only, recompute in the backward
                 st["enc_layers"].append(dict(ckpt_in=x))
                 x = self.encoder_block_fwd(blk, x, B, N, emask, None, f"enc{i % 2}", defer_out=True, out_name=f"enc{i}.x_out")
+                st["enc_layers"][-1]["dp"] = self._last_dp
                 continue
             sv = {} if save else None
             x = self.encoder_block_fwd(blk, x, B, N, emask, sv, f"enc{i}" if save else f"enc{i % 2}", defer_out=True)   # next: norm1 / encoder_norm
@@ -656,6 +686,7 @@ class FourMEngine:
                 st["dec_layers"].append(dict(ckpt_in=y))
                 y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, None, f"dec{i % 2}", defer_out=i + 1 < len(m.decoder),
                                            out_name=f"dec{i}.y_out")
+                st["dec_layers"][-1]["dp"] = self._last_dp
                 continue
             sv = {} if save else None
             y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, sv, f"dec{i}" if save else f"dec{i % 2}",
@@ -833,9 +864,14 @@ class FourMEngine:
     def encoder_block_bwd(self, blk, sv, g, g_bf, B, N, mask):
         R, Rp = B * N, g.shape[0]
         self._dw_jobs = []
+        dp = sv.get("dp")                                                       # DropPath: the gradient entering a branch carries its scale
+        if dp:
+            ops.scale_rows_bf16(g_bf, dp[1], N, R)
         dh = self._mlp_bwd(blk.mlp, sv, g_bf, R, Rp)
         g1 = self.ws.get("bwd.enc.gbf1", tuple(g_bf.shape), g_bf.dtype)      # g_bf is still an operand of the queued fc2 dW
         self._ln_bwd(blk.norm2, dh, sv["x_mid"], sv, "n2", g, g1, R, dres=g)
+        if dp:
+            ops.scale_rows_bf16(g1, dp[0], N, R)
         dh = self._self_attn_bwd(blk.attn, sv, g1, B, N, R, Rp, mask)
         self._flush_dW()
         self._ln_bwd(blk.norm1, dh, sv["x_in"], sv, "n1", g, g_bf, R, dres=g)
@@ -846,9 +882,14 @@ class FourMEngine:
         ws = self.ws
         self._dw_jobs = []
         g_in = g_bf
+        dp = sv.get("dp")
+        if dp:
+            ops.scale_rows_bf16(g_in, dp[2], M, Rq)
         dh = self._mlp_bwd(blk.mlp, sv, g_in, Rq, Rqp)
         g_bf = ws.get("bwd.dec.gbf1", tuple(g_in.shape), g_in.dtype)          # each copy stays an operand of a queued dW
         self._ln_bwd(blk.norm2, dh, sv["y2"], sv, "n2", g, g_bf, Rq, dres=g)
+        if dp:
+            ops.scale_rows_bf16(g_bf, dp[1], M, Rq)
         # cross attention
         xa = blk.cross_attn
         self._dW(g_bf, sv["o2"], xa.proj, Rq)
@@ -871,6 +912,8 @@ class FourMEngine:
         ops.gemm_nt(dq, self.wt(xa.q.weight), dhq, M=Rq, N=D, K=D)
         g_bf = ws.get("bwd.dec.gbf2", tuple(g_in.shape), g_in.dtype)
         self._ln_bwd(blk.query_norm, dhq, sv["y1"], sv, "nq", g, g_bf, Rq, dres=g)
+        if dp:
+            ops.scale_rows_bf16(g_bf, dp[0], M, Rq)
         self._dW(dkv, sv["hc"], xa.kv, Rc)
         dhc = ws.get("bwd.dhc", (Rcp, D), bf)
         ops.gemm_nt(dkv, self.wt(xa.kv.weight), dhc, M=Rc, N=D, K=2 * D)
@@ -959,8 +1002,8 @@ class FourMEngine:
         for i in reversed(range(len(m.decoder))):
             sv = st["dec_layers"][i]
             if "ckpt_in" in sv:       # recompute this block's activations from its saved input (one shared set of buffers)
-                y_in, sv = sv["ckpt_in"], {}
-                self.decoder_block_fwd(m.decoder[i], y_in, st["ctx"], B, Mt, N, st["smask"], st["emask"], sv, "ckpt", out_name="ckpt.out")
+                y_in, dp, sv = sv["ckpt_in"], sv["dp"], {}
+                self.decoder_block_fwd(m.decoder[i], y_in, st["ctx"], B, Mt, N, st["smask"], st["emask"], sv, "ckpt", out_name="ckpt.out", dp=dp)
             self.decoder_block_bwd(m.decoder[i], sv, g, g_bf, dctx, dctx_bf, st["ctx"], B, Mt, N, st["smask"], st["emask"])
             self._stage(f"dec{i}")
         self._embed_bwd(dec, g, None, True)
@@ -979,8 +1022,8 @@ class FourMEngine:
         for i in reversed(range(len(m.encoder))):
             sv = st["enc_layers"][i]
             if "ckpt_in" in sv:
-                x_in, sv = sv["ckpt_in"], {}
-                self.encoder_block_fwd(m.encoder[i], x_in, B, N, st["emask"], sv, "ckpt", out_name="ckpt.out")
+                x_in, dp, sv = sv["ckpt_in"], sv["dp"], {}
+                self.encoder_block_fwd(m.encoder[i], x_in, B, N, st["emask"], sv, "ckpt", out_name="ckpt.out", dp=dp)
             self.encoder_block_bwd(m.encoder[i], sv, ge, ge_bf, B, N, st["emask"])
             self._stage(f"enc{i}")
         # d(x0) -> token tables / projections / embeddings; d(ctx) also reaches the encoder embeddings

@@ -387,6 +387,12 @@ def bf16_to_f32_scaled(src, dst, scale=1.0):
     return dst
 
 
+def scale_rows_bf16(x, scale, rows_per_sample, R, N=None):
+    """x[r] *= scale[r // rows_per_sample] (bf16, in place): DropPath on a branch output / on the gradient entering the branch."""
+    L.check(L.scale_rows_bf16(_p(x), _ld(x), _p(scale), rows_per_sample, R, x.shape[1] if N is None else N, _stream()))
+    return x
+
+
 def add_bf16_to_f32(x, delta, out, R=None):
     """out[:R] = x[:R] + delta[:R] (contiguous (rows, D) buffers of equal width)."""
     R = x.shape[0] if R is None else R

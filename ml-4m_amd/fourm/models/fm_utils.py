@@ -157,10 +157,26 @@ def _mlp(dim, mlp_ratio, act_layer, mlp_bias, gated_mlp, drop):
     return Mlp(in_features=dim, hidden_features=hidden, act_layer=act_layer, bias=mlp_bias, drop=drop)
 
 
+class DropPath(nn.Module):
+    """Stochastic depth per sample (upstream fm_utils.py:64-87): in training mode a residual branch's output is multiplied by
+    floor(keep_prob + u) / keep_prob with one uniform u per sample.  Parameter-free marker: the engine draws the scales
+    (``sample_scale``) and applies them with fm_scale_rows_bf16 in the forward and in the backward."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def sample_scale(self, batch: int, device, uniforms=None):
+        keep = 1.0 - self.drop_prob
+        u = torch.rand(batch, device=device) if uniforms is None else uniforms.to(device=device, dtype=torch.float32)
+        return (torch.floor(keep + u) / keep).float().contiguous()
+
+    def extra_repr(self) -> str:
+        return "p={}".format(self.drop_prob)
+
+
 def _no_drop_path(rate):
-    if rate and rate > 0.:
-        raise NotImplementedError("stochastic depth (drop_path > 0) is not implemented in the HIP path")
-    return nn.Identity()
+    return DropPath(rate) if rate and rate > 0. else nn.Identity()
 
 
 class Block(nn.Module):

@@ -396,23 +396,34 @@ def mlp(P, pre, x, cfg, num):
     return num.linear(h, P[pre + ".fc2.weight"], P.get(pre + ".fc2.bias"))
 
 
-def encoder_forward(P, cfg, x, enc_mask, num, taps=None):
+def drop_path_scale(u: Tensor, drop_prob: float) -> Tensor:
+    """DropPath (fm_utils.py:64-76) with its uniform draw explicit: floor(keep_prob + u) / keep_prob per sample, shaped (B, 1, 1)."""
+    keep = 1.0 - drop_prob
+    return (torch.floor(keep + u.float()) / keep).reshape(-1, 1, 1)
+
+
+def _dp(drop, side, i, j):
+    """Scale of branch j of block i (``drop`` = {"enc": [[s_attn, s_mlp], ...], "dec": [[s_self, s_cross, s_mlp], ...]}), or 1."""
+    return 1.0 if drop is None else drop[side][i][j]
+
+
+def encoder_forward(P, cfg, x, enc_mask, num, taps=None, drop=None):
     for i in range(cfg.enc_depth):
         pre = f"encoder.{i}"
-        x = x + self_attention(P, pre + ".attn", _ln(P, pre + ".norm1", x, cfg, num), enc_mask, cfg, num)
-        x = x + mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", x, cfg, num), cfg, num)
+        x = x + _dp(drop, "enc", i, 0) * self_attention(P, pre + ".attn", _ln(P, pre + ".norm1", x, cfg, num), enc_mask, cfg, num)
+        x = x + _dp(drop, "enc", i, 1) * mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", x, cfg, num), cfg, num)
         if taps is not None:
             taps[f"enc_block{i}"] = x
     return _ln(P, "encoder_norm", x, cfg, num)
 
 
-def decoder_forward(P, cfg, y, ctx, enc_mask, sa_blocked, num, taps=None):
+def decoder_forward(P, cfg, y, ctx, enc_mask, sa_blocked, num, taps=None, drop=None):
     for i in range(cfg.dec_depth):
         pre = f"decoder.{i}"
-        y = y + self_attention(P, pre + ".self_attn", _ln(P, pre + ".norm1", y, cfg, num), sa_blocked, cfg, num)
-        y = y + cross_attention(P, pre + ".cross_attn", _ln(P, pre + ".query_norm", y, cfg, num),
-                                _ln(P, pre + ".context_norm", ctx, cfg, num), enc_mask, cfg, num)
-        y = y + mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", y, cfg, num), cfg, num)
+        y = y + _dp(drop, "dec", i, 0) * self_attention(P, pre + ".self_attn", _ln(P, pre + ".norm1", y, cfg, num), sa_blocked, cfg, num)
+        y = y + _dp(drop, "dec", i, 1) * cross_attention(P, pre + ".cross_attn", _ln(P, pre + ".query_norm", y, cfg, num),
+                                                        _ln(P, pre + ".context_norm", ctx, cfg, num), enc_mask, cfg, num)
+        y = y + _dp(drop, "dec", i, 2) * mlp(P, pre + ".mlp", _ln(P, pre + ".norm2", y, cfg, num), cfg, num)
         if taps is not None:
             taps[f"dec_block{i}"] = y
     return _ln(P, "decoder_norm", y, cfg, num)
@@ -448,7 +459,7 @@ def modality_losses(P, cfg, y, target_ids, dec_mod_mask, dec_names, loss_type, n
 def fourm_forward(P: Dict[str, Tensor], cfg: TrunkCfg, mod_dict: Dict[str, Dict[str, Tensor]],
                   num_encoder_tokens: int, num_decoder_tokens: int, dec_order: Sequence[str],
                   loss_type: str = "mod", return_logits: bool = False, emulate_bf16: bool = False,
-                  taps: Optional[dict] = None):
+                  taps: Optional[dict] = None, drop: Optional[dict] = None):
     """Whole-model forward (fm.py:640-691).  ``dec_order`` lists the decoder modalities present in
     ``mod_dict`` in the order they are concatenated.  Returns (loss, {mod: loss}) or {mod: logits}.
     ``taps`` (a dict) receives intermediate tensors at named cut points."""
@@ -458,9 +469,9 @@ def fourm_forward(P: Dict[str, Tensor], cfg: TrunkCfg, mod_dict: Dict[str, Dict[
     if taps is not None:
         taps.update({"enc_" + k: v for k, v in enc.items()})
         taps.update({"dec_" + k: v for k, v in dec.items()})
-    x = encoder_forward(P, cfg, enc["tokens"] + enc["emb"], enc["mask"], num, taps)
+    x = encoder_forward(P, cfg, enc["tokens"] + enc["emb"], enc["mask"], num, taps, drop)      # drop: DropPath scales in training mode
     ctx = num.linear(x, P["decoder_proj_context.weight"], P["decoder_proj_context.bias"]) + enc["emb"]
-    y = decoder_forward(P, cfg, dec["tokens"] + dec["emb"], ctx, enc["mask"], dec["attn_mask"], num, taps)
+    y = decoder_forward(P, cfg, dec["tokens"] + dec["emb"], ctx, enc["mask"], dec["attn_mask"], num, taps, drop)
     if taps is not None:
         taps["enc_out"], taps["context"], taps["dec_out"] = x, ctx, y
     dec_names = [n for n in mod_dict if n in dec_order]     # heads iterate in mod_dict order

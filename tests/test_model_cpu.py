@@ -202,3 +202,67 @@ def test_ctypes_prototypes_match_the_header():
                 assert at is ctypes.c_int64, (name, decl, at)
             else:
                 assert at in (ctypes.c_int, ctypes.c_int32), (name, decl, at)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not on this machine")
+def test_oracle_drop_path_matches_upstream():
+    """Stochastic depth: the oracle's explicit per-branch scales against the unmodified upstream blocks whose DropPath draws are replayed
+    (fm_utils.py:64-87, :331-334, :362-366)."""
+    import subprocess
+    import sys
+    child = r'''
+import sys, os, random
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, ROOT)
+import make_golden as MG
+import torch
+from oracle import fourm_oracle as O
+from tests.golden.cases import build_case
+case = build_case("micro_swiglu")
+cfg, sd, md = case["cfg"], case["sd"], case["mod_dict"]
+model = MG.upstream_model(cfg, case["share_embedding"], case["norm_bias"], case["learned_pos"])
+model.load_state_dict(sd, strict=True)
+model.train()
+B = next(iter(md.values()))["tensor"].shape[0]
+pe = [0.2 + 0.1 * i for i in range(cfg.enc_depth)]
+pd = [0.3 + 0.1 * i for i in range(cfg.dec_depth)]
+for blk, p in zip(list(model.encoder) + list(model.decoder), pe + pd):
+    blk.drop_path = MG.ref_utils.DropPath(p)
+g = torch.Generator().manual_seed(4)
+draws = [torch.rand(B, generator=g) for _ in range(2 * cfg.enc_depth + 3 * cfg.dec_depth)]
+it = iter(draws)
+real = torch.rand
+def fake(*a, **k):
+    shape = a[0] if a and isinstance(a[0], (tuple, list, torch.Size)) else a
+    if len(shape) == 3 and tuple(shape[1:]) == (1, 1):
+        return next(it).reshape(shape).to(k.get("dtype", torch.float32))
+    return real(*a, **k)
+torch.rand = fake
+random.seed(case["order_seed"])
+loss, _ = model(MG.clone_mod_dict(md), case["N"], case["M"], loss_type=case["loss_type"])
+loss.sum().backward()
+torch.rand = real
+assert next(it, None) is None
+drop = {"enc": [[O.drop_path_scale(draws[2 * i + j], pe[i]) for j in range(2)] for i in range(cfg.enc_depth)],
+        "dec": [[O.drop_path_scale(draws[2 * cfg.enc_depth + 3 * i + j], pd[i]) for j in range(3)] for i in range(cfg.dec_depth)]}
+assert any(float(s.min()) == 0.0 for side in drop.values() for l in side for s in l) and any(float(s.max()) > 1.0 for side in drop.values() for l in side for s in l)
+P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+for m in cfg.mods:
+    if m.in_enc and m.in_dec:
+        P[f"decoder_embeddings.{m.name}.mod_emb"] = P[f"encoder_embeddings.{m.name}.mod_emb"]
+    if m.in_dec and case["share_embedding"]:
+        P[f"decoder_embeddings.{m.name}.to_logits.weight"] = P[f"decoder_embeddings.{m.name}.token_emb.weight"]
+order = MG.dec_order_for_seed([n for n in md if n in model.decoder_embeddings], case["order_seed"])
+ol, _ = O.fourm_forward(P, cfg, md, case["N"], case["M"], order, loss_type=case["loss_type"], drop=drop)
+ol.sum().backward()
+assert abs(float(ol.sum()) - float(loss.sum())) < 2e-5 * abs(float(loss.sum())), (float(ol.sum()), float(loss.sum()))
+n = 0
+for k, p in model.named_parameters():
+    if p.grad is not None and P[k].grad is not None and float(p.grad.norm()) > 1e-8:
+        assert float((P[k].grad - p.grad).norm() / p.grad.norm()) < 1e-3, k
+        n += 1
+assert n > 20
+print("ok")
+'''
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    p = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + child], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0 and "ok" in p.stdout, (p.stdout + p.stderr)[-3000:]
