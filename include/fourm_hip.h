@@ -162,6 +162,8 @@ typedef struct fm_attn_args {
     int32_t force_tr;         /* -1 = library default, 0 = 2-byte LDS gathers, 1 = transpose reads */
     int32_t kv_batch_rows;    /* forward only: rows between two samples in K / V (0 = Nk).  A K/V cache of capacity T holds sample b's
                                  keys at rows [b*T, b*T + Nk): incremental decoding attends to the Nk filled rows without copying */
+    int32_t zero_attn;        /* allow_zero_attn (fm_utils.py:28-30, :171-172): softmax over the scores AND one extra zero logit whose
+                                 probability is dropped (p_k = e^{s_k} / (1 + sum_j e^{s_j})): a query may attend to nothing */
 } fm_attn_args;
 int fm_attn_fwd(const fm_attn_args* args, void* stream);
 int fm_attn_bwd(const fm_attn_args* args, void* stream);   /* any Nq, Nk (single pass up to 512 rows, 256-row chunks above) */

@@ -42,6 +42,7 @@ struct AttnArgs {
     const bf16_t* dO; bf16_t* dQ; bf16_t* dK; bf16_t* dV;
     int lddo, lddq, lddk, lddv;
     int kvr;                      // forward: rows between two samples in K / V (>= Nk: a K/V cache filled up to Nk)
+    int zero_attn;                // softmax1: one extra zero logit in the denominator (allow_zero_attn)
     int chunk;                    // rows of the two LDS tiles of the backward (a multiple of 32; >= max(Nq, Nk) padded when one chunk does)
 };
 
@@ -223,8 +224,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             }
         __syncthreads();
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float m_fin = m_run, oscale = 1.0f;
+    if (a.zero_attn) {      // softmax1 (fm_utils.py:28-30): the padded zero logit joins the maximum and the sum, its probability is dropped
+        m_fin = fmaxf(m_run, 0.f);
+        oscale = __builtin_amdgcn_exp2f(m_run - m_fin);
+        l_tot = l_tot * oscale + __builtin_amdgcn_exp2f(-m_fin);
+    }
+    const float inv = oscale / l_tot;
     {   // lanes l and l+32 own the same query row: 16-byte stores (store_bf16_groups)
         bf16_t* orow = a.O + ((size_t)b * a.Nq + qc) * a.ldo + h * HD;
         const bool wide_o = (a.ldo & 7) == 0 && (((uintptr_t)a.O) & 15) == 0;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (q < a.Nq) {
         if (fhi == 0 && a.stat_m) {
             const size_t si = ((size_t)b * a.H + h) * a.Nq + q;
-            a.stat_m[si] = m_run;
+            a.stat_m[si] = m_fin;
             a.stat_l[si] = l_tot;
         }
     }
@@ -576,6 +583,7 @@ int fill(AttnArgs& a, const fm_attn_args* p, const char* who) {
     a.kpad = (const uint8_t*)p->kpad; a.cs = p->cs; a.modq = p->modq; a.modk = p->modk; a.dense = (const uint8_t*)p->dense;
     a.causal = p->causal;
     a.kvr = p->kv_batch_rows > 0 ? p->kv_batch_rows : p->Nk;
+    a.zero_attn = p->zero_attn;
     FM_CHECK_ARG(a.kvr >= p->Nk, "%s: kv_batch_rows=%d < Nk=%d", who, p->kv_batch_rows, p->Nk);
     a.dO = (const bf16_t*)p->dO; a.dQ = (bf16_t*)p->dQ; a.dK = (bf16_t*)p->dK; a.dV = (bf16_t*)p->dV;
     a.lddo = p->lddo; a.lddq = p->lddq; a.lddk = p->lddk; a.lddv = p->lddv;

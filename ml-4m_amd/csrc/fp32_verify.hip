@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(fm_gemm_f32_args a) 
 // ------------------------------------------------------------------------------------------------------------------------------
 struct Attn32 {
     const float* Q; const float* K; const float* V; float* O; const float* dO; float* dQ; float* dK; float* dV;
-    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, B, H, Nq, Nk, mask_kind, causal;
+    int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, B, H, Nq, Nk, mask_kind, causal, zero_attn;
     float scale;
     const uint8_t* kpad; const int32_t* cs; const int16_t* modq; const int16_t* modk; const uint8_t* dense;
 };
@@ -242,9 +242,11 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(Attn32 a) {
         mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
+    if (a.zero_attn) mx = fmaxf(mx, 0.f);                  // softmax1: the padded zero logit (fm_utils.py:28-30)
     float sum = 0.f;
     for (int k = t; k < a.Nk; k += 64) { const float e = expf(p[k] - mx); p[k] = e; sum += e; }
     sum = wave_sum(sum);
+    if (a.zero_attn) sum += expf(-mx);
     __syncthreads();
     const float inv = 1.0f / sum;
     float o = 0.f;                                          // thread t owns output dimension t
@@ -394,7 +396,7 @@ static int fill32(Attn32& a, const fm_attn_args* p) {
     a.Q = (const float*)p->Q; a.K = (const float*)p->K; a.V = (const float*)p->V; a.O = (float*)p->O;
     a.dO = (const float*)p->dO; a.dQ = (float*)p->dQ; a.dK = (float*)p->dK; a.dV = (float*)p->dV;
     a.ldq = p->ldq; a.ldk = p->ldk; a.ldv = p->ldv; a.ldo = p->ldo; a.lddo = p->lddo; a.lddq = p->lddq; a.lddk = p->lddk; a.lddv = p->lddv;
-    a.B = p->B; a.H = p->H; a.Nq = p->Nq; a.Nk = p->Nk; a.mask_kind = p->mask_kind; a.causal = p->causal; a.scale = p->scale;
+    a.B = p->B; a.H = p->H; a.Nq = p->Nq; a.Nk = p->Nk; a.mask_kind = p->mask_kind; a.causal = p->causal; a.scale = p->scale; a.zero_attn = p->zero_attn;
     a.kpad = (const uint8_t*)p->kpad; a.cs = p->cs; a.modq = p->modq; a.modk = p->modk; a.dense = (const uint8_t*)p->dense;
     return 0;
 }

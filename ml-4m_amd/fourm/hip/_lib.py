@@ -70,7 +70,7 @@ class AttnArgs(C.Structure):
                 ("scale", f32), ("causal", i32),
                 ("kpad", vp), ("cs", vp), ("modq", vp), ("modk", vp), ("dense", vp),
                 ("dO", vp), ("dQ", vp), ("dK", vp), ("dV", vp),
-                ("lddo", i32), ("lddq", i32), ("lddk", i32), ("lddv", i32), ("force_tr", i32), ("kv_batch_rows", i32)]
+                ("lddo", i32), ("lddq", i32), ("lddk", i32), ("lddv", i32), ("force_tr", i32), ("kv_batch_rows", i32), ("zero_attn", i32)]
 
 
 class ModDesc(C.Structure):

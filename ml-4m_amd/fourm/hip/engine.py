@@ -567,7 +567,7 @@ class FourMEngine:
         if sv is not None:
             sm = self._buf(sv, tag, "sm", (B, self.H, N), torch.float32)
             sl = self._buf(sv, tag, "sl", (B, self.H, N), torch.float32)
-        ops.attn_fwd(q_in, k_in, qkv[:, 2 * D:], o, B, self.H, N, N, self.scale, stat_m=sm, stat_l=sl, **mask)
+        ops.attn_fwd(q_in, k_in, qkv[:, 2 * D:], o, B, self.H, N, N, self.scale, stat_m=sm, stat_l=sl, zero_attn=getattr(attn, "allow_zero_attn", False), **mask)
         self._residual(o, attn.proj, x_res, x_out, R, D, D, defer=True)       # (every caller normalises x_out next)
 
     def _cross_attn_fwd(self, attn, hq, hc, x_res, x_out, B, M, N, Rq, Rqp, Rc, Rcp, mask, sv, tag):
@@ -584,7 +584,7 @@ class FourMEngine:
         q_in, k_in = q, kv[:, :D]
         if self.qk_norm:
             q_in, k_in = self._qk_norm_fwd(attn, q_in, k_in, Rq, Rc, Rqp, Rcp, sv, tag, "xqkn")
-        ops.attn_fwd(q_in, k_in, kv[:, D:], o, B, self.H, M, N, self.scale, stat_m=sm, stat_l=sl, **mask)
+        ops.attn_fwd(q_in, k_in, kv[:, D:], o, B, self.H, M, N, self.scale, stat_m=sm, stat_l=sl, zero_attn=getattr(attn, "allow_zero_attn", False), **mask)
         self._residual(o, attn.proj, x_res, x_out, Rq, D, D, defer=True)
 
     def encoder_block_fwd(self, blk, x_in, B, N, mask, sv, tag, defer_out=False, out_name=None, dp=None):
@@ -851,11 +851,11 @@ class FourMEngine:
         if self.qk_norm:
             dqkn = ws.get("bwd.dqkn", (Rp, 2 * D), bf)
             ops.attn_bwd(sv["qkn.q"], sv["qkn.k"], qkv[:, 2 * D:], sv["o"], do, dqkn[:, :D], dqkn[:, D:], dqkv[:, 2 * D:],
-                         B, self.H, N, N, self.scale, sv["sm"], sv["sl"], **mask)
+                         B, self.H, N, N, self.scale, sv["sm"], sv["sl"], zero_attn=getattr(attn, "allow_zero_attn", False), **mask)
             self._qk_norm_bwd(attn, sv, "qkn", dqkn[:, :D], dqkn[:, D:], qkv[:, :D], qkv[:, D:2 * D], dqkv[:, :D], dqkv[:, D:2 * D], R, R)
         else:
             ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["o"], do, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
-                         B, self.H, N, N, self.scale, sv["sm"], sv["sl"], **mask)
+                         B, self.H, N, N, self.scale, sv["sm"], sv["sl"], zero_attn=getattr(attn, "allow_zero_attn", False), **mask)
         self._dW(dqkv, sv["h1"], attn.qkv, R64)
         dh = ws.get("bwd.dh", (Rp, D), bf)
         ops.gemm_nt(dqkv, self.wt(attn.qkv.weight), dh, M=R, N=D, K=3 * D)
@@ -902,11 +902,11 @@ class FourMEngine:
             dqn = ws.get("bwd.dqn", (Rqp, D), bf)
             dkn = ws.get("bwd.dkn", (Rcp, D), bf)
             ops.attn_bwd(sv["xqkn.q"], sv["xqkn.k"], kv[:, D:], sv["o2"], do, dqn, dkn, dkv[:, D:], B, self.H, M, N, self.scale,
-                         sv["sm2"], sv["sl2"], **xa_mask)
+                         sv["sm2"], sv["sl2"], zero_attn=getattr(xa, "allow_zero_attn", False), **xa_mask)
             self._qk_norm_bwd(xa, sv, "xqkn", dqn, dkn, sv["q"], kv[:, :D], dq, dkv[:, :D], Rq, Rc)
         else:
             ops.attn_bwd(sv["q"], kv[:, :D], kv[:, D:], sv["o2"], do, dq, dkv[:, :D], dkv[:, D:], B, self.H, M, N, self.scale,
-                         sv["sm2"], sv["sl2"], **xa_mask)
+                         sv["sm2"], sv["sl2"], zero_attn=getattr(xa, "allow_zero_attn", False), **xa_mask)
         self._dW(dq, sv["hq"], xa.q, Rq)
         dhq = ws.get("bwd.dh", (Rqp, D), bf)
         ops.gemm_nt(dq, self.wt(xa.q.weight), dhq, M=Rq, N=D, K=D)

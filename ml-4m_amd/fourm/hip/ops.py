@@ -254,7 +254,7 @@ def headnorm_bwd(dy, x, w, stats, dx, dw, db, R, H):
 # ---------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------
-def _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr):
+def _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr, zero_attn=False):
     a = L.AttnArgs()
     a.Q, a.K, a.V, a.O = _p(q), _p(k), _p(v), _p(o)
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
@@ -262,15 +262,15 @@ def _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk,
     a.scale, a.causal = scale, 1 if causal else 0
     a.kpad, a.cs, a.modq, a.modk, a.dense = _p(kpad), _p(cs), _p(modq), _p(modk), _p(dense)
     a.stat_m, a.stat_l = _p(stat_m), _p(stat_l)
-    a.force_tr = force_tr
+    a.force_tr, a.zero_attn = force_tr, 1 if zero_attn else 0
     return a
 
 
 def attn_fwd(q, k, v, o, B, H, Nq, Nk, scale, *, mask_kind=L.MASK_NONE, kpad=None, cs=None, modq=None, modk=None, dense=None,
-             causal=False, stat_m=None, stat_l=None, force_tr=-1, kv_batch_rows=0):
+             causal=False, stat_m=None, stat_l=None, force_tr=-1, kv_batch_rows=0, zero_attn=False):
     """q/k/v/o: 2-D bf16 views whose row t of sample b is row b*N + t; head h occupies columns [64h, 64h+64).
     kv_batch_rows > Nk: k / v are views of a K/V cache whose sample b starts at row b * kv_batch_rows."""
-    a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
+    a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr, zero_attn)
     a.kv_batch_rows = kv_batch_rows
     if q.dtype == torch.float32:
         L.check(L.attn_f32_fwd(C.byref(a), _stream()))
@@ -281,8 +281,8 @@ def attn_fwd(q, k, v, o, B, H, Nq, Nk, scale, *, mask_kind=L.MASK_NONE, kpad=Non
 
 
 def attn_bwd(q, k, v, o, do, dq, dk, dv, B, H, Nq, Nk, scale, stat_m, stat_l, *, mask_kind=L.MASK_NONE, kpad=None, cs=None,
-             modq=None, modk=None, dense=None, causal=False, force_tr=-1):
-    a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr)
+             modq=None, modk=None, dense=None, causal=False, force_tr=-1, zero_attn=False):
+    a = _attn_args(q, k, v, o, B, H, Nq, Nk, scale, mask_kind, kpad, cs, modq, modk, dense, causal, stat_m, stat_l, force_tr, zero_attn)
     a.dO, a.dQ, a.dK, a.dV = _p(do), _p(dq), _p(dk), _p(dv)
     a.lddo, a.lddq, a.lddk, a.lddv = do.stride(0), dq.stride(0), dk.stride(0), dv.stride(0)
     if q.dtype == torch.float32:

@@ -102,8 +102,6 @@ class GatedMlp(nn.Module):
 def _check_attn_args(attn_drop, proj_drop, allow_zero_attn):
     if attn_drop or proj_drop:
         raise NotImplementedError("attention / projection dropout is not implemented in the HIP path")
-    if allow_zero_attn:
-        raise NotImplementedError("softmax1 (allow_zero_attn) is not implemented in the HIP path")
 
 
 class Attention(nn.Module):
@@ -114,6 +112,7 @@ class Attention(nn.Module):
         _check_attn_args(attn_drop, proj_drop, allow_zero_attn)
         self.num_heads = num_heads
         self.scale = (dim // num_heads) ** -0.5
+        self.allow_zero_attn = allow_zero_attn          # softmax1 (upstream fm_utils.py:28-30): fm_attn_args.zero_attn
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim, bias=proj_bias)
 
@@ -127,6 +126,7 @@ class CrossAttention(nn.Module):
         _check_attn_args(attn_drop, proj_drop, allow_zero_attn)
         self.num_heads = num_heads
         self.scale = (dim // num_heads) ** -0.5
+        self.allow_zero_attn = allow_zero_attn
         self.q = nn.Linear(dim, dim, bias=qkv_bias)
         self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim, bias=proj_bias)

@@ -448,11 +448,12 @@ class GenerationSampler(nn.Module):
                     row = c.view(B, Tc * 3 * D)[:, p * 3 * D:(p + 1) * 3 * D]              # this token's q | k | v inside the cache
                     ops.gemm_nt(h, eng.w(sa.qkv.weight), row, bias=sa.qkv.bias, M=B, N=3 * D, K=D)
                     flat = c.view(B * Tc, 3 * D)
-                    ops.attn_fwd(row[:, :D], flat[:, D:2 * D], flat[:, 2 * D:], o, B, H, 1, p + 1, eng.scale, kv_batch_rows=Tc)
+                    ops.attn_fwd(row[:, :D], flat[:, D:2 * D], flat[:, 2 * D:], o, B, H, 1, p + 1, eng.scale, kv_batch_rows=Tc,
+                                 zero_attn=getattr(blk.self_attn, "allow_zero_attn", False))
                     ops.gemm_nt(o, eng.w(sa.proj.weight), y1, epilogue=L.EPI_RESIDUAL, res=y, bias=sa.proj.bias, M=B, N=D, K=D)
                     ops.layernorm_fwd(y1, blk.query_norm.weight, blk.query_norm.bias, h, eps=blk.query_norm.eps, R=B)
                     ops.gemm_nt(h, eng.w(xa.q.weight), q2, bias=xa.q.bias, M=B, N=D, K=D)
-                    ops.attn_fwd(q2, kvc[l][:, :D], kvc[l][:, D:], o, B, H, 1, N, eng.scale, **emask)
+                    ops.attn_fwd(q2, kvc[l][:, :D], kvc[l][:, D:], o, B, H, 1, N, eng.scale, zero_attn=getattr(blk.cross_attn, "allow_zero_attn", False), **emask)
                     ops.gemm_nt(o, eng.w(xa.proj.weight), y2, epilogue=L.EPI_RESIDUAL, res=y1, bias=xa.proj.bias, M=B, N=D, K=D)
                     ops.layernorm_fwd(y2, blk.norm2.weight, blk.norm2.bias, h, eps=blk.norm2.eps, R=B)
                     y = yb if y is ya else ya

@@ -107,6 +107,7 @@ class TrunkCfg:
     causal: bool = False       # decoder_causal_mask
     sep: bool = True           # decoder_sep_mask
     registers: int = 0
+    zero_attn: bool = False    # allow_zero_attn of every Attention / CrossAttention (Block argument upstream)
     eps: float = 1e-6
     mods: List[ModSpec] = field(default_factory=list)
 
@@ -349,9 +350,11 @@ def _ln(P, pre: str, x: Tensor, cfg: TrunkCfg, num: _Num) -> Tensor:
     return num.layer_norm(x, P[pre + ".weight"], P.get(pre + ".bias"), cfg.eps)
 
 
-def _softmax_masked(scores: Tensor, blocked: Optional[Tensor], num: _Num) -> Tensor:
+def _softmax_masked(scores: Tensor, blocked: Optional[Tensor], num: _Num, zero_attn: bool = False) -> Tensor:
     if blocked is not None:
         scores = scores.masked_fill(blocked, num.neg_fill)
+    if zero_attn:            # softmax1 (fm_utils.py:28-30, :171-172): a zero logit joins the softmax, its probability is dropped
+        return torch.softmax(F.pad(scores, (0, 1)), -1)[..., :-1]
     return torch.softmax(scores, -1)
 
 
@@ -367,7 +370,7 @@ def _attend(q, k, v, blocked, cfg: TrunkCfg, num: _Num, P=None, pre=None) -> Ten
         q = num.layer_norm(q, P[pre + ".q_norm.weight"], P.get(pre + ".q_norm.bias"), cfg.eps)
         k = num.layer_norm(k, P[pre + ".k_norm.weight"], P.get(pre + ".k_norm.bias"), cfg.eps)
     s = num.r(num.r(num.r(q) @ num.r(k).transpose(-1, -2)) * (q.shape[-1] ** -0.5))
-    p = _softmax_masked(s, blocked, num)
+    p = _softmax_masked(s, blocked, num, cfg.zero_attn)
     o = num.r(num.r(p) @ num.r(v))
     return o.transpose(1, 2).reshape(o.shape[0], o.shape[2], -1)
 

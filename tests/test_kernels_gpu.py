@@ -678,3 +678,50 @@ def test_adamw_matches_torch():
     ops.clip_coef(ss, 1.0, nrm, coef)
     assert abs(float(nrm) - float(g.norm())) < 1e-3 * float(g.norm())
     assert abs(float(coef) - min(1.0, 1.0 / (float(g.norm()) + 1e-6))) < 1e-6
+
+
+@pytest.mark.parametrize("kind,Nq,Nk", [("none", 128, 128), ("keypad", 100, 100), ("decoder", 64, 64), ("keypad", 40, 130)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_attention_zero_attn(kind, Nq, Nk, dtype):
+    """allow_zero_attn (upstream softmax1, fm_utils.py:28-30): p = softmax(pad(scores, one zero logit))[..., :-1], forward and backward,
+    on the bf16 kernels and on the fp32 verification kernels; small and large scores (the zero logit dominates / vanishes)."""
+    import torch.nn.functional as F
+    ops, L = _ops()
+    B, H = 2, 2
+    D = H * 64
+    scale = 64 ** -0.5
+    cast = (lambda t: bf(t)) if dtype == torch.bfloat16 else (lambda t: t.float().contiguous())
+    # every key shares a component u; queries run from -30 u (all scores ~ -11: the zero logit takes the mass) to +30 u (it vanishes)
+    u = torch.nn.functional.normalize(randn(1, 64, seed=59), dim=-1).repeat(1, H)
+    q2 = cast(randn(B * Nq, D, seed=60) * 0.5 + torch.linspace(-30.0, 30.0, B * Nq, device=DEV)[:, None] * u)
+    kv = randn(B * Nk, 2 * D, seed=61) * 1.5
+    kv[:, :D] = kv[:, :D] * 0.2 + 3.0 * u
+    kv = cast(kv)
+    k2, v2 = kv[:, :D], kv[:, D:]
+    mk = make_masks(kind, B, Nq, Nk, seed=62)
+    kinds = dict(none=L.MASK_NONE, keypad=L.MASK_KEYPAD, decoder=L.MASK_DECODER)
+    o = torch.zeros(B * Nq, D, device=DEV, dtype=dtype)
+    sm, sl = torch.zeros(B, H, Nq, device=DEV), torch.zeros(B, H, Nq, device=DEV)
+    kw = dict(mask_kind=kinds[kind], kpad=mk["kpad"], cs=mk["cs"], modq=mk["modq"], modk=mk["modk"], zero_attn=True)
+    ops.attn_fwd(q2, k2, v2, o, B, H, Nq, Nk, scale, stat_m=sm, stat_l=sl, **kw)
+    qh = q2.reshape(B, Nq, H, 64).transpose(1, 2).float().requires_grad_(True)
+    kh = k2.reshape(B, Nk, H, 64).transpose(1, 2).float().requires_grad_(True)
+    vh = v2.reshape(B, Nk, H, 64).transpose(1, 2).float().requires_grad_(True)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if mk["blocked"] is not None:
+        s = s.masked_fill(mk["blocked"], NEG)
+    p = torch.softmax(F.pad(s, (0, 1)), -1)[..., :-1]
+    ref = p @ vh
+    assert float(p.sum(-1).min()) < 0.1 and float(p.sum(-1).max()) > 0.99                  # both regimes are in the data
+    oh = o.reshape(B, Nq, H, 64).transpose(1, 2).float()
+    tol = 8e-3 if dtype == torch.bfloat16 else 2e-5
+    assert rel_err(oh, ref) < tol, rel_err(oh, ref)
+    plain = torch.softmax(s, -1) @ vh
+    assert rel_err(plain, ref) > 10 * tol                                                  # the flag matters here
+    do = cast(randn(B * Nq, D, seed=63))
+    ref.backward(do.reshape(B, Nq, H, 64).transpose(1, 2).float())
+    dq, dk, dv = (torch.zeros(B * n, D, device=DEV, dtype=dtype) for n in (Nq, Nk, Nk))
+    ops.attn_bwd(q2, k2, v2, o, do, dq, dk, dv, B, H, Nq, Nk, scale, sm, sl, **kw)
+    for name, got, want, n in (("dq", dq, qh.grad, Nq), ("dk", dk, kh.grad, Nk), ("dv", dv, vh.grad, Nk)):
+        got = got.reshape(B, n, H, 64).transpose(1, 2).float()
+        assert rel_err(got, want) < (2e-2 if dtype == torch.bfloat16 else 5e-5), (name, rel_err(got, want))

@@ -266,3 +266,51 @@ print("ok")
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     p = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + child], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0 and "ok" in p.stdout, (p.stdout + p.stderr)[-3000:]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference tree not on this machine")
+def test_oracle_zero_attn_matches_upstream():
+    """allow_zero_attn (softmax1, fm_utils.py:28-30): oracle vs the unmodified upstream attention modules with the flag set."""
+    import subprocess
+    import sys
+    child = r'''
+import sys, os, random
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden")); sys.path.insert(0, ROOT)
+import make_golden as MG
+import dataclasses, torch
+from oracle import fourm_oracle as O
+from tests.golden.cases import build_case
+for name in ("micro_swiglu", "micro_qknorm"):
+    case = build_case(name)
+    cfg, sd, md = dataclasses.replace(case["cfg"], zero_attn=True), case["sd"], case["mod_dict"]
+    model = MG.upstream_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    model.load_state_dict(sd, strict=True)
+    n = 0
+    for mod in model.modules():
+        if hasattr(mod, "allow_zero_attn"):
+            mod.allow_zero_attn = True; n += 1
+    assert n == len(model.encoder) + 2 * len(model.decoder)
+    model.train()
+    random.seed(case["order_seed"])
+    loss, _ = model(MG.clone_mod_dict(md), case["N"], case["M"], loss_type=case["loss_type"])
+    loss.sum().backward()
+    P = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    for m in cfg.mods:
+        if m.in_enc and m.in_dec:
+            P[f"decoder_embeddings.{m.name}.mod_emb"] = P[f"encoder_embeddings.{m.name}.mod_emb"]
+        if m.in_dec and case["share_embedding"]:
+            P[f"decoder_embeddings.{m.name}.to_logits.weight"] = P[f"decoder_embeddings.{m.name}.token_emb.weight"]
+    order = MG.dec_order_for_seed([n_ for n_ in md if n_ in model.decoder_embeddings], case["order_seed"])
+    ol, _ = O.fourm_forward(P, cfg, md, case["N"], case["M"], order, loss_type=case["loss_type"])
+    ol.sum().backward()
+    plain, _ = O.fourm_forward({k: v.detach() for k, v in P.items()}, case["cfg"], md, case["N"], case["M"], order, loss_type=case["loss_type"])
+    assert abs(float(plain.sum()) - float(ol.sum())) > 1e-6                           # the flag changes the result
+    assert abs(float(ol.sum()) - float(loss.sum())) < 2e-5 * abs(float(loss.sum())), (float(ol.sum()), float(loss.sum()))
+    for k, p in model.named_parameters():
+        if p.grad is not None and P[k].grad is not None and float(p.grad.norm()) > 1e-8:
+            assert float((P[k].grad - p.grad).norm() / p.grad.norm()) < 1e-3, k
+    print("ok")
+'''
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    p = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + child], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0 and p.stdout.count("ok") == 2, (p.stdout + p.stderr)[-3000:]
