@@ -33,6 +33,7 @@ MOD21_IN = ("caption-t5_caption-det-metadata-rgb@224-tok_rgb@224-tok_normal@224-
 MOD21_OUT = [m for m in MOD21_IN if m not in ("rgb@224", "t5_caption")]
 MODS = {"mod7": (MOD7_IN, MOD7_OUT), "mod21": (MOD21_IN, MOD21_OUT)}
 BF16_PEAK_TFLOPS = 2500.0          # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+F32_MATRIX_PEAK_TFLOPS = 157.3     # v_mfma_f32_*_f32 (f32 in / f32 accumulate), same guide: 1/16 of the bf16 rate
 HBM_PEAK_GBS = 8000.0
 
 
@@ -416,8 +417,13 @@ def main_vq(a):
         traffic, detail = (None, None)
         if world == 1 and not a.no_traffic and fam in KERNEL_REGEX:
             traffic, detail = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0"), worker_args=["--workload", "vq", "--batch", str(batch)])
-        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
-                           "kernel": f"{name} (csrc/gemm.hip)", "traffic": traffic, "traffic_detail": detail, "launches_per_step": d["n"] // 2,
+        # the fp32 tail (tanh post-MLP, upstream disables autocast there) runs on v_mfma_f32_32x32x2_f32: exact fp32 at 1/16 of the bf16
+        # rate - its launches are priced against the fp32 matrix peak of MI355X_MICROARCH.md, every other kernel against the bf16 peak
+        f32_kernel = name.startswith("gemm_f32")
+        peak = F32_MATRIX_PEAK_TFLOPS if f32_kernel else BF16_PEAK_TFLOPS
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                           "kernel": f"{name} ({'csrc/fp32_verify.hip, fp32 MFMA: peak = the fp32 matrix rate' if f32_kernel else 'csrc/gemm.hip'})",
+                           "traffic": traffic, "traffic_detail": detail, "launches_per_step": d["n"] // 2,
                            "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms,
                            "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
         out["kernel_breakdown_ms_per_step"] = {k: round(v["ms"] / 2, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}

@@ -417,6 +417,17 @@ int fm_vq_latent_grad(const void* z, int ldz, const void* embed, const int64_t* 
                       float commitment_weight, void* dz, int ld_dz, void* commit_value, int R, int D, void* stream);
 int fm_tanh_bwd_f32(const void* dy, const void* t, void* dx, int R, int N, int ld, void* stream);
 int fm_embed_rows_f32(const void* table, const int64_t* idx, void* out, int ld_out, int R, int D, void* stream);
+/* Input variants of the tokenizer (VQ.prepare_input, vq/vqvae.py:269-286) folded into the patch gather: fm_vq_patchify with
+ *   labels != NULL: class maps int64 (B, H, W) embedded by cls_emb f32 (n_labels, C) (semantic segmentation, n_labels; img unused);
+ *   scale / shift: DEVICE float[C] (or both NULL): value = scale[c] * v + shift[c] (undo_std: 2 * denormalize(x) - 1).
+ * fm_vq_cls_emb_bwd: d cls_emb[label] += the bf16 gradient of the patch rows (B * G, ld), fp32 atomics (the embedding's backward).
+ * fm_vq_latent_grad_normalized: fm_vq_latent_grad for norm_latents = True (quantize_lucid.py:525-527): x = l2norm(z) enters the
+ *   commitment term, dz carries the backward of the normalisation. */
+int fm_vq_patchify_ex(const void* img, const int64_t* labels, const void* cls_emb, const void* scale, const void* shift, void* out, int ld_out,
+                      int B, int C, int H, int W, int P, void* stream);
+int fm_vq_cls_emb_bwd(const void* d_patches, int ld, const int64_t* labels, void* d_cls_emb, int B, int C, int H, int W, int P, void* stream);
+int fm_vq_latent_grad_normalized(const void* z, int ldz, const void* embed, const int64_t* tokens, const void* dquant, int ld_dquant, const void* grad_loss,
+                                 float commitment_weight, void* dz, int ld_dz, void* commit_value, int R, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Data side: input / target masks of an image-like modality (UnifiedMasking.image_mask, fourm/data/masking.py:237-266)

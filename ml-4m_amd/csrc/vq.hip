@@ -299,3 +299,106 @@ extern "C" int fm_embed_rows_f32(const void* table, const int64_t* idx, void* ou
     FM_CHECK_LAUNCH("fm_embed_rows_f32");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Input variants of the tokenizer (VQ.prepare_input, vq/vqvae.py:269-286): ImageNet-standardised pixels brought back to [-1, 1]
+// (undo_std) and semantic-segmentation class maps embedded by a learned table (cls_emb), folded into the patch gather.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// out[(b*G + g)][c*P*P + py*P + px] = scale[c] * v + shift[c],  v = img[b][c][y][x]  or  cls_emb[labels[b][y][x]][c]
+__global__ __launch_bounds__(256) void vq_patchify_ex_kernel(const float* __restrict__ img, const long long* __restrict__ labels, const float* __restrict__ cls_emb,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, bf16_t* __restrict__ out, int ldo,
+                                                             int B, int C, int H, int W, int P) {
+    const int gw = W / P, gh = H / P, F = C * P * P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = blockIdx.x * 4 + wave; r < B * gh * gw; r += gridDim.x * 4) {
+        const int b = r / (gh * gw), g = r % (gh * gw), gy = g / gw, gx = g % gw;
+        for (int f = lane; f < ldo; f += 64) {
+            float v = 0.f;
+            if (f < F) {
+                const int c = f / (P * P), py = (f / P) % P, px = f % P;
+                const size_t pix = (size_t)(gy * P + py) * W + gx * P + px;
+                v = labels ? cls_emb[(size_t)labels[(size_t)b * H * W + pix] * C + c] : img[((size_t)b * C + c) * H * W + pix];
+                if (scale) v = scale[c] * v + shift[c];
+            }
+            out[(size_t)r * ldo + f] = f2bf(v);
+        }
+    }
+}
+
+// d cls_emb[labels[b][y][x]][c] += d patches[(b*G + g)][c*P*P + py*P + px]   (bf16 patch-row gradients, fp32 atomics)
+__global__ __launch_bounds__(256) void vq_cls_emb_bwd_kernel(const bf16_t* __restrict__ dp, int ld, const long long* __restrict__ labels, float* __restrict__ d_emb,
+                                                             int B, int C, int H, int W, int P) {
+    const int gw = W / P;
+    const size_t total = (size_t)B * H * W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int x = (int)(e % W), y = (int)((e / W) % H), b = (int)(e / ((size_t)W * H));
+        const size_t r = (size_t)b * (H / P) * gw + (y / P) * gw + x / P;
+        const long long k = labels[e];
+        for (int c = 0; c < C; ++c) unsafeAtomicAdd(d_emb + (size_t)k * C + c, bf2f(dp[r * ld + (c * P + y % P) * P + x % P]));
+    }
+}
+
+// Training-mode quantizer with norm_latents (quantize_lucid.py:525-527, :533-541): x = l2norm(z) enters the codebook and the commitment term.
+//   dx = dquant + g_loss * w * 2 (x - q) / (R D);   dz = (dx - x <x, dx>) / max(|z|, 1e-12)      (backward of F.normalize)
+__global__ __launch_bounds__(256) void vq_latent_grad_norm_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ embed, const long long* __restrict__ tokens,
+                                                                  const float* __restrict__ dq, int lddq, const float* __restrict__ g_loss, float weight,
+                                                                  float* __restrict__ dz, int lddz, float* __restrict__ commit, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float gl = g_loss ? g_loss[0] : 0.f;
+    const float coef = gl * weight * 2.0f / ((float)R * (float)D);
+    float sq = 0.f;
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
+        const float zv = lane < D ? z[(size_t)r * ldz + lane] : 0.f;
+        const float nrm = fmaxf(sqrtf(wave_sum(zv * zv)), 1e-12f);
+        const float x = zv / nrm;
+        const float diff = lane < D ? x - embed[(size_t)tokens[r] * D + lane] : 0.f;
+        sq += diff * diff;
+        if (dz) {
+            const float dx = lane < D ? (dq ? dq[(size_t)r * lddq + lane] : 0.f) + coef * diff : 0.f;
+            const float dot = wave_sum(x * dx);
+            if (lane < D) dz[(size_t)r * lddz + lane] = (dx - x * dot) / nrm;
+        }
+    }
+    if (commit) {
+        sq = wave_sum(sq);
+        if (lane == 0 && sq != 0.f) unsafeAtomicAdd(commit, sq * weight / ((float)R * (float)D));
+    }
+}
+
+}  // namespace
+
+extern "C" int fm_vq_patchify_ex(const void* img, const int64_t* labels, const void* cls_emb, const void* scale, const void* shift, void* out, int ld_out,
+                                 int B, int C, int H, int W, int P, void* stream) {
+    FM_CHECK_ARG(out && B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0 && ld_out >= C * P * P, "fm_vq_patchify_ex: bad argument");
+    FM_CHECK_ARG((labels && cls_emb) || (img && !labels), "fm_vq_patchify_ex: pass pixels (img) or class ids (labels + cls_emb)");
+    FM_CHECK_ARG((scale == nullptr) == (shift == nullptr), "fm_vq_patchify_ex: scale and shift go together");
+    int grid = (B * (H / P) * (W / P) + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(vq_patchify_ex_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)img, (const long long*)labels, (const float*)cls_emb,
+                       (const float*)scale, (const float*)shift, (bf16_t*)out, ld_out, B, C, H, W, P);
+    FM_CHECK_LAUNCH("fm_vq_patchify_ex");
+    return 0;
+}
+
+extern "C" int fm_vq_cls_emb_bwd(const void* d_patches, int ld, const int64_t* labels, void* d_cls_emb, int B, int C, int H, int W, int P, void* stream) {
+    FM_CHECK_ARG(d_patches && labels && d_cls_emb && B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0 && ld >= C * P * P, "fm_vq_cls_emb_bwd: bad argument");
+    size_t blocks = ((size_t)B * H * W + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(vq_cls_emb_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_patches, ld, (const long long*)labels,
+                       (float*)d_cls_emb, B, C, H, W, P);
+    FM_CHECK_LAUNCH("fm_vq_cls_emb_bwd");
+    return 0;
+}
+
+extern "C" int fm_vq_latent_grad_normalized(const void* z, int ldz, const void* embed, const int64_t* tokens, const void* dquant, int ld_dquant, const void* grad_loss,
+                                            float commitment_weight, void* dz, int ld_dz, void* commit_value, int R, int D, void* stream) {
+    FM_CHECK_ARG(z && embed && tokens && R > 0 && D > 0 && D <= 64 && (dz || commit_value), "fm_vq_latent_grad_normalized: bad argument (D <= 64)");
+    int grid = (R + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(vq_latent_grad_norm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)z, ldz, (const float*)embed, (const long long*)tokens,
+                       (const float*)dquant, ld_dquant, (const float*)grad_loss, commitment_weight, (float*)dz, ld_dz, (float*)commit_value, R, D);
+    FM_CHECK_LAUNCH("fm_vq_latent_grad_normalized");
+    return 0;
+}

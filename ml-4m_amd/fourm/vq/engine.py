@@ -115,26 +115,36 @@ def _post_mlp_fwd(eng, vit, stream, R, st, prefix):
     return out
 
 
-def _tokens(enc, x, st=None):
+def _tokens(enc, x, st=None, prep=None):
     """(B, C, H, W) -> fp32 residual stream (Rp, D) after the last block (+ post MLP), plus (B, n_h, n_w).
-    ``st`` (a dict) keeps what the backward needs (tokenizer training)."""
+    ``st`` (a dict) keeps what the backward needs (tokenizer training).  ``prep`` (VQ._prep): class maps (B, H, W) embedded by a table
+    and / or a per-channel affine map, applied inside the patch gather."""
     eng = _engine(enc)
     ws, D = eng.ws, eng.D
-    B, C, Hh, Ww = x.shape
+    labels = prep is not None and prep["cls_emb"] is not None
+    if labels:
+        (B, Hh, Ww), C = x.shape, prep["cls_emb"].shape[1]
+    else:
+        B, C, Hh, Ww = x.shape
     P = enc.P_H
     assert enc.P_H == enc.P_W and Hh % P == 0 and Ww % P == 0, f"Image sizes {Hh}x{Ww} must be divisible by patch size {P}"
     nh, nw = Hh // P, Ww // P
     G, R = nh * nw, B * nh * nw
     Rp = ru(R, 128)
-    x = x.float().contiguous()
+    x = x.long().contiguous() if labels else x.float().contiguous()
     feat = C * P * P
     patches = ws.get("vq.patches", (Rp, ru(feat, 64)), torch.bfloat16)
-    L.check(L.vq_patchify(ops._p(x), ops._p(patches), patches.stride(0), B, C, Hh, Ww, P, ops._stream()))
+    if prep is None:
+        L.check(L.vq_patchify(ops._p(x), ops._p(patches), patches.stride(0), B, C, Hh, Ww, P, ops._stream()))
+    else:
+        emb = prep["cls_emb"].detach().float().contiguous() if labels else None
+        L.check(L.vq_patchify_ex(None if labels else ops._p(x), ops._p(x) if labels else None, ops._p(emb), ops._p(prep["scale"]), ops._p(prep["shift"]),
+                                 ops._p(patches), patches.stride(0), B, C, Hh, Ww, P, ops._stream()))
     pos = _pos_rows(eng, enc, B, nh, nw, Rp)
     stream = ws.get("vq.x0", (Rp, D), torch.float32)
     ops.gemm_nt(patches, eng.w(enc.proj.weight), stream, epilogue=L.EPI_RESIDUAL, res=pos, bias=enc.proj.bias, M=R, N=D, K=ru(feat, 64))
     if st is not None:
-        st.update(layers=[], patches=patches)
+        st.update(layers=[], patches=patches, labels=x if labels else None, image=(B, C, Hh, Ww))
     stream = _blocks_fwd(eng, enc, stream, B, G, st, "enc" if st is not None else "vit")
     if hasattr(enc, "post_mlp"):
         stream = _post_mlp_fwd(eng, enc, stream, R, st, "vq")
@@ -179,7 +189,7 @@ def _assign(vq, eng, z, R, G, B, nh, nw, want_quant):
 @torch.no_grad()
 def vq_encode(vq, x):
     enc = vq.encoder
-    eng, stream, (B, nh, nw) = _tokens(enc, x)
+    eng, stream, (B, nh, nw) = _tokens(enc, x, prep=vq._prep())
     ws, D, Ld = eng.ws, eng.D, vq.latent_dim
     G, R = nh * nw, B * nh * nw
     # 1x1 convolution to the latent dimension: fp32 like the codebook search that follows (the tokenization script runs without
@@ -287,21 +297,20 @@ def vqvae_train_forward(vq, x):
     st = dict(enc={} if trainable_enc else None, dec={})
     if enc.pos_emb.requires_grad or vq.decoder.pos_emb.requires_grad:
         raise NotImplementedError("learnable position embeddings have no gradient kernel (learnable_pos_emb=False upstream default)")
-    eng, stream, (B, nh, nw) = _tokens(enc, x, st["enc"])
+    eng, stream, (B, nh, nw) = _tokens(enc, x, st["enc"], prep=vq._prep())
     ws, D, Ld = eng.ws, eng.D, vq.latent_dim
     G, R = nh * nw, B * nh * nw
     z = ws.get("vq.z", (stream.shape[0], Ld), torch.float32)
     ops.gemm_nt(stream, vq.quant_proj.weight.detach().reshape(Ld, D), z, epilogue=L.EPI_F32, bias=vq.quant_proj.bias, M=R, N=Ld, K=D)
-    if vq.quantize.norm_latents:
-        raise NotImplementedError("norm_latents=True: the l2-normalisation in front of the commitment loss has no backward kernel")
+    lat_grad = L.vq_latent_grad_normalized if vq.quantize.norm_latents else L.vq_latent_grad      # (norm_latents: x = l2norm(z), :525-527)
     tokens = _assign(vq, eng, z, R, G, B, nh, nw, None)
     q_rows = _quant_rows(vq, tokens, x.device)
     cw = float(vq.quantize.commitment_weight)
     code_loss = torch.zeros(1, dtype=torch.float32, device=x.device)
     cb = vq.quantize._codebook
     if cw > 0:
-        L.check(L.vq_latent_grad(ops._p(z), z.stride(0), ops._p(cb.embed), ops._p(tokens.reshape(-1)), None, 0, None, cw, None, 0,
-                                 ops._p(code_loss), R, Ld, ops._stream()))
+        L.check(lat_grad(ops._p(z), z.stride(0), ops._p(cb.embed), ops._p(tokens.reshape(-1)), None, 0, None, cw, None, 0,
+                         ops._p(code_loss), R, Ld, ops._stream()))
     dec = _decode_rows(vq, q_rows, B, nh, nw, st["dec"])
     st.update(z=z, tokens=tokens, x_enc_final=stream, dims=(B, nh, nw), embed_at_forward=cb.embed.clone() if vq.quantize.training else cb.embed)
     if vq.quantize.training:
@@ -352,8 +361,9 @@ def vqvae_train_backward(vq, st, g_dec, g_loss):
     z, tokens = st["z"], st["tokens"]
     dz = ews.get("bwd.dz", tuple(z.shape), f32)
     gl = None if g_loss is None else g_loss.reshape(1).float().contiguous()
-    L.check(L.vq_latent_grad(ops._p(z), z.stride(0), ops._p(st["embed_at_forward"]), ops._p(tokens.reshape(-1)), ops._p(dq), dq.stride(0), ops._p(gl),
-                             float(vq.quantize.commitment_weight), ops._p(dz), dz.stride(0), None, R, Ld, ops._stream()))
+    lat_grad = L.vq_latent_grad_normalized if vq.quantize.norm_latents else L.vq_latent_grad
+    L.check(lat_grad(ops._p(z), z.stride(0), ops._p(st["embed_at_forward"]), ops._p(tokens.reshape(-1)), ops._p(dq), dq.stride(0), ops._p(gl),
+                     float(vq.quantize.commitment_weight), ops._p(dz), dz.stride(0), None, R, Ld, ops._stream()))
     # ---- quant_proj (fp32) -------------------------------------------------------------------------------------------------------------
     qp = vq.quant_proj
     xf = st["x_enc_final"]
@@ -369,7 +379,17 @@ def vqvae_train_backward(vq, st, g_dec, g_loss):
         ops.f32_to_bf16(ge, ge_bf)
     _blocks_bwd(ee, enc, se, ge, ge_bf, B, G)
     ee._dW(ge_bf, se["patches"], enc.proj, R)
-    ee.attach(list(enc.parameters()) + list(qp.parameters()))
+    extra = []
+    if se["labels"] is not None and vq.cls_emb.weight.requires_grad:       # the class-embedding table behind the patch projection
+        Bi, Ci, Hi, Wi = se["image"]
+        P_ = enc.P_H
+        dpatch = ews.get("bwd.dpatch", tuple(se["patches"].shape), bf)
+        ops.gemm_nt(ge_bf, ee.wt(enc.proj.weight), dpatch, M=R, N=Ci * P_ * P_, K=De)
+        ee.open_window([vq.cls_emb.weight])
+        L.check(L.vq_cls_emb_bwd(ops._p(dpatch), dpatch.stride(0), ops._p(se["labels"]), ops._p(ee.grad_view(vq.cls_emb.weight)), Bi, Ci, Hi, Wi, P_,
+                                 ops._stream()))
+        extra = [vq.cls_emb.weight]
+    ee.attach(list(enc.parameters()) + list(qp.parameters()) + extra)
 
 
 class VQVAEStep(torch.autograd.Function):

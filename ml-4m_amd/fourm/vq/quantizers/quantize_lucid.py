@@ -102,9 +102,14 @@ class CosineSimCodebook(nn.Module):
         if self.threshold_ema_dead_code > 0:
             dead = self.cluster_size < self.threshold_ema_dead_code
             n_dead = int(dead.sum())                                     # (upstream reads mask.sum().item() as well)
-            if n_dead:
+            if n_dead and self.code_replacement_policy == "linde_buzo_gray":
+                # dead codes restart next to the most used ones (+ noise of 1e-10, re-normalised): quantize_lucid.py:351-356
+                most_used = self.cluster_size.argsort(descending=True)[:n_dead]
+                codes = self.embed[most_used]
+                self.embed[dead] = F.normalize(codes + torch.randn(codes.shape, device=codes.device, generator=generator) * 1e-10, p=2, dim=-1)
+            elif n_dead:
                 if self.code_replacement_policy != "batch_random":
-                    raise NotImplementedError(f"code_replacement_policy {self.code_replacement_policy!r} is not implemented")
+                    raise ValueError(f"{self.code_replacement_policy} is not a valid dead code replacement strategy.")
                 if self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                     raise NotImplementedError("distributed dead-code sampling (sample_vectors_distributed) is not implemented")
                 if R >= n_dead:

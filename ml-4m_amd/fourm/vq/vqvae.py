@@ -37,10 +37,8 @@ class VQ(nn.Module, PyTorchModelHubMixin):
             self.__init__(**copy.deepcopy(config))
             return
         super().__init__()
-        if n_labels is not None:
-            raise NotImplementedError("semantic-segmentation class embeddings (n_labels) are not implemented")
-        if undo_std:
-            raise NotImplementedError("undo_std=True is not implemented (normalise to [-1, 1] in the loader)")
+        if undo_std and (n_channels != 3 or n_labels is not None):
+            raise ValueError("undo_std expects ImageNet-standardised RGB input")
         if quant_type != "lucid":
             raise NotImplementedError(f"quant_type {quant_type!r} has no HIP kernel")
         if "vit" not in enc_type or not hasattr(vit_models, enc_type):
@@ -52,7 +50,10 @@ class VQ(nn.Module, PyTorchModelHubMixin):
                          code_replacement_policy=code_replacement_policy, commitment_weight=commitment_weight, kmeans_init=kmeans_init,
                          ckpt_path=ckpt_path, ignore_keys=ignore_keys, freeze_enc=freeze_enc, undo_std=undo_std).items():
             setattr(self, k, v)
-        self.cls_emb = None
+        # semantic segmentation (vqvae.py:141-146): class maps (B, H, W) are embedded by a learned table before the patch projection
+        self.cls_emb = nn.Embedding(num_embeddings=n_labels, embedding_dim=n_channels) if n_labels is not None else None
+        if n_labels is not None:
+            self.colorize = torch.randn(3, n_labels, 1, 1)
         self.encoder = getattr(vit_models, enc_type)(in_channels=n_channels, patch_size=patch_size, resolution=image_size_enc or image_size,
                                                      patch_proj=patch_proj, post_mlp=post_mlp)
         self.enc_dim = self.encoder.dim_tokens
@@ -80,7 +81,25 @@ class VQ(nn.Module, PyTorchModelHubMixin):
         return self
 
     def prepare_input(self, x: torch.Tensor) -> torch.Tensor:
+        """Upstream (vqvae.py:269-286) denormalises (undo_std) and embeds class maps (n_labels) here; this package folds both into the
+        patch gather of the encoder (fm_vq_patchify_ex), so the input passes through unchanged - see ``_prep``."""
         return x
+
+    def _prep(self):
+        """What the patch gather applies to the raw input: class-embedding table and / or a per-channel affine map."""
+        if self.cls_emb is None and not self.undo_std:
+            return None
+        prep = dict(cls_emb=self.cls_emb.weight if self.cls_emb is not None else None, scale=None, shift=None)
+        if self.undo_std:      # 2 * denormalize(x) - 1 with the ImageNet statistics (fourm/utils/misc.py:23-37): (2 std) x + (2 mean - 1)
+            dev = self.quant_proj.weight.device
+            mean, std = torch.tensor((0.485, 0.456, 0.406), device=dev), torch.tensor((0.229, 0.224, 0.225), device=dev)
+            prep["scale"], prep["shift"] = (2.0 * std).contiguous(), (2.0 * mean - 1.0).contiguous()
+        return prep
+
+    def to_rgb(self, x: torch.Tensor) -> torch.Tensor:
+        """Class scores / embeddings (B, n_labels, H, W) -> a pseudo-colour image for visualisation (vqvae.py:288-300)."""
+        x = torch.nn.functional.conv2d(x, weight=self.colorize.to(x))
+        return (x - x.min()) / (x.max() - x.min())
 
     def encode(self, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.LongTensor]:
         """(quant (B, latent_dim, h, w) f32, code_loss (1,), tokens (B, h, w) int64)   [vqvae.py:302-318]"""
@@ -130,7 +149,7 @@ class VQVAE(VQ):
         if "vit" not in dec_type or not hasattr(vit_models, dec_type):
             raise NotImplementedError(f"{dec_type} not implemented.")
         self.dec_type, self.out_conv = dec_type, out_conv
-        self.decoder = getattr(vit_models, dec_type)(out_channels=self.n_channels, patch_size=patch_size_dec or self.patch_size,
+        self.decoder = getattr(vit_models, dec_type)(out_channels=self.n_channels if self.n_labels is None else self.n_labels, patch_size=patch_size_dec or self.patch_size,
                                                      resolution=image_size_dec or self.image_size, out_conv=out_conv, post_mlp=self.post_mlp,
                                                      patch_proj=self.patch_proj)
         self.dec_dim = self.decoder.dim_tokens

@@ -106,11 +106,33 @@ def vit_stack(P, pre0, t, dim, depth, heads, eps, post_mlp, num, tail):
     return t
 
 
-def vq_encode(P: Dict[str, Tensor], cfg: VQCfg, x: Tensor, emulate_bf16: bool = False):
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+
+def prepare_input(P, x: Tensor, undo_std: bool = False) -> Tensor:
+    """VQ.prepare_input (vq/vqvae.py:269-286): ``2 * denormalize(x) - 1`` (denormalize = x * std + mean, fourm/utils/misc.py:23-37) and, when the
+    state dict holds ``cls_emb.weight`` and x is an integer class map (B, H, W), the class embedding 'b h w c -> b c h w'."""
+    if undo_std:
+        mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+        x = 2.0 * (x * std + mean) - 1.0
+    if not x.is_floating_point():
+        x = P["cls_emb.weight"][x].permute(0, 3, 1, 2)
+    return x
+
+
+def synthetic_labels(cfg: VQCfg, batch: int, n_labels: int, seed: int = 0) -> Tensor:
+    """Class maps (B, H, W) int64 in blocks of 4 x 4 pixels (segmentation-like)."""
+    g = torch.Generator().manual_seed(seed)
+    coarse = torch.randint(0, n_labels, (batch, cfg.image // 4, cfg.image // 4), generator=g)
+    return coarse.repeat_interleave(4, 1).repeat_interleave(4, 2).contiguous()
+
+
+def vq_encode(P: Dict[str, Tensor], cfg: VQCfg, x: Tensor, emulate_bf16: bool = False, undo_std: bool = False):
     """Returns (quant (B, L, h, w), tokens (B, h, w) int64, latents z (B, h*w, L) before normalisation).
     ``emulate_bf16`` rounds at upstream's autocast points: the patch projection and the 12 blocks.  The post-MLP (autocast
     disabled, vit_models.py:494-496), the 1x1 projection and the codebook search (quantize_lucid.py:388-390) stay fp32."""
     num, tail = _Num(emulate_bf16), _Num(False)
+    x = prepare_input(P, x, undo_std)
     B, C, H, W = x.shape
     p, g = cfg.patch, H // cfg.patch
     # Conv2d(k = s = p): patches ordered (c, py, px) against weight.view(D, -1)
@@ -168,7 +190,7 @@ def codebook_ema_update(embed: Tensor, cluster_size: Tensor, z: Tensor, ind: Ten
 DEC_DIMS = {"vit_s_dec": (512, 8, 8), "vit_b_dec": (768, 12, 12), "vit_l_dec": (1024, 24, 16)}
 
 
-def seeded_vqvae_state_dict(cfg: VQCfg, dec_type: str, seed: int = 0) -> Dict[str, Tensor]:
+def seeded_vqvae_state_dict(cfg: VQCfg, dec_type: str, seed: int = 0, n_labels: int = None) -> Dict[str, Tensor]:
     """Encoder / quantizer as seeded_vq_state_dict + ``decoder.*`` and ``post_quant_proj.*`` in upstream's state_dict layout."""
     sd = seeded_vq_state_dict(cfg, seed)
     D, depth, _ = DEC_DIMS[dec_type]
@@ -190,7 +212,9 @@ def seeded_vqvae_state_dict(cfg: VQCfg, dec_type: str, seed: int = 0) -> Dict[st
     if cfg.post_mlp:
         norm("decoder.norm_mlp")
         lin("decoder.post_mlp.fc1", Hd, D); lin("decoder.post_mlp.fc2", D, Hd)
-    lin("decoder.out_proj", cfg.channels * cfg.patch * cfg.patch, D)
+    lin("decoder.out_proj", (n_labels or cfg.channels) * cfg.patch * cfg.patch, D)
+    if n_labels:
+        sd["cls_emb.weight"] = seeded_tensor("cls_emb.weight", (n_labels, cfg.channels), 1.0, seed)
     sd["post_quant_proj.weight"] = seeded_tensor("post_quant_proj.weight", (D, cfg.latent, 1, 1), 1.0 / math.sqrt(cfg.latent), seed)
     sd["post_quant_proj.bias"] = seeded_tensor("post_quant_proj.bias", (D,), 0.02, seed)
     return sd
@@ -205,16 +229,19 @@ def vqvae_decode(P, cfg: VQCfg, dec_type: str, quant: Tensor, emulate_bf16: bool
     t = t + P["decoder.pos_emb"][0].permute(1, 2, 0).reshape(g * g, D)
     t = vit_stack(P, "decoder", t, D, depth, heads, cfg.eps, cfg.post_mlp, num, tail)
     rows = num.linear(t, P["decoder.out_proj.weight"], P["decoder.out_proj.bias"]).float()
-    p, C = cfg.patch, cfg.channels
+    p = cfg.patch
+    C = P["decoder.out_proj.weight"].shape[0] // (p * p)          # n_channels, or n_labels for class maps
     return rows.reshape(B, g, g, C, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B, C, g * p, g * p)
 
 
-def vqvae_forward(P, cfg: VQCfg, dec_type: str, x: Tensor, commitment_weight: float = 1.0, emulate_bf16: bool = False):
+def vqvae_forward(P, cfg: VQCfg, dec_type: str, x: Tensor, commitment_weight: float = 1.0, emulate_bf16: bool = False, norm_latents: bool = False):
     """Training-mode ``VQVAE.forward``: (dec, code_loss (1,), tokens).  Differentiable w.r.t. P: the quantised code passes its gradient
     straight to the latents (quantize = z + (q - z).detach()) and code_loss = w * mse(q.detach(), z)   [quantize_lucid.py:533-541]."""
     _, tokens, z = vq_encode(P, cfg, x, emulate_bf16)
     B, g = x.shape[0], x.shape[2] // cfg.patch
     q = P["quantize._codebook.embed"][tokens.reshape(B, -1)].detach()
+    if norm_latents:                      # the latents are normalised in front of the codebook and the commitment term (:525-527)
+        z = F.normalize(z, p=2, dim=-1)
     quant = z + (q - z).detach()
     code_loss = (F.mse_loss(q, z) * commitment_weight).reshape(1)
     dec = vqvae_decode(P, cfg, dec_type, quant.reshape(B, g, g, cfg.latent).permute(0, 3, 1, 2), emulate_bf16)

@@ -57,22 +57,24 @@ def run_vqvae(name, check):
     """Training step of upstream's VQVAE (train mode: straight-through + commitment loss; EMA update on, dead-code replacement off) against
     torch autograd through the oracle: reconstruction, code loss and every parameter gradient."""
     c = VQVAE_CASES[name]
-    cfg = V.vq_cfg(c["enc_type"], image=c["image"], patch=c["patch"], codebook=c["codebook"], post_mlp=c["post_mlp"])
-    sd = V.seeded_vqvae_state_dict(cfg, c["dec_type"], seed=c["seed"])
-    x = V.synthetic_images(cfg, c["batch"], seed=c["seed"])
+    nl, nlat = c.get("n_labels"), c.get("norm_latents", False)
+    cfg = V.vq_cfg(c["enc_type"], image=c["image"], patch=c["patch"], codebook=c["codebook"], post_mlp=c["post_mlp"], channels=c.get("channels", 3))
+    sd = V.seeded_vqvae_state_dict(cfg, c["dec_type"], seed=c["seed"], n_labels=nl)
+    x = V.synthetic_images(cfg, c["batch"], seed=c["seed"]) if nl is None else V.synthetic_labels(cfg, c["batch"], nl, seed=c["seed"])
     ref = RefVQVAE(dec_type=c["dec_type"], image_size=cfg.image, enc_type=c["enc_type"], patch_size=cfg.patch, post_mlp=cfg.post_mlp,
                    codebook_size=cfg.codebook, latent_dim=cfg.latent, norm_codes=True, sync_codebook=False, threshold_ema_dead_code=0,
-                   commitment_weight=c["commitment_weight"])
+                   commitment_weight=c["commitment_weight"], n_labels=nl, n_channels=cfg.channels, norm_latents=nlat)
+    rec_loss = (lambda d: torch.nn.functional.mse_loss(d, x)) if nl is None else (lambda d: torch.nn.functional.cross_entropy(d, x))
     msg = ref.load_state_dict(sd, strict=True)
     assert not msg.missing_keys and not msg.unexpected_keys
     ref.train()
     dec, code_loss = ref(x)
-    loss = torch.nn.functional.mse_loss(dec, x) + code_loss.sum()
+    loss = rec_loss(dec) + code_loss.sum()
     loss.backward()
     grads = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
     P = {k: v.clone().requires_grad_(k in grads) for k, v in sd.items()}
-    odec, ocl, otok = V.vqvae_forward(P, cfg, c["dec_type"], x, commitment_weight=c["commitment_weight"])
-    (torch.nn.functional.mse_loss(odec, x) + ocl.sum()).backward()
+    odec, ocl, otok = V.vqvae_forward(P, cfg, c["dec_type"], x, commitment_weight=c["commitment_weight"], norm_latents=nlat)
+    (rec_loss(odec) + ocl.sum()).backward()
     assert torch.allclose(odec, dec, atol=2e-5 * float(dec.abs().max())), float((odec - dec).abs().max())
     assert torch.allclose(ocl, code_loss, rtol=1e-5)
     worst = 0.0
