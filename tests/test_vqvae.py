@@ -128,12 +128,22 @@ def test_training_step_matches_upstream_fixture(name):
     log("vqvae_train_step", case=name, dec_rel=e_dec, code_loss_rel=e_cl, grad_norm_rel_worst=errs[worst], grad_norm_rel_median=med, worst=worst)
     assert e_dec < 2e-2 and e_cl < 1e-2, (e_dec, e_cl)
     assert errs[worst] < 8e-2 and med < 2e-2, (worst, errs[worst], med)
-    # gradient heads of the largest tensors on both sides of the quantizer (direction, not only norm)
-    for k in ("decoder.out_proj.weight", "post_quant_proj.weight", "quant_proj.weight", "encoder.proj.weight", "encoder.blocks.0.attn.qkv.weight") + \
-            (("cls_emb.weight",) if c.get("n_labels") else ()):
-        got = dict(m.named_parameters())[k].grad.reshape(-1)[:16].cpu()
-        ref = torch.from_numpy(g["grad_head/" + k])
-        assert _rel(got, ref) < 0.15, (k, _rel(got, ref))
+    if cfg.dim <= 512:
+        # small models: every gradient TENSOR against torch autograd through the oracle (fp32, pinned to upstream by the fixture test above)
+        gk = set(g["meta/grad_keys"].tolist())
+        P = {k: v.clone().requires_grad_(k in gk) for k, v in sd.items()}
+        odec, ocl, _ = V.vqvae_forward(P, cfg, c["dec_type"], x, commitment_weight=c["commitment_weight"], norm_latents=c.get("norm_latents", False))
+        (rec_loss(c, odec, x) + ocl.sum()).backward()
+        full = {k: _rel(p.grad.cpu(), P[k].grad) for k, p in m.named_parameters() if k in gk and float(P[k].grad.norm()) > 1e-10}
+        wk = max(full, key=full.get)
+        log("vqvae_train_step.full_tensors", case=name, grad_rel_worst=full[wk], worst=wk, grad_rel_median=float(np.median(list(full.values()))))
+        assert full[wk] < 6e-2 and float(np.median(list(full.values()))) < 2.5e-2, (wk, full[wk])
+    else:
+        # gradient heads of the largest tensors on both sides of the quantizer (direction, not only norm)
+        for k in ("decoder.out_proj.weight", "post_quant_proj.weight", "quant_proj.weight", "encoder.proj.weight", "encoder.blocks.0.attn.qkv.weight"):
+            got = dict(m.named_parameters())[k].grad.reshape(-1)[:16].cpu()
+            ref = torch.from_numpy(g["grad_head/" + k])
+            assert _rel(got, ref) < 0.15, (k, _rel(got, ref))
     # the EMA codebook update ran once, after the code assignment
     assert float(m.quantize._codebook.cluster_size.sum()) == pytest.approx((1 - m.quantize._codebook.decay) * x.shape[0] * cfg.grid ** 2, rel=1e-5)
 
