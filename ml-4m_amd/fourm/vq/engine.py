@@ -126,7 +126,7 @@ def _tokens(enc, x, st=None, prep=None):
         (B, Hh, Ww), C = x.shape, prep["cls_emb"].shape[1]
     else:
         B, C, Hh, Ww = x.shape
-    P = enc.P_H
+    P = enc.P_H if getattr(enc, "patch_proj", True) else 1          # (feature-map inputs: one token per position, vit_models.py:478-481)
     assert enc.P_H == enc.P_W and Hh % P == 0 and Ww % P == 0, f"Image sizes {Hh}x{Ww} must be divisible by patch size {P}"
     nh, nw = Hh // P, Ww // P
     G, R = nh * nw, B * nh * nw
@@ -218,8 +218,8 @@ def _quant_rows(vq, tokens, dev):
 def _decode_rows(vq, q_rows, B, nh, nw, st=None):
     """Quantised rows (R, latent_dim) f32 -> image (B, C, H, W) f32 through post_quant_proj, the decoder blocks and out_proj."""
     dec = vq.decoder
-    if not getattr(dec, "patch_proj", True) or hasattr(dec, "out_conv"):
-        raise NotImplementedError("ViTDecoder with patch_proj=False / out_conv=True has no HIP path")
+    if hasattr(dec, "out_conv"):
+        raise NotImplementedError("ViTDecoder with out_conv=True has no HIP path")
     eng = _engine(dec)
     ws, D, Ld = eng.ws, eng.D, vq.latent_dim
     G, R = nh * nw, B * nh * nw
@@ -235,7 +235,7 @@ def _decode_rows(vq, q_rows, B, nh, nw, st=None):
     stream = _blocks_fwd(eng, dec, stream, B, G, st, "dec" if st is not None else "vit")
     if hasattr(dec, "post_mlp"):
         stream = _post_mlp_fwd(eng, dec, stream, R, st, "decpost")
-    P, C = dec.P_H, dec.out_channels
+    P, C = (dec.P_H if dec.patch_proj else 1), dec.out_channels
     Fo = C * P * P
     xb = ws.get("dec.xb", (Rp, D), torch.bfloat16)                      # out_proj runs under autocast: bf16 operands, fp32 result
     ops.f32_to_bf16(stream, xb)
@@ -329,7 +329,7 @@ def vqvae_train_backward(vq, st, g_dec, g_loss):
     ws, D, Ld, f32, bf = de.ws, de.D, vq.latent_dim, torch.float32, torch.bfloat16
     Rp = ru(R, 128)
     sd = st["dec"]
-    P, C = dec.P_H, dec.out_channels
+    P, C = (dec.P_H if dec.patch_proj else 1), dec.out_channels
     Fo = C * P * P
     # ---- out_proj ------------------------------------------------------------------------------------------------------------------
     drow = ws.get("bwd.drow", (Rp, ru(Fo, 64)), bf)
@@ -382,7 +382,7 @@ def vqvae_train_backward(vq, st, g_dec, g_loss):
     extra = []
     if se["labels"] is not None and vq.cls_emb.weight.requires_grad:       # the class-embedding table behind the patch projection
         Bi, Ci, Hi, Wi = se["image"]
-        P_ = enc.P_H
+        P_ = enc.P_H if enc.patch_proj else 1
         dpatch = ews.get("bwd.dpatch", tuple(se["patches"].shape), bf)
         ops.gemm_nt(ge_bf, ee.wt(enc.proj.weight), dpatch, M=R, N=Ci * P_ * P_, K=De)
         ee.open_window([vq.cls_emb.weight])

@@ -61,8 +61,6 @@ class ViTEncoder(nn.Module):
                  learnable_pos_emb: bool = False, patch_proj: bool = True, post_mlp: bool = False, ckpt_path: Optional[str] = None,
                  **ignore_kwargs):
         super().__init__()
-        if not patch_proj:
-            raise NotImplementedError("patch_proj=False (feature-map inputs) has no HIP path yet")
         self.in_channels, self.dim_tokens, self.patch_proj = in_channels, dim_tokens, patch_proj
         self.P_H, self.P_W = pair(patch_size)
         self.H, self.W = pair(resolution)
@@ -73,7 +71,9 @@ class ViTEncoder(nn.Module):
         else:
             self.pos_emb = nn.Parameter(torch.zeros(1, dim_tokens, n_h, n_w))
             nn.init.trunc_normal_(self.pos_emb, std=0.02)
-        self.proj = nn.Conv2d(in_channels, dim_tokens, kernel_size=(self.P_H, self.P_W), stride=(self.P_H, self.P_W))
+        # patch_proj=False (feature-map tokenizers: CLIP / DINOv2 / ImageBind): the input is already one vector per token, 1 x 1 projection
+        k = (self.P_H, self.P_W) if patch_proj else (1, 1)
+        self.proj = nn.Conv2d(in_channels, dim_tokens, kernel_size=k, stride=k)
         self.blocks = nn.Sequential(*[Block(dim=dim_tokens, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, drop=drop_rate,
                                             attn_drop=attn_drop_rate, drop_path=drop_path_rate, norm_layer=norm_layer) for _ in range(depth)])
         if post_mlp:
@@ -130,8 +130,6 @@ class ViTDecoder(nn.Module):
                  drop_path_rate: float = 0.0, norm_layer: nn.Module = partial(nn.LayerNorm, eps=1e-6), sincos_pos_emb: bool = True,
                  learnable_pos_emb: bool = False, patch_proj: bool = True, post_mlp: bool = False, out_conv: bool = False, **ignore_kwargs):
         super().__init__()
-        if not patch_proj:
-            raise NotImplementedError("patch_proj=False (feature-map outputs) has no HIP path yet")
         if out_conv:
             raise NotImplementedError("out_conv=True (ConvNeXt blocks behind the decoder) has no HIP path")
         self.out_channels, self.dim_tokens, self.patch_proj = out_channels, dim_tokens, patch_proj
@@ -149,7 +147,7 @@ class ViTDecoder(nn.Module):
         if post_mlp:
             self.norm_mlp = norm_layer(dim_tokens)
             self.post_mlp = Mlp(dim_tokens, int(mlp_ratio * dim_tokens), act_layer=nn.Tanh)
-        self.out_proj = nn.Linear(dim_tokens, out_channels * self.P_H * self.P_W)
+        self.out_proj = nn.Linear(dim_tokens, out_channels * self.P_H * self.P_W if patch_proj else out_channels)
         _init_vit_weights(self)
 
     def get_num_layers(self) -> int:

@@ -34,6 +34,7 @@ class VQCfg:
     heads: int = 12
     mlp_ratio: float = 4.0
     post_mlp: bool = True
+    patch_proj: bool = True    # False: feature-map tokenizer, 1 x 1 projection of (B, C, grid, grid) inputs
     codebook: int = 16384
     latent: int = 32
     eps: float = 1e-6
@@ -60,8 +61,9 @@ def seeded_vq_state_dict(cfg: VQCfg, seed: int = 0) -> Dict[str, Tensor]:
         sd[pre + ".weight"] = 1.0 + seeded_tensor(pre + ".weight", (D,), 0.1, seed)
         sd[pre + ".bias"] = seeded_tensor(pre + ".bias", (D,), 0.05, seed)
     sd["encoder.pos_emb"] = sincos_2d(g, g, D).reshape(g, g, D).permute(2, 0, 1)[None].contiguous()
-    f = cfg.channels * cfg.patch * cfg.patch
-    sd["encoder.proj.weight"] = seeded_tensor("encoder.proj.weight", (D, cfg.channels, cfg.patch, cfg.patch), 1.0 / math.sqrt(f), seed)
+    pp = cfg.patch if cfg.patch_proj else 1
+    f = cfg.channels * pp * pp
+    sd["encoder.proj.weight"] = seeded_tensor("encoder.proj.weight", (D, cfg.channels, pp, pp), 1.0 / math.sqrt(f), seed)
     sd["encoder.proj.bias"] = seeded_tensor("encoder.proj.bias", (D,), 0.02, seed)
     for i in range(cfg.depth):
         p = f"encoder.blocks.{i}"
@@ -81,7 +83,8 @@ def seeded_vq_state_dict(cfg: VQCfg, seed: int = 0) -> Dict[str, Tensor]:
 
 def synthetic_images(cfg: VQCfg, batch: int, seed: int = 0) -> Tensor:
     g = torch.Generator().manual_seed(seed)
-    return torch.rand(batch, cfg.channels, cfg.image, cfg.image, generator=g) * 2 - 1
+    side = cfg.image if cfg.patch_proj else cfg.grid           # feature-map tokenizers take (B, C, grid, grid)
+    return torch.rand(batch, cfg.channels, side, side, generator=g) * 2 - 1
 
 
 def vit_stack(P, pre0, t, dim, depth, heads, eps, post_mlp, num, tail):
@@ -134,7 +137,8 @@ def vq_encode(P: Dict[str, Tensor], cfg: VQCfg, x: Tensor, emulate_bf16: bool = 
     num, tail = _Num(emulate_bf16), _Num(False)
     x = prepare_input(P, x, undo_std)
     B, C, H, W = x.shape
-    p, g = cfg.patch, H // cfg.patch
+    p = cfg.patch if cfg.patch_proj else 1
+    g = H // p
     # Conv2d(k = s = p): patches ordered (c, py, px) against weight.view(D, -1)
     patches = x.reshape(B, C, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, C * p * p)
     t = num.linear(patches, P["encoder.proj.weight"].reshape(cfg.dim, -1), P["encoder.proj.bias"])
@@ -212,7 +216,7 @@ def seeded_vqvae_state_dict(cfg: VQCfg, dec_type: str, seed: int = 0, n_labels: 
     if cfg.post_mlp:
         norm("decoder.norm_mlp")
         lin("decoder.post_mlp.fc1", Hd, D); lin("decoder.post_mlp.fc2", D, Hd)
-    lin("decoder.out_proj", (n_labels or cfg.channels) * cfg.patch * cfg.patch, D)
+    lin("decoder.out_proj", (n_labels or cfg.channels) * (cfg.patch * cfg.patch if cfg.patch_proj else 1), D)
     if n_labels:
         sd["cls_emb.weight"] = seeded_tensor("cls_emb.weight", (n_labels, cfg.channels), 1.0, seed)
     sd["post_quant_proj.weight"] = seeded_tensor("post_quant_proj.weight", (D, cfg.latent, 1, 1), 1.0 / math.sqrt(cfg.latent), seed)
@@ -229,7 +233,7 @@ def vqvae_decode(P, cfg: VQCfg, dec_type: str, quant: Tensor, emulate_bf16: bool
     t = t + P["decoder.pos_emb"][0].permute(1, 2, 0).reshape(g * g, D)
     t = vit_stack(P, "decoder", t, D, depth, heads, cfg.eps, cfg.post_mlp, num, tail)
     rows = num.linear(t, P["decoder.out_proj.weight"], P["decoder.out_proj.bias"]).float()
-    p = cfg.patch
+    p = cfg.patch if cfg.patch_proj else 1
     C = P["decoder.out_proj.weight"].shape[0] // (p * p)          # n_channels, or n_labels for class maps
     return rows.reshape(B, g, g, C, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B, C, g * p, g * p)
 
@@ -238,7 +242,7 @@ def vqvae_forward(P, cfg: VQCfg, dec_type: str, x: Tensor, commitment_weight: fl
     """Training-mode ``VQVAE.forward``: (dec, code_loss (1,), tokens).  Differentiable w.r.t. P: the quantised code passes its gradient
     straight to the latents (quantize = z + (q - z).detach()) and code_loss = w * mse(q.detach(), z)   [quantize_lucid.py:533-541]."""
     _, tokens, z = vq_encode(P, cfg, x, emulate_bf16)
-    B, g = x.shape[0], x.shape[2] // cfg.patch
+    B, g = x.shape[0], x.shape[2] // (cfg.patch if cfg.patch_proj else 1)
     q = P["quantize._codebook.embed"][tokens.reshape(B, -1)].detach()
     if norm_latents:                      # the latents are normalised in front of the codebook and the commitment term (:525-527)
         z = F.normalize(z, p=2, dim=-1)

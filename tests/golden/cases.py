@@ -92,5 +92,7 @@ VQVAE_CASES = {
     "vqvae_small": dict(enc_type="vit_s_enc", dec_type="vit_s_dec", image=64, patch=16, codebook=512, post_mlp=True, batch=3, seed=2, commitment_weight=1.0),
     "vqvae_semseg": dict(enc_type="vit_s_enc", dec_type="vit_s_dec", image=64, patch=16, codebook=256, post_mlp=False, batch=3, seed=7, commitment_weight=0.5,
                          n_labels=12, channels=4, norm_latents=True),
+    "vqvae_feat": dict(enc_type="vit_s_enc", dec_type="vit_s_dec", image=96, patch=16, codebook=256, post_mlp=True, batch=3, seed=9, commitment_weight=1.0,
+                       channels=40, patch_proj=False),
     "vqvae_b224": dict(enc_type="vit_b_enc", dec_type="vit_b_dec", image=224, patch=16, codebook=16384, post_mlp=False, batch=2, seed=5, commitment_weight=0.25),
 }

@@ -58,12 +58,13 @@ def run_vqvae(name, check):
     torch autograd through the oracle: reconstruction, code loss and every parameter gradient."""
     c = VQVAE_CASES[name]
     nl, nlat = c.get("n_labels"), c.get("norm_latents", False)
-    cfg = V.vq_cfg(c["enc_type"], image=c["image"], patch=c["patch"], codebook=c["codebook"], post_mlp=c["post_mlp"], channels=c.get("channels", 3))
+    cfg = V.vq_cfg(c["enc_type"], image=c["image"], patch=c["patch"], codebook=c["codebook"], post_mlp=c["post_mlp"], channels=c.get("channels", 3),
+                   patch_proj=c.get("patch_proj", True))
     sd = V.seeded_vqvae_state_dict(cfg, c["dec_type"], seed=c["seed"], n_labels=nl)
     x = V.synthetic_images(cfg, c["batch"], seed=c["seed"]) if nl is None else V.synthetic_labels(cfg, c["batch"], nl, seed=c["seed"])
     ref = RefVQVAE(dec_type=c["dec_type"], image_size=cfg.image, enc_type=c["enc_type"], patch_size=cfg.patch, post_mlp=cfg.post_mlp,
                    codebook_size=cfg.codebook, latent_dim=cfg.latent, norm_codes=True, sync_codebook=False, threshold_ema_dead_code=0,
-                   commitment_weight=c["commitment_weight"], n_labels=nl, n_channels=cfg.channels, norm_latents=nlat)
+                   commitment_weight=c["commitment_weight"], n_labels=nl, n_channels=cfg.channels, norm_latents=nlat, patch_proj=cfg.patch_proj)
     rec_loss = (lambda d: torch.nn.functional.mse_loss(d, x)) if nl is None else (lambda d: torch.nn.functional.cross_entropy(d, x))
     msg = ref.load_state_dict(sd, strict=True)
     assert not msg.missing_keys and not msg.unexpected_keys

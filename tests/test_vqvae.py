@@ -17,7 +17,8 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 def case(name):
     c = VQVAE_CASES[name]
     nl = c.get("n_labels")
-    cfg = V.vq_cfg(c["enc_type"], image=c["image"], patch=c["patch"], codebook=c["codebook"], post_mlp=c["post_mlp"], channels=c.get("channels", 3))
+    cfg = V.vq_cfg(c["enc_type"], image=c["image"], patch=c["patch"], codebook=c["codebook"], post_mlp=c["post_mlp"], channels=c.get("channels", 3),
+                   patch_proj=c.get("patch_proj", True))
     sd = V.seeded_vqvae_state_dict(cfg, c["dec_type"], seed=c["seed"], n_labels=nl)
     x = V.synthetic_images(cfg, c["batch"], seed=c["seed"]) if nl is None else V.synthetic_labels(cfg, c["batch"], nl, seed=c["seed"])
     return c, cfg, sd, x, np.load(os.path.join(GOLD, f"{name}.npz"))
@@ -27,7 +28,7 @@ def build(c, cfg, **kw):
     from fourm.vq import VQVAE
     return VQVAE(dec_type=c["dec_type"], image_size=cfg.image, enc_type=c["enc_type"], patch_size=cfg.patch, post_mlp=cfg.post_mlp,
                  codebook_size=cfg.codebook, latent_dim=cfg.latent, norm_codes=True, sync_codebook=False, threshold_ema_dead_code=0,
-                 commitment_weight=c["commitment_weight"], n_labels=c.get("n_labels"), n_channels=cfg.channels, norm_latents=c.get("norm_latents", False), **kw)
+                 commitment_weight=c["commitment_weight"], n_labels=c.get("n_labels"), n_channels=cfg.channels, norm_latents=c.get("norm_latents", False), patch_proj=cfg.patch_proj, **kw)
 
 
 def rec_loss(c, dec, x):
@@ -35,7 +36,7 @@ def rec_loss(c, dec, x):
     return F.mse_loss(dec, x) if c.get("n_labels") is None else F.cross_entropy(dec, x)
 
 
-@pytest.mark.parametrize("name", ["vqvae_small", "vqvae_semseg"])
+@pytest.mark.parametrize("name", ["vqvae_small", "vqvae_semseg", "vqvae_feat"])
 def test_oracle_training_step_matches_upstream_fixture(name):
     c, cfg, sd, x, g = case(name)
     assert sum(float(v.double().abs().sum()) for v in sd.values()) == pytest.approx(float(g["meta/weight_checksum"]), rel=1e-9)
