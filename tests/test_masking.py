@@ -350,3 +350,54 @@ def test_device_unified_masking_contract():
     out2 = um(md, generator=torch.Generator(device=dev).manual_seed(0))
     out3 = um(md, generator=torch.Generator(device=dev).manual_seed(0))       # same seed, same draws: the whole pipeline is a function of the generator
     assert all(torch.equal(out2[k][f], out3[k][f]) for k in out2 for f in ("input_mask", "target_mask", "decoder_attention_mask"))
+
+
+@pytest.mark.gpu
+def test_device_masking_feeds_the_model():
+    """The loader contract end to end: DeviceUnifiedMasking's batched output is what FourM.forward consumes - loss and
+    per-modality losses follow the CPU oracle run on the very same mod_dict."""
+    import random
+    from fourm.data.masking import DeviceUnifiedMasking
+    from oracle import fourm_oracle as FO
+    from tests.golden.cases import build_case
+    from tests.util_model import build_hip_model, tie
+    case = build_case("micro_swiglu")
+    cfg = case["cfg"]
+    model = build_hip_model(cfg, case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    model.load_state_dict(case["sd"], strict=True)
+    model = model.cuda().train()
+    typ = {"tok": "img", "patch": "img", "seq": "seq", "seq_emb": "seq_emb"}
+    info = {m.name: dict(type=typ[m.kind], max_tokens=m.n_pos, min_tokens=0, input_alphas=[1.0, 0.3], target_alphas=[1.0 if m.in_dec else 0.0, 0.5 if m.in_dec else 0.0],
+                         keep=["random", "all"]) for m in cfg.mods}
+    B, dev = 6, "cuda"
+    um = DeviceUnifiedMasking(info, None, input_tokens_range=20, target_tokens_range=18, max_tries=50, device=dev,
+                              sentinel_to_id={k: 4 + k for k in range(20)}, pad_id=0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    raw = {}
+    for m in cfg.mods:
+        if m.kind == "tok":
+            s = int(round(m.n_pos ** 0.5))
+            raw[m.name] = torch.randint(0, m.vocab, (B, s, s), device=dev, generator=g)
+        elif m.kind == "patch":
+            s = int(round(m.n_pos ** 0.5)) * m.patch
+            raw[m.name] = torch.randn(B, m.channels, s, s, device=dev, generator=g)
+        elif m.kind == "seq":
+            raw[m.name] = {"ids": torch.randint(30, m.vocab, (B, m.n_pos), device=dev, generator=g, dtype=torch.int32),
+                           "len": torch.randint(2, m.n_pos + 1, (B,), device=dev, generator=g, dtype=torch.int32)}
+        else:
+            raw[m.name] = torch.randn(B, m.n_pos, m.orig_dim, device=dev, generator=g)
+    md = um(raw, generator=g)
+    for m in cfg.mods:
+        assert md[m.name]["input_mask"].shape == (B, m.tensor_len) and md[m.name]["decoder_attention_mask"].dtype == torch.int32, m.name
+    random.seed(5)
+    loss, mod_loss = model({k: {a: b for a, b in v.items() if a != "tries"} for k, v in md.items()}, 20, 18)
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    cpu_md = {k: {a: b.cpu() for a, b in v.items() if a != "tries"} for k, v in md.items()}
+    P = tie({k: v.clone() for k, v in case["sd"].items()}, cfg, case["share_embedding"])
+    random.seed(5)
+    names = [n for n in cpu_md if n in model.decoder_embeddings]
+    order = random.sample(names, len(names))                                  # (cat_decoder_tensors shuffles the same way, fm.py:306)
+    with torch.no_grad():
+        o_loss, o_mod = FO.fourm_forward(P, cfg, cpu_md, 20, 18, order, emulate_bf16=True)
+    assert abs(float(loss.detach()) - float(o_loss.sum())) < 5e-3 * abs(float(o_loss.sum())), (float(loss.detach()), float(o_loss.sum()))
