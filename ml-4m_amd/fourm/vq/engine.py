@@ -324,7 +324,6 @@ def vqvae_train_backward(vq, st, g_dec, g_loss):
     B, nh, nw = st["dims"]
     G, R = nh * nw, B * nh * nw
     de = _engine(dec)
-    params = [p for p in vq.parameters()]
     de.open_window(list(dec.parameters()) + list(vq.post_quant_proj.parameters()))
     ws, D, Ld, f32, bf = de.ws, de.D, vq.latent_dim, torch.float32, torch.bfloat16
     Rp = ru(R, 128)

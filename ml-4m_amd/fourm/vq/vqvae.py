@@ -179,7 +179,7 @@ class VQVAE(VQ):
         return dec, code_loss
 
     def _eval_forward(self, x):
-        quant, code_loss, tokens = self.encode(x)
+        _, code_loss, tokens = self.encode(x)
         return self.decode_tokens(tokens), code_loss
 
     def autoencode(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
