@@ -58,6 +58,10 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
     const int fswz = (frow >> 1) & (CPR - 1);
 
     const int total = a.n_tiles_w * a.n_tiles_x;
+    if (a.dephase_groups > 1) {      // experiment (fm_lab_set 0 / 1): groups of CUs start out of phase, so that store epilogues do not coincide
+        const int ph = ((int)blockIdx.x / 8) % a.dephase_groups;
+        for (int i = 0; i < ph * a.dephase_step; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     const int n_my = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int KT = a.K / KB;
     const int G = n_my * KT;

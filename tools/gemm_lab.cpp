@@ -114,17 +114,20 @@ int main(int argc, char** argv) {
         std::vector<int> cfgs = {266, 267, 268};
         if (argc > 2) { cfgs.clear(); char* t = strtok(argv[2], ","); while (t) { cfgs.push_back(atoi(t)); t = strtok(nullptr, ","); } }
         NTCase cases[] = {{"qkv      N2304 K768 ", 2304, 768, FM_EPI_BF16}, {"proj/dX  N768  K768 ", 768, 768, FM_EPI_BF16}, {"dX fc2   N2048 K768 ", 2048, 768, FM_EPI_BF16},
-                          {"dX qkv   N768  K2304", 768, 2304, FM_EPI_BF16}, {"fc2+res  N768  K2048", 768, 2048, FM_EPI_RESIDUAL}, {"proj+res N768  K768 ", 768, 768, FM_EPI_RESIDUAL}};
+                          {"dX qkv   N768  K2304", 768, 2304, FM_EPI_BF16}, {"fc2+res  N768  K2048", 768, 2048, FM_EPI_RESIDUAL}, {"proj+res N768  K768 ", 768, 768, FM_EPI_RESIDUAL},
+                          {"swiglu   N2x2048 K768", 2048, 768, FM_EPI_SWIGLU}};
         const int knobs[][2] = {{0, 0}, {2, 6}, {2, 12}, {2, 24}, {4, 4}, {4, 8}, {8, 2}, {8, 4}};
         for (auto& c : cases) {
-            void* W = dev_rand_bf16((size_t)c.N * c.K, 1), *X = dev_rand_bf16((size_t)R * c.K, 3);
-            const bool f32out = c.epi == FM_EPI_RESIDUAL;
+            void* W = dev_rand_bf16((size_t)c.N * c.K, 1), *W2 = dev_rand_bf16((size_t)c.N * c.K, 2), *X = dev_rand_bf16((size_t)R * c.K, 3);
+            const bool f32out = c.epi == FM_EPI_RESIDUAL, swi = c.epi == FM_EPI_SWIGLU;
             void* out = dev_zero((size_t)R * c.N * (f32out ? 4 : 2));
+            void* out2 = swi ? dev_zero((size_t)R * c.N * 2 * 2) : nullptr;
             void* res = f32out ? dev_zero((size_t)R * c.N * 4) : nullptr;
             fm_gemm_nt_args a{};
-            a.W = W; a.X = X; a.out = out; a.res = res; a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.ldr = c.N; a.epilogue = c.epi;
+            a.W = W; a.W2 = swi ? W2 : nullptr; a.X = X; a.out = out; a.out2 = out2; a.res = res; a.M = R; a.N = c.N; a.K = c.K; a.ldw = c.K; a.ldx = c.K; a.ldo = c.N; a.ldo2 = 2 * c.N;
+            a.ldr = c.N; a.Hp = c.N; a.epilogue = c.epi;
             for (int cfg : cfgs) {
-                fm_set_gemm_nt_config(cfg);
+                set_cfg(cfg);
                 printf("%s c%d |", c.name, cfg);
                 double best[8]; for (auto& b : best) b = 1e30;
                 for (int rep = 0; rep < 3; ++rep)
@@ -136,7 +139,7 @@ int main(int argc, char** argv) {
                 printf("  us\n"); fflush(stdout);
             }
             fm_lab_set(0, 0); fm_lab_set(1, 0);
-            CK(hipFree(W)); CK(hipFree(X)); CK(hipFree(out)); if (res) CK(hipFree(res));
+            CK(hipFree(W)); CK(hipFree(W2)); CK(hipFree(X)); CK(hipFree(out)); if (out2) CK(hipFree(out2)); if (res) CK(hipFree(res));
         }
     } else if (mode == "pmc") {
         // counter runs (rocprofv3 --pmc, GEMM_LAB_NOWARM=1): exactly 5 launches per (case, configuration), case-major, so that the
