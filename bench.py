@@ -451,6 +451,9 @@ def main():
     ap.add_argument("--model", default=None)
     ap.add_argument("--n-in", type=int, default=None)
     ap.add_argument("--n-out", type=int, default=None)
+    ap.add_argument("--masking", default="uniform", choices=["uniform", "dirichlet"], help="uniform = SURVEY §8d's synthetic budgets (the headline); "
+                    "dirichlet = the batches come from the device-side masking pipeline (Dirichlet token budgets, image masks, span masking: "
+                    "fourm.data.masking.DeviceUnifiedMasking), and the record carries the producer's time per batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test hook: several ranks on one GPU)")
@@ -461,7 +464,7 @@ def main():
     a = ap.parse_args()
     a.user_batch = a.batch
     # the sub-records of BASELINE configs[3] / [4] ride on the DEFAULT invocation only (N = 1, mod7, no size overrides)
-    a.extras = not a.no_extras and a.workload == "train" and a.mods == "mod7" and a.batch is None and a.model is None and not a.pmc_worker \
+    a.extras = not a.no_extras and a.workload == "train" and a.mods == "mod7" and a.batch is None and a.model is None and not a.pmc_worker and a.masking == "uniform" \
         and not a.cpu_baseline_worker and a.gpus == 1 and a.dist_backend == "nccl" and not a.no_cpu_baseline
     dflt = {"mod7": ("fm_base_12e_12d_swiglu_nobias", 256, 128), "mod21": ("fm_large_24e_24d_swiglu_nobias", 64, 256)}[a.mods]
     a.model = a.model or dflt[0]
@@ -511,7 +514,20 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         groups = get_parameter_groups(model, weight_decay=0.05, skip_list=model.no_weight_decay())
     opt = FusedAdamW(groups, lr=1e-4 * a.batch * world / 256, betas=(0.9, 0.95), eps=1e-8)
-    batches = [synthetic_batch(model, a.batch, a.n_in, a.n_out, device=dev, seed=1000 * rank + i) for i in range(2)]
+    masking_ms = None
+    if a.masking == "dirichlet":      # SURVEY §8d "realistic variant": the loader's UnifiedMasking, run on the device over the whole batch
+        from fourm.data.synthetic import device_masked_batch, device_masking_for
+        um = device_masking_for(model, a.n_in, a.n_out, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(1000 * rank)
+        batches = [device_masked_batch(model, um, a.batch, device=dev, generator=gen) for _ in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            device_masked_batch(model, um, a.batch, device=dev, generator=gen)
+        torch.cuda.synchronize()
+        masking_ms = (time.perf_counter() - t0) / 5 * 1e3
+    else:
+        batches = [synthetic_batch(model, a.batch, a.n_in, a.n_out, device=dev, seed=1000 * rank + i) for i in range(2)]
     import random
     random.seed(rank)
 
@@ -565,6 +581,9 @@ def main():
         "mfu": flops_step * a.steps / dt / (BF16_PEAK_TFLOPS * 1e12),
         "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12, "final_loss": last_loss,
     }
+    if masking_ms is not None:
+        out["data"] = "synthetic modalities masked on the device (Dirichlet token budgets, image masks, span masking)"
+        out["masking_ms_per_batch"] = masking_ms          # the producer, outside the timed region (batches are resident when it starts)
 
     # ---- dominant kernel vs its roofline, measured live with events on the launch stream (rank 0) ----------
     if not a.no_kernel_profile:

@@ -82,14 +82,64 @@ def synthetic_batch(model, batch: int, n_in: int, n_out: int, device="cuda", see
     return out
 
 
+def device_masking_for(model, num_input_tokens, num_target_tokens, device="cuda", alpha: float = 1.0, max_tries: int = 32):
+    """A ``DeviceUnifiedMasking`` over the model's modalities (what upstream builds from the data YAML, run_training_4m.py:296-310): one
+    Dirichlet component with concentration ``alpha`` on every modality the encoder / decoder embeds, span-masking sentinels 4 .. 203 as
+    in the 4M text tokenizer."""
+    from .masking import DeviceUnifiedMasking
+    shp = modality_shapes(model)
+    info = {}
+    for n, s in shp.items():
+        typ = {0: "img", 1: "img", 2: "seq", 3: "seq_emb"}[s["kind"]]
+        info[n] = dict(type=typ, max_tokens=s.get("room", s["L"]) if typ != "img" else s["L"], min_tokens=0,
+                       input_alphas=[alpha if n in model.encoder_embeddings else 0.0], target_alphas=[alpha if n in model.decoder_embeddings else 0.0])
+    return DeviceUnifiedMasking(info, None, input_tokens_range=num_input_tokens, target_tokens_range=num_target_tokens, max_tries=max_tries, device=device,
+                                sentinel_to_id={k: 4 + k for k in range(200)}, pad_id=0)
+
+
+@torch.no_grad()
+def device_masked_batch(model, masking, batch: int, device="cuda", generator=None) -> Dict[str, Dict[str, torch.Tensor]]:
+    """Raw synthetic modalities (token grids, pixels, tokenised sequences with their lengths, sequence embeddings) pushed through the
+    device-side masking pipeline (fourm.data.masking.DeviceUnifiedMasking): the mod_dict the loader would deliver, produced on the GPU."""
+    shp = modality_shapes(model)
+    raw = {}
+    for n, s in shp.items():
+        kind = s["kind"]
+        if kind == 0:
+            raw[n] = torch.randint(0, s["vocab"], (batch, s["side"], s["side"]), device=device, generator=generator)
+        elif kind == 1:
+            raw[n] = torch.randn(batch, s["channels"], s["image"][0], s["image"][1], device=device, generator=generator)
+        elif kind == 2:
+            room = s["room"]
+            raw[n] = {"ids": torch.randint(204, s["vocab"], (batch, room), device=device, generator=generator, dtype=torch.int32),
+                      "len": torch.randint(max(1, room // 8), room + 1, (batch,), device=device, generator=generator, dtype=torch.int32)}
+        else:
+            raw[n] = torch.randn(batch, s["L"], s["dim"], device=device, generator=generator)
+    out = masking(raw, generator=generator, batch_size=batch)
+    return {n: {k: v for k, v in d.items() if k != "tries"} for n, d in out.items()}
+
+
 class SyntheticLoader:
     """An iterable with the training loader's output contract (one ``mod_dict`` per step, ``len()`` = steps per epoch): ``distinct``
     pre-generated synthetic batches handed out in turn.  Stands in for ``build_mixture_dataloader`` when the trainer runs without a
     dataset (``data_config`` of type 'synthetic', benchmarks, smoke tests)."""
 
     def __init__(self, model, batch_size: int, num_input_tokens: int, num_target_tokens: int, steps: int, device="cpu", seed: int = 0,
-                 distinct: int = 4):
+                 distinct: int = 4, masking: str = "uniform"):
+        """``masking='uniform'``: pre-generated batches with uniform multinomial budgets (synthetic_batch).  ``'dirichlet'``: every step's
+        batch is produced on the device by the masking kernels (Dirichlet budgets, image masks, span masking) from fresh draws."""
         self.steps = int(steps)
+        self.live = None
+        if masking == "dirichlet":
+            if torch.device(device).type != "cuda":
+                raise ValueError("device-side masking needs the GPU")
+            gen = torch.Generator(device=device).manual_seed(seed)
+            um = device_masking_for(model, num_input_tokens, num_target_tokens, device=device)
+            self.live = lambda: device_masked_batch(model, um, batch_size, device=device, generator=gen)
+            self.batches = []
+            return
+        if masking != "uniform":
+            raise ValueError(f"masking {masking!r}: 'uniform' or 'dirichlet'")
         self.batches = [synthetic_batch(model, batch_size, num_input_tokens, num_target_tokens, device=device, seed=seed + i)
                         for i in range(max(1, min(distinct, self.steps)))]
 
@@ -98,5 +148,5 @@ class SyntheticLoader:
 
     def __iter__(self):
         for i in range(self.steps):
-            b = self.batches[i % len(self.batches)]
+            b = self.live() if self.live is not None else self.batches[i % len(self.batches)]
             yield {m: dict(d) for m, d in b.items()}           # the forward adds keys to the inner dicts

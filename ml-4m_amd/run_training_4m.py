@@ -161,9 +161,10 @@ def _domains(cfgs, key):
 
 
 def load_data_config(args):
-    if args.data_config == "synthetic":
+    if args.data_config in ("synthetic", "synthetic:dirichlet"):       # ':dirichlet' = batches masked on the device (DeviceUnifiedMasking)
         mods = "rgb@224-tok_rgb@224-tok_depth@224-tok_semseg@224-tok_normal@224-tok_clip@224-caption-det"
-        return {"train": {"datasets": {"synthetic": {"type": "synthetic", "in_domains": mods, "out_domains": mods.partition("-")[2]}}}}
+        return {"train": {"datasets": {"synthetic": {"type": "synthetic", "in_domains": mods, "out_domains": mods.partition("-")[2],
+                                                     "masking": "dirichlet" if args.data_config.endswith(":dirichlet") else "uniform"}}}}
     print(f"Loading data config from: {args.data_config}")
     with open(args.data_config) as f:
         return yaml.safe_load(f)
@@ -184,6 +185,7 @@ def setup_data(args):
     info = setup_modality_info(args)
     steps = (args.epoch_size or 0) // (args.batch_size * args.num_tasks)
     args.synthetic_data = all(c.get("type") == "synthetic" for c in train_cfg.values())
+    args.synthetic_masking = next((c.get("masking", "uniform") for c in train_cfg.values() if c.get("type") == "synthetic"), "uniform")
     if args.synthetic_data:
         return info, None, steps, None, None
 
@@ -224,10 +226,13 @@ def setup_data(args):
 
 
 def attach_synthetic_loaders(args, model, steps, device):
-    """Loaders for ``type: synthetic`` data configs: batches generated on the device once, shaped by the model's embeddings."""
+    """Loaders for ``type: synthetic`` data configs, shaped by the model's embeddings: batches generated on the device once
+    (``masking: uniform``, the default), or raw modalities masked on the device every step (``masking: dirichlet``: token budgets, image
+    masks and span masking by fourm.data.masking.DeviceUnifiedMasking - the loader's UnifiedMasking moved onto the GPU)."""
     from fourm.data import SyntheticLoader
     seed = args.seed + 1000 * utils.get_rank()
-    train = SyntheticLoader(model, args.batch_size, args.num_input_tokens, args.num_target_tokens, steps, device=device, seed=seed)
+    train = SyntheticLoader(model, args.batch_size, args.num_input_tokens, args.num_target_tokens, steps, device=device, seed=seed,
+                            masking=getattr(args, "synthetic_masking", "uniform"))
     val = {"synthetic": SyntheticLoader(model, args.batch_size, args.num_input_tokens, args.num_target_tokens, max(1, min(2, steps)),
                                         device=device, seed=seed + 500)}
     return train, val

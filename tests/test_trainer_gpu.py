@@ -94,3 +94,29 @@ def test_train_one_epoch_and_checkpoint_round_trip(tmp_path):
     num = sum(float((v.float() - w.float()).pow(2).sum()) for v, w in zip(model.module.state_dict().values(), model2.module.state_dict().values()))
     den = sum(float(v.float().pow(2).sum()) for v in model.module.state_dict().values())
     assert (num / den) ** 0.5 < 1e-4, (num / den) ** 0.5
+
+
+def test_main_with_device_side_masking(tmp_path):
+    """``data_config: synthetic:dirichlet``: every step's mod_dict is produced on the GPU by the masking kernels (Dirichlet token budgets,
+    image masks, span masking) and consumed by the train step - the loader's UnifiedMasking + the model, both on the device."""
+    T, a = _args(tmp_path, "--data_config", "synthetic:dirichlet", "--epoch_size", "8", "--epochs", "1")
+    T.main(copy.deepcopy(a))
+    rows = [json.loads(l) for l in open(os.path.join(a.output_dir, "log.txt"))]
+    assert len(rows) == 1 and 0 < rows[0]["[Epoch] loss"] < 12 and rows[0]["[Epoch] grad_norm"] > 0
+    # the producer on its own: fresh draws every call, token budgets respected, the loader contract's shapes
+    from fourm.data.synthetic import device_masked_batch, device_masking_for
+    from tests.golden.cases import build_case
+    from tests.util_model import build_hip_model
+    case = build_case("ti_mod7")
+    tiny = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"]).cuda()
+    um = device_masking_for(tiny, 128, 128, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    b1, b2 = device_masked_batch(tiny, um, 4, generator=g), device_masked_batch(tiny, um, 4, generator=g)
+    n_in = sum((~d["input_mask"]).flatten(1).sum(1) for d in b1.values())
+    n_tg = sum((~d["target_mask"]).flatten(1).sum(1) for d in b1.values())
+    assert int(n_in.max()) <= 128 and int(n_tg.max()) <= 128 and int(n_in.min()) > 0 and int(n_tg.min()) > 0
+    assert any(not torch.equal(b1[k]["input_mask"], b2[k]["input_mask"]) for k in b1)
+    for m in case["cfg"].mods:
+        assert b1[m.name]["input_mask"].shape == (4, m.tensor_len), m.name
+    loss, _ = tiny.train()(b1, 128, 128)
+    assert torch.isfinite(loss)
