@@ -9,8 +9,8 @@ ROOT=$(pwd)
 export LD_LIBRARY_PATH=$ROOT/ml-4m_amd/fourm/_lib:$LD_LIBRARY_PATH
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 1500 python -m pytest tests -v -m gpu -x --tb=short > gpurun_out/final_pytest_full.txt 2>&1     # (-v into a file: a cut-off run still shows how far it got)
-  grep -v Warning gpurun_out/final_pytest_full.txt | tail -12 | cut -c1-300 > gpurun_out/final_pytest.txt
+  timeout 1500 python -m pytest tests -v -m gpu -x --tb=short --durations=15 > gpurun_out/final_pytest_full.txt 2>&1     # (-v into a file: a cut-off run still shows how far it got)
+  grep -v Warning gpurun_out/final_pytest_full.txt | tail -30 | cut -c1-300 > gpurun_out/final_pytest.txt
   tail -3 gpurun_out/final_pytest.txt
 fi
 BENCH_SHAPE_TABLE=gpurun_out/final_shape_table.txt timeout 900 python bench.py 2> gpurun_out/final_bench.err | tail -1 > gpurun_out/final_bench.json
