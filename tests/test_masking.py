@@ -401,3 +401,28 @@ def test_device_masking_feeds_the_model():
     with torch.no_grad():
         o_loss, o_mod = FO.fourm_forward(P, cfg, cpu_md, 20, 18, order, emulate_bf16=True)
     assert abs(float(loss.detach()) - float(o_loss.sum())) < 5e-3 * abs(float(o_loss.sum())), (float(loss.detach()), float(o_loss.sum()))
+
+
+def test_device_masking_for_a_named_model():
+    """Host logic (no GPU): the DeviceUnifiedMasking built for a model mirrors the registry - modality types, max_tokens, one Dirichlet
+    component over the encoder / decoder sides, the tokenizer's sentinel ids - and the output row lengths are the loader contract's."""
+    from fourm.data.modality_info import MODALITY_INFO
+    from fourm.data.synthetic import device_masking_for, modality_shapes
+    from tests.golden.cases import build_case
+    from tests.util_model import build_hip_model
+    case = build_case("ti_mod7")
+    model = build_hip_model(case["cfg"], case["share_embedding"], case["norm_bias"], case["learned_pos"])
+    um = device_masking_for(model, 128, 128, device="cpu")
+    shp = modality_shapes(model)
+    assert list(um.modality_info) == list(shp)
+    for n, info in um.modality_info.items():
+        ref = MODALITY_INFO[n]
+        assert info["type"] == ref["type"] and info["max_tokens"] == (ref["max_tokens"] or 196), n        # (registry: None = (224 / 16)^2 grid tokens)
+        assert (info["input_alphas"][0] > 0) == (n in model.encoder_embeddings) and (info["target_alphas"][0] > 0) == (n in model.decoder_embeddings)
+        L_out = {"img": info["max_tokens"], "seq": 2 * (info["max_tokens"] + 1), "seq_emb": info["max_tokens"]}[info["type"]]
+        assert L_out == shp[n]["L"], n
+    assert um.sentinel_ids.tolist() == list(range(4, 204)) and um.pad_id == 0 and um.num_dirichlets == 1
+    assert float(um.target_alphas[0][list(shp).index("rgb@224")]) < 1e-6          # rgb pixels are never a target (clamped alpha, masking.py:160)
+    with pytest.raises(ValueError):
+        from fourm.data import SyntheticLoader
+        SyntheticLoader(model, 2, 128, 128, 1, device="cpu", masking="dirichlet")       # the producer needs the GPU: no CPU fallback
