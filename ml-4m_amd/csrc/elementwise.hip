@@ -179,13 +179,37 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const fm_shadow_des
     }
 }
 
-// db[n] += sum_r dY[r][n]
+// db[n] += sum_r dY[r][n].  A block covers 256 columns x rows_per_block rows as 32 column groups (8 columns = one 16-byte load) x 8 row
+// lanes: a wave reads two 512-byte row pieces per load; the 8 row lanes are summed through LDS, one atomic per column and block.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dy, int ldy, float* __restrict__ db, int R, int N, int rows_per_block) {
+    __shared__ float red[8][256 + 8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int n0 = blockIdx.x * 256 + cg * 8;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
-    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
-        float s = 0.f;
-        for (int r = r0; r < r1; ++r) s += bf2f(dy[(size_t)r * ldy + n]);
-        unsafeAtomicAdd(db + n, s);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n0 < N) {
+        const bool wide = n0 + 8 <= N && (ldy & 7) == 0 && (((uintptr_t)dy) & 15) == 0;
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const bf16_t* row = dy + (size_t)r * ldy + n0;
+            if (wide) {
+                const uint4 v = *(const uint4*)row;
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[2 * e] += bf2f((bf16_t)(w[e] & 0xffff)); s[2 * e + 1] += bf2f((bf16_t)(w[e] >> 16)); }
+            } else {
+                for (int e = 0; e < 8; ++e) if (n0 + e < N) s[e] += bf2f(row[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = s[e];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        unsafeAtomicAdd(db + n, t);
     }
 }
 
@@ -406,7 +430,7 @@ extern "C" int fm_shadow_refresh(const fm_shadow_desc* descs, int n_descs, int t
 
 extern "C" int fm_colsum(const void* dy, int ldy, void* db, int R, int N, void* stream) {
     FM_CHECK_ARG(dy && db && R > 0 && N > 0, "fm_colsum: bad argument");
-    const int rpb = 256;
+    const int rpb = 128;
     dim3 grid((N + 255) / 256, (R + rpb - 1) / rpb);
     hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, ldy, (float*)db, R, N, rpb);
     FM_CHECK_LAUNCH("fm_colsum");

@@ -263,21 +263,28 @@ def vqvae_decode_tokens(vq, tokens):
 
 
 def _post_mlp_bwd(eng, vit, sp, g, g_bf, R):
-    """Backward of x + fc2(tanh(fc1(norm_mlp(x)))) in fp32.  g (Rp, D) f32: in = d(out), out = d(x); g_bf receives the bf16 copy."""
+    """Backward of x + fc2(tanh(fc1(norm_mlp(x)))) in fp32.  g (Rp, D) f32: in = d(out), out = d(x); g_bf receives the bf16 copy.
+    Every GEMM runs on the fp32 matrix cores (fm_gemm_f32's MFMA kernel wants both operands contiguous along the reduction): dX against
+    transposed fp32 copies of the two weights, dW = dY^T X as an NT product of the transposed row blocks (layout copies, a few MB)."""
     ws, f32, D = eng.ws, torch.float32, eng.D
     fc1, fc2 = vit.post_mlp.fc1, vit.post_mlp.fc2
     hid = fc1.weight.shape[0]
+    gT = g[:R].t().contiguous()                                          # (D, R)
     if fc2.weight.requires_grad:
-        ops.gemm_tn(g, sp["t"], eng.grad_view(fc2.weight), N=D, K=hid, R=R)
+        tT = sp["t"][:R].t().contiguous()                                # (hid, R)
+        ops._gemm_f32(gT, tT, eng.grad_view(fc2.weight), M=D, N=hid, K=R, accumulate=True)        # dW2[d][h] += sum_r g[r][d] t[r][h]
         ops.colsum(g, eng.grad_view(fc2.bias), D, R=R)
+        del tT
     dt = ws.get("bwd.post.dt", tuple(sp["t"].shape), f32)
-    ops.gemm_nt(g, fc2.weight.detach().t(), dt, epilogue=L.EPI_F32, M=R, N=hid, K=D)
+    ops.gemm_nt(g, fc2.weight.detach().t().contiguous(), dt, epilogue=L.EPI_F32, M=R, N=hid, K=D)
     L.check(L.tanh_bwd_f32(ops._p(dt), ops._p(sp["t"]), ops._p(dt), R, hid, dt.stride(0), ops._stream()))
     if fc1.weight.requires_grad:
-        ops.gemm_tn(dt, sp["n"], eng.grad_view(fc1.weight), N=hid, K=D, R=R)
+        dtT, nT = dt[:R].t().contiguous(), sp["n"][:R].t().contiguous()  # (hid, R), (D, R)
+        ops._gemm_f32(dtT, nT, eng.grad_view(fc1.weight), M=hid, N=D, K=R, accumulate=True)
         ops.colsum(dt, eng.grad_view(fc1.bias), hid, R=R)
+        del dtT, nT
     dn = ws.get("bwd.post.dn", tuple(g.shape), f32)
-    ops.gemm_nt(dt, fc1.weight.detach().t(), dn, epilogue=L.EPI_F32, M=R, N=D, K=hid)
+    ops.gemm_nt(dt, fc1.weight.detach().t().contiguous(), dn, epilogue=L.EPI_F32, M=R, N=D, K=hid)
     nm = vit.norm_mlp
     # (the fp32 LayerNorm backward writes its second copy in fp32 too - it serves the verification mode: convert separately)
     ops.layernorm_bwd(dn, sp["x"], nm.weight, sp["mu"], sp["rs"], g, dres=g, dw=eng._g(nm.weight), db=eng._g(nm.bias), R=R)
