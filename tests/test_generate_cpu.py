@@ -101,3 +101,58 @@ def test_generate_dispatches_the_schedule(monkeypatch):
     assert calls[3][2] == (0.7, 5, 0.9) and calls[3][3] == {"seed": 13}
     with pytest.raises(ValueError):
         s.generate(md, [dict(target_domain="tok_depth@224", scheme="beam", num_tokens=1, temperature=1.0)])
+
+
+def test_generate_iter_and_sam_dense_host_logic(monkeypatch):
+    """generate_iter yields after every step and asks guided MaskGIT steps to show all predictions; generate_sam_dense expands the batch,
+    keeps only the key modality's schedule and merges the copies' sequences at their sentinels (generate.py:1099-1161, :1230-1272)."""
+    from fourm.models.generate import GenerationSampler
+
+    class M:
+        modality_info = {"tok_depth@224": {"type": "img"}, "sam_instance": {"type": "seq"}}
+    s = GenerationSampler(None)
+    object.__setattr__(s, "model", M())
+    calls = []
+
+    def rec(name):
+        def f(mod_dict, target, *a, **k):
+            calls.append((name, target, k.get("write_all_predictions"), k.get("seed")))
+            return mod_dict
+        return f
+    for n in ("maskgit_step_batched", "guided_maskgit_step_batched", "autoregressive_step_batched"):
+        monkeypatch.setattr(s, n, rec(n))
+    md = {"tok_depth@224": {"tensor": torch.zeros(1, 4)}, "sam_instance": {"tensor": torch.zeros(1, 6, dtype=torch.long)}}
+    sched = [dict(target_domain="tok_depth@224", scheme="maskgit", num_tokens=2, temperature=1.0),
+             dict(target_domain="tok_depth@224", scheme="maskgit", num_tokens=2, temperature=1.0, cfg_scale=3.0, cfg_cond_domains=["sam_instance"]),
+             dict(target_domain="sam_instance", temperature=0.5)]
+    seen = []
+    for cur in s.generate_iter(md, sched, seed=7):
+        seen.append(len(calls))
+        assert cur is not md
+    assert seen == [1, 2, 3]
+    assert calls == [("maskgit_step_batched", "tok_depth@224", None, 7), ("guided_maskgit_step_batched", "tok_depth@224", True, 8),
+                     ("autoregressive_step_batched", "sam_instance", None, 9)]
+    # dense prediction: the generate() call sees a batch of 3 copies and only the key's schedule; its output is merged per copy
+    tok = FakeTokenizer()
+    S0, S1 = tok.vocab["[S_0]"], tok.vocab["[S_1]"]
+    got = {}
+
+    def fake_generate(mod_dict, schedule, **kw):
+        got["batch"] = mod_dict["sam_instance"]["tensor"].shape[0]
+        got["schedule"] = schedule
+        out = {m: dict(d) for m, d in mod_dict.items()}
+        t = torch.tensor([[20, S0, 21, S0, 30 + i, S1, 0] for i in range(3)])             # input "20 [S_0] 21", target "[S_0] x [S_1]"
+        out["sam_instance"] = {"tensor": t, "input_mask": torch.tensor([[0, 0, 0, 1, 1, 1, 1]] * 3).bool(),
+                               "target_mask": torch.tensor([[1, 1, 1, 0, 0, 0, 1]] * 3).bool()}
+        return out
+    monkeypatch.setattr(s, "generate", fake_generate)
+    md2 = {"tok_depth@224": {"tensor": torch.arange(4.)[None], "input_mask": torch.zeros(1, 4).bool()},
+           "sam_instance": {"tensor": torch.zeros(1, 7, dtype=torch.long), "input_mask": torch.ones(1, 7).bool(), "target_mask": torch.zeros(1, 7).bool()}}
+    out = s.generate_sam_dense(md2, sched, tok, batch_size=3, key="sam_instance")
+    assert got["batch"] == 3 and [x["target_domain"] for x in got["schedule"]] == ["sam_instance"]
+    assert out["sam_instance"]["tensor"].tolist() == [[20, 30, 21, 20, 31, 21, 20, 32, 21]]
+    assert not bool(out["sam_instance"]["input_mask"].any()) and bool(out["sam_instance"]["target_mask"].all())
+    assert torch.equal(out["tok_depth@224"]["tensor"], md2["tok_depth@224"]["tensor"]) and out["tok_depth@224"]["tensor"] is not md2["tok_depth@224"]["tensor"]
+    with pytest.raises(ValueError):
+        bad = {"sam_instance": {"tensor": torch.zeros(2, 7, dtype=torch.long), "input_mask": torch.ones(2, 7).bool(), "target_mask": torch.zeros(2, 7).bool()}}
+        s.generate_sam_dense(bad, sched, tok, batch_size=3, key="sam_instance")

@@ -177,3 +177,18 @@ def test_trainer_schedule_bookkeeping():
     from fourm.utils.run_name import setup_run_name
     setup_run_name(a)
     assert a.run_name == "4m-ti_mod7_synth"
+
+
+def test_synthetic_data_config_variants():
+    """``--data_config synthetic`` / ``synthetic:dirichlet``: our dataset type (no upstream counterpart) and its masking switch."""
+    out = child(r'''
+        import types
+        import run_training_4m as T
+        for name, want in (("synthetic", "uniform"), ("synthetic:dirichlet", "dirichlet")):
+            cfg = T.load_data_config(types.SimpleNamespace(data_config=name))
+            ds = cfg["train"]["datasets"]["synthetic"]
+            assert ds["type"] == "synthetic" and ds["masking"] == want
+            assert "rgb@224" in ds["in_domains"].split("-") and "rgb@224" not in ds["out_domains"].split("-")
+        print("ok")
+    ''', upstream=False)
+    assert "ok" in out
