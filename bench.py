@@ -185,7 +185,12 @@ def extra_record(argv, timeout_s):
     import subprocess
     t0 = time.perf_counter()
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", *argv], capture_output=True, text=True, timeout=timeout_s)
+        env = dict(os.environ)
+        if env.get("BENCH_SHAPE_TABLE"):      # the child writes its own per-shape table NEXT TO the headline's, not over it
+            base, ext = os.path.splitext(env["BENCH_SHAPE_TABLE"])
+            tag = "_".join(x.lstrip("-") for x in argv[:2])
+            env["BENCH_SHAPE_TABLE"] = f"{base}_{tag}{ext}"
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras", *argv], capture_output=True, text=True, timeout=timeout_s, env=env)
         rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         rec["wall_s"] = round(time.perf_counter() - t0, 1)
         return rec

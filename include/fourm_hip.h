@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 4
+#define FM_ABI_VERSION 5
 int fm_abi_version(void);
 const char* fm_last_error(void);
 
@@ -280,12 +280,29 @@ int fm_gelu_bwd(const void* dh, int lddh, const void* pre, int ldp, void* dpre, 
  * casts amount to, fm_utils.py Linear layers under torch.autocast).  Job i covers the 64x64 tiles
  * [tile_start_i, tile_start_{i+1}) of its (rows, cols) source, tiles_i = ceil(rows/64)*ceil(cols/64);
  * transpose == 0: dst[r][c] = bf16(src[r][c]);  transpose == 1: dst[c][r] = bf16(src[r][c]).
+ * col_scale (optional, fp32[cols]): the source is multiplied by col_scale[c] first - a LayerNorm weight folded into the Linear
+ * that consumes the normalised rows (DecoderBlock.context_norm -> cross_attn.kv, fm_utils.py:364: every decoder block normalises
+ * the SAME context, so x_hat is computed once and gamma_l lives in the weight image).  dst_f32 != 0: fp32 destination (the
+ * fp32 verification mode keeps the same launch sequence).
  * Destination padding is not written.  descs: DEVICE pointer, sorted by tile_start (first = 0). */
 typedef struct fm_shadow_desc {
     const void* src; void* dst;
     int32_t ld_src, ld_dst, rows, cols, transpose, tile_start;
+    const void* col_scale;
+    int32_t dst_f32, reserved;
 } fm_shadow_desc;
 int fm_shadow_refresh(const fm_shadow_desc* descs, int n_descs, int total_tiles, void* stream);
+/* Gradient of a folded LayerNorm weight (see col_scale above).  With W' = W diag(gamma) used in the forward and
+ * dWp = dL/dW' (rows x cols, fp32, leading dimension ld_dwp) produced by the ordinary weight-gradient GEMM:
+ *     gW[r][c]  += dWp[r][c] * gamma[c]                (dL/dW,     accumulated like every gradient)
+ *     ggamma[c] += sum_r dWp[r][c] * W[r][c]           (dL/dgamma, fp32 atomics)
+ * W, gW: contiguous (rows x cols) fp32.  Job table passed by value (graph-capturable, no upload). */
+#define FM_FOLD_MAX_JOBS 48
+typedef struct fm_fold_grad_job {
+    const void* dWp; const void* W; const void* gamma; void* gW; void* ggamma;
+    int32_t rows, cols, ld_dwp, reserved;
+} fm_fold_grad_job;
+int fm_fold_colscale_grad(const fm_fold_grad_job* jobs, int n_jobs, void* stream);
 
 /* bf16 weight shadows: dst[r][c] = src[r][c], columns [cols, ld_dst) zero /
  * dst[c][r] = src[r][c], columns [rows, dst_cols) zero (dst_cols <= ld_dst) */

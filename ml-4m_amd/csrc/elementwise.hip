@@ -147,6 +147,36 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const fm_shadow_des
                 }
             }
         }
+        if (d.col_scale) {                                    // folded LayerNorm weight: src[r][c] * scale[c] (context-norm hoist)
+            const float* cs = (const float*)d.col_scale;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sc = tc0 + q + e < d.cols ? cs[tc0 + q + e] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i][e] *= sc;
+            }
+        }
+        if (d.dst_f32) {                                      // fp32 verification mode: same walk, fp32 destination, scalar stores
+            float* df = (float*)d.dst;
+            if (!d.transpose) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gr = tr0 + p + 16 * i, gc = tc0 + q;
+                    if (gr >= d.rows) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gc + e < d.cols) df[(size_t)gr * d.ld_dst + gc + e] = v[i][e];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int gr = tr0 + p + 16 * i, gc = tc0 + q;
+                    if (gr >= d.rows) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (gc + e < d.cols) df[(size_t)(gc + e) * d.ld_dst + gr] = v[i][e];
+                }
+            }
+            continue;
+        }
         if (!d.transpose) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -425,6 +455,49 @@ extern "C" int fm_shadow_refresh(const fm_shadow_desc* descs, int n_descs, int t
     hipLaunchKernelGGL(shadow_refresh_kernel, dim3((total_tiles + SHADOW_TILES_PER_BLOCK - 1) / SHADOW_TILES_PER_BLOCK), dim3(256), 0,
                        (hipStream_t)stream, descs, n_descs, total_tiles);
     FM_CHECK_LAUNCH("fm_shadow_refresh");
+    return 0;
+}
+
+// Gradient of a LayerNorm weight folded into the following Linear's weight image (fm_fold_colscale_grad in the header).
+// Block = 64 columns x 64 rows of one job: thread (cl, rl) walks rows rl, rl + 4, ...; the column sums meet in LDS, one atomic per column.
+struct FoldArgs { fm_fold_grad_job job[FM_FOLD_MAX_JOBS]; int n; };
+__global__ __launch_bounds__(256) void fold_colscale_grad_kernel(FoldArgs a) {
+    __shared__ float red[4][64];
+    const fm_fold_grad_job j = a.job[blockIdx.z];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl, r0 = blockIdx.y * 64;
+    float s = 0.f;
+    if (c < j.cols && r0 < j.rows) {
+        const float g = ((const float*)j.gamma)[c];
+        const float* dwp = (const float*)j.dWp;
+        const float* w = (const float*)j.W;
+        float* gw = (float*)j.gW;
+        const int r1 = min(j.rows, r0 + 64);
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float d = dwp[(size_t)r * j.ld_dwp + c];
+            if (gw) gw[(size_t)r * j.cols + c] += d * g;
+            s += d * w[(size_t)r * j.cols + c];
+        }
+    }
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < j.cols && j.ggamma && r0 < j.rows) atomicAdd((float*)j.ggamma + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
+extern "C" int fm_fold_colscale_grad(const fm_fold_grad_job* jobs, int n_jobs, void* stream) {
+    FM_CHECK_ARG(jobs && n_jobs > 0 && n_jobs <= FM_FOLD_MAX_JOBS, "fm_fold_colscale_grad: 1..FM_FOLD_MAX_JOBS jobs");
+    FoldArgs a{};
+    int max_r = 0, max_c = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const fm_fold_grad_job& j = jobs[i];
+        FM_CHECK_ARG(j.dWp && j.W && j.gamma && j.rows > 0 && j.cols > 0 && j.ld_dwp >= j.cols, "fm_fold_colscale_grad: bad job");
+        a.job[i] = j;
+        max_r = j.rows > max_r ? j.rows : max_r;
+        max_c = j.cols > max_c ? j.cols : max_c;
+    }
+    a.n = n_jobs;
+    hipLaunchKernelGGL(fold_colscale_grad_kernel, dim3((max_c + 63) / 64, (max_r + 63) / 64, n_jobs), dim3(256), 0, (hipStream_t)stream, a);
+    FM_CHECK_LAUNCH("fm_fold_colscale_grad");
     return 0;
 }
 

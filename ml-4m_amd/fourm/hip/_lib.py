@@ -26,7 +26,7 @@ def _load():
 lib = _load()
 lib.fm_last_error.restype = C.c_char_p
 lib.fm_abi_version.restype = C.c_int
-ABI_VERSION = 4
+ABI_VERSION = 5
 if lib.fm_abi_version() != ABI_VERSION:
     raise FourmHipUnavailable(f"libfourm_hip.so ABI {lib.fm_abi_version()} != expected {ABI_VERSION}; rebuild")
 
@@ -82,7 +82,14 @@ class ModDesc(C.Structure):
 
 class ShadowDesc(C.Structure):
     _fields_ = [("src", vp), ("dst", vp), ("ld_src", i32), ("ld_dst", i32), ("rows", i32), ("cols", i32),
-                ("transpose", i32), ("tile_start", i32)]
+                ("transpose", i32), ("tile_start", i32), ("col_scale", vp), ("dst_f32", i32), ("reserved", i32)]
+
+
+FOLD_MAX_JOBS = 48
+
+
+class FoldGradJob(C.Structure):
+    _fields_ = [("dWp", vp), ("W", vp), ("gamma", vp), ("gW", vp), ("ggamma", vp), ("rows", i32), ("cols", i32), ("ld_dwp", i32), ("reserved", i32)]
 
 
 class GemmF32Args(C.Structure):
@@ -156,6 +163,7 @@ cast_pad = _sig("fm_cast_pad", vp, i32, vp, i32, i32, i32, vp)
 transpose_cast_pad = _sig("fm_transpose_cast_pad", vp, i32, vp, i32, i32, i32, i32, vp)
 colsum = _sig("fm_colsum", vp, i32, vp, i32, i32, vp)
 shadow_refresh = _sig("fm_shadow_refresh", vp, i32, i32, vp)
+fold_colscale_grad = _sig("fm_fold_colscale_grad", vp, i32, vp)
 headnorm_fwd = _sig("fm_headnorm_fwd", vp, i32, vp, vp, vp, i32, vp, i32, i32, C.c_float, vp)
 headnorm_bwd = _sig("fm_headnorm_bwd", vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp)
 f32_to_bf16 = _sig("fm_f32_to_bf16", vp, vp, i64, vp)
@@ -211,7 +219,7 @@ EXPORTS = ["fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_fwd_res", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
-           "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_colsum", "fm_f32_to_bf16", "fm_adamw", "fm_adamw_shadow",
+           "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_fold_colscale_grad", "fm_colsum", "fm_f32_to_bf16", "fm_adamw", "fm_adamw_shadow",
            "fm_sumsq", "fm_clip_coef", "fm_vq_patchify", "fm_l2norm_rows", "fm_vq_assign",
            "fm_sample_tokens", "fm_maskgit_commit", "fm_gemm_f32", "fm_attn_f32_fwd", "fm_attn_f32_bwd", "fm_layernorm_bwd_f32", "fm_headnorm_f32_fwd", "fm_headnorm_f32_bwd",
            "fm_swiglu_bwd_f32", "fm_gelu_bwd_f32", "fm_colsum_f32", "fm_cross_entropy_f32"]

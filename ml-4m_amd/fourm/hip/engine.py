@@ -33,6 +33,12 @@ FUSE_ACT_BWD = os.environ.get("FOURM_FUSE_ACT_BWD", "0") == "1"
 # GEMM epilogue: the GEMM becomes a plain bf16 launch (the lock-step kernel), the fp32 read-modify-write of the stream moves from an
 # epilogue all workgroups enter together (~2.8 TB/s) into a streaming kernel (5.5 TB/s).  Bit-identical.  FOURM_DEFER_RESIDUAL=0: fused.
 DEFER_RESIDUAL = os.environ.get("FOURM_DEFER_RESIDUAL", "1") == "1"
+# Every decoder block normalises the SAME context (fm_utils.py:364, fm.py:514-515): x_hat = (context - mean) * rstd does not depend on the
+# layer.  With bias-free context norms the engine computes x_hat once, keeps gamma_l inside the bf16 image of cross_attn.kv.weight
+# (kv_l = x_hat (W_l diag(gamma_l))^T), sums the layers' gradients with respect to x_hat in ONE long-K GEMM and runs the LayerNorm backward
+# once (FourMEngine.hoist_ctx).  Only the bf16 rounding point moves: bf16(x_hat gamma) bf16(W) -> bf16(x_hat) bf16(W gamma).
+# FOURM_HOIST_CTX=0: one LayerNorm forward / backward per decoder block, as upstream computes it.
+HOIST_CTX = os.environ.get("FOURM_HOIST_CTX", "1") == "1"
 
 
 def bump_weight_epoch():
@@ -195,7 +201,10 @@ class FourMEngine:
 
         def nodecay(n):
             return "norm." in n or ".norm" in n or n.endswith(".bias")
-        named.sort(key=lambda np_: (nodecay(np_[0]),))
+        # (context-norm hoist: the decoder blocks' cross_attn.kv weights get their gradient in one piece after the decoder loop - they
+        # sit together behind the other decay-type tensors so that their slice of the gradient store is ONE range of one stage)
+        late = {id(b.cross_attn.kv.weight) for b in self.model.decoder} if self.hoist_ctx else set()
+        named.sort(key=lambda np_: (nodecay(np_[0]), id(np_[1]) in late))
         off, slices = 0, {}
         for n, p in named:
             slices[id(p)] = (off, p.numel())
@@ -233,6 +242,8 @@ class FourMEngine:
                 owner[id(p)] = stage          # later claims win
         for i, blk in enumerate(m.decoder):
             claim(f"dec{i}", blk)
+        if self.hoist_ctx:          # final only when the folded gradients have been unfolded (train_backward, after the decoder loop)
+            claim("dec_emb", [b.cross_attn.kv.weight for b in m.decoder] + [b.context_norm.weight for b in m.decoder])
         claim("heads", [m.decoder_norm.weight] + ([m.decoder_norm.bias] if isinstance(m.decoder_norm.bias, nn.Parameter) else []))
         claim("dec_emb", m.decoder_embeddings)
         claim("dec_emb", [m.mask_token])
@@ -331,8 +342,8 @@ class FourMEngine:
         stale = [s for s in self.shadows.values() if s.stamp != self._stamp(s.params)]
         jobs = []
         for s in stale:
-            jobs += [(p.detach().reshape(p.shape[0], -1), dst, tr) for (p, dst, tr) in s.jobs]
-        sig = tuple((a.data_ptr(), b.data_ptr(), tr) for (a, b, tr) in jobs)
+            jobs += [(j[0].detach().reshape(j[0].shape[0], -1), j[1], j[2], j[3].detach() if len(j) > 3 and j[3] is not None else None) for j in s.jobs]
+        sig = tuple((a.data_ptr(), b.data_ptr(), tr, sc.data_ptr() if sc is not None else 0) for (a, b, tr, sc) in jobs)
         if self._shadow_table is None or self._shadow_table[0] != sig:
             table, tiles = ops.shadow_jobs_table(jobs, self.device)
             self._shadow_table = (sig, table, len(jobs), tiles)
@@ -346,7 +357,7 @@ class FourMEngine:
         jobs is in ``written`` = {(id(param), destination data_ptr)}."""
         for key in keys:
             s = self.shadows.get(key)
-            if s is not None and all((id(p), dst.data_ptr()) in written for (p, dst, _) in s.jobs):
+            if s is not None and all(len(j) == 3 and (id(j[0]), j[1].data_ptr()) in written for j in s.jobs):
                 s.stamp = self._stamp(s.params)
 
     def w(self, p):
@@ -368,6 +379,43 @@ class FourMEngine:
             buf = torch.zeros(in_f, ru(out_f, 64), dtype=torch.bfloat16, device=p.device)
             return Shadow(buf, (p,), [(p, buf, True)])
         return self._get_shadow(("wt", id(p)), make)
+
+    def w_fold(self, lin, norm):
+        """(out, in_p) image of lin.weight * norm.weight[None, :] - the W operand of y = x_hat (W diag(gamma))^T (context-norm hoist)."""
+        p, g = lin.weight, norm.weight
+        def make():
+            out_f, in_f = p.shape
+            buf = torch.zeros(out_f, in_f if self.fp32 else ru(in_f, 64), dtype=self.adt, device=p.device)
+            return Shadow(buf, (p, g), [(p, buf, False, g)])
+        return self._get_shadow(("wfold", id(p)), make)
+
+    def wt_fold_stack(self):
+        """(D, L * 2D) image [ (W_0 diag(gamma_0))^T | (W_1 diag(gamma_1))^T | ... ] of every decoder block's cross_attn.kv weight:
+        the W operand of d(x_hat) = [dkv_0 | dkv_1 | ...] W_stack, the sum over the layers as ONE reduction of length L * 2D."""
+        m, D = self.model, self.D
+        def make():
+            Ld = len(m.decoder)
+            buf = torch.zeros(D, Ld * 2 * D, dtype=self.adt, device=self.device)
+            ps, jobs = [], []
+            for i, blk in enumerate(m.decoder):
+                p, g = blk.cross_attn.kv.weight, blk.context_norm.weight
+                ps += [p, g]
+                jobs.append((p, buf[:, i * 2 * D:(i + 1) * 2 * D], True, g))
+            return Shadow(buf, tuple(ps), jobs)
+        return self._get_shadow(("wtfold", 0), make)
+
+    @property
+    def hoist_ctx(self):
+        """The context-norm hoist applies: every decoder block's context_norm is bias-free (all 4M swiglu_nobias configurations) and
+        its cross-attention K/V projection is trainable or frozen as a whole with it."""
+        h = getattr(self, "_hoist_ctx", None)
+        if h is None:
+            m = self.model
+            h = HOIST_CTX and len(m.decoder) > 0 and all(
+                not isinstance(b.context_norm.bias, nn.Parameter) and b.cross_attn.kv.bias is None
+                and b.cross_attn.kv.weight.requires_grad == b.context_norm.weight.requires_grad for b in m.decoder)
+            self._hoist_ctx = h
+        return h
 
     def w13t(self, mlp):
         """(D, 2*Hp) bf16 = [fc1^T | fc3^T]: the W operand of d(h2) = [dg | du] [fc1; fc3]."""
@@ -510,6 +558,15 @@ class FourMEngine:
         self._last_dp = dp
         return dp
 
+    def _unit_norm(self):
+        """LayerNorm without an affine part (weight 1, no bias) at the decoder blocks' context_norm epsilon: x_hat of the hoisted context norm."""
+        n = getattr(self, "_unit", None)
+        if n is None or n.weight.device != self.device:
+            from types import SimpleNamespace
+            n = self._unit = SimpleNamespace(weight=torch.ones(self.D, dtype=torch.float32, device=self.device), bias=None,
+                                             eps=self.model.decoder[0].context_norm.eps)
+        return n
+
     def _settle(self):
         """A deferred residual sum nobody normalised (a caller outside the trunk loops wants the stream itself): write it now."""
         pend, self._pending = self._pending, None
@@ -570,13 +627,13 @@ class FourMEngine:
         ops.attn_fwd(q_in, k_in, qkv[:, 2 * D:], o, B, self.H, N, N, self.scale, stat_m=sm, stat_l=sl, zero_attn=getattr(attn, "allow_zero_attn", False), **mask)
         self._residual(o, attn.proj, x_res, x_out, R, D, D, defer=True)       # (every caller normalises x_out next)
 
-    def _cross_attn_fwd(self, attn, hq, hc, x_res, x_out, B, M, N, Rq, Rqp, Rc, Rcp, mask, sv, tag):
+    def _cross_attn_fwd(self, attn, hq, hc, x_res, x_out, B, M, N, Rq, Rqp, Rc, Rcp, mask, sv, tag, w_kv=None):
         bf, D = self.adt, self.D
         q = self._buf(sv, tag, "q", (Rqp, D), bf)
         kv = self._buf(sv, tag, "kv", (Rcp, 2 * D), bf)
         o = self._buf(sv, tag, "o2", (Rqp, D), bf)
         ops.gemm_nt(hq, self.w(attn.q.weight), q, bias=attn.q.bias, M=Rq, N=D, K=D)
-        ops.gemm_nt(hc, self.w(attn.kv.weight), kv, bias=attn.kv.bias, M=Rc, N=2 * D, K=D)
+        ops.gemm_nt(hc, self.w(attn.kv.weight) if w_kv is None else w_kv, kv, bias=attn.kv.bias, M=Rc, N=2 * D, K=D)
         sm = sl = None
         if sv is not None:
             sm = self._buf(sv, tag, "sm2", (B, self.H, M), torch.float32)
@@ -606,8 +663,10 @@ class FourMEngine:
             sv["x_in"] = x_in
         return x_out
 
-    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag, defer_out=False, out_name=None, dp=None):
-        """[upstream DecoderBlock.forward, fm_utils.py:362-366]"""
+    def decoder_block_fwd(self, blk, y_in, ctx, B, M, N, sa_mask, xa_mask, sv, tag, defer_out=False, out_name=None, dp=None, ctx_hat=None):
+        """[upstream DecoderBlock.forward, fm_utils.py:362-366]
+        ctx_hat (trunk loops with the context-norm hoist): the normalised context WITHOUT the affine part, computed once for all blocks;
+        this block's context_norm.weight is then inside the kv weight image (w_fold)."""
         Rq, Rqp, Rc, Rcp, D = B * M, y_in.shape[0], B * N, ctx.shape[0], self.D
         bf, f32 = self.adt, torch.float32
         dp = self._drop_scales(blk, B, 3, sv, dp)
@@ -617,9 +676,12 @@ class FourMEngine:
         self._self_attn_fwd(blk.self_attn, h1, y_in, y1, B, M, Rq, Rqp, sa_mask, sv, tag)
         self._drop_now = (dp[1], M) if dp else None
         hq = self._ln(blk.query_norm, y1, self._buf(sv, tag, "hq", (Rqp, D), bf), Rq, sv, "nq", tag)
-        hc = self._ln(blk.context_norm, ctx, self._buf(sv, tag, "hc", (Rcp, D), bf), Rc, sv, "nc", tag)
+        if ctx_hat is None:
+            hc, w_kv = self._ln(blk.context_norm, ctx, self._buf(sv, tag, "hc", (Rcp, D), bf), Rc, sv, "nc", tag), None
+        else:
+            hc, w_kv = ctx_hat, self.w_fold(blk.cross_attn.kv, blk.context_norm)
         y2 = self._buf(sv, tag, "y2", (Rqp, D), f32)
-        self._cross_attn_fwd(blk.cross_attn, hq, hc, y1, y2, B, M, N, Rq, Rqp, Rc, Rcp, xa_mask, sv, tag)
+        self._cross_attn_fwd(blk.cross_attn, hq, hc, y1, y2, B, M, N, Rq, Rqp, Rc, Rcp, xa_mask, sv, tag, w_kv=w_kv)
         h2 = self._ln(blk.norm2, y2, self._buf(sv, tag, "h2", (Rqp, D), bf), Rq, sv, "n2", tag)
         y_out = self.ws.get(out_name or (tag + ".y_out" if sv is not None else "scratch.y_out" + tag[-1:]), (Rqp, D), f32)
         self._drop_now = (dp[2], M) if dp else None
@@ -681,20 +743,24 @@ class FourMEngine:
         x, ctx, emask, sv_top = self.encode_context(enc, st)
         y = dec["x0"]
         smask = self.decoder_mask(dec["cs"], dec["mod_pre"]) if "cs" in dec else dec["sa_mask"]
+        ctx_hat, sv_hat = None, None
+        if self.hoist_ctx:        # x_hat of the context once for all decoder blocks (see HOIST_CTX)
+            sv_hat = {} if save else None
+            ctx_hat = self._ln(self._unit_norm(), ctx, self._buf(sv_hat, "top", "ctx_hat", (ctx.shape[0], self.D), self.adt), B * N, sv_hat, "ch", "top")
         for i, blk in enumerate(m.decoder):
             if save and self.checkpointing:
                 st["dec_layers"].append(dict(ckpt_in=y))
                 y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, None, f"dec{i % 2}", defer_out=i + 1 < len(m.decoder),
-                                           out_name=f"dec{i}.y_out")
+                                           out_name=f"dec{i}.y_out", ctx_hat=ctx_hat)
                 st["dec_layers"][-1]["dp"] = self._last_dp
                 continue
             sv = {} if save else None
             y = self.decoder_block_fwd(blk, y, ctx, B, Mt, N, smask, emask, sv, f"dec{i}" if save else f"dec{i % 2}",
-                                       defer_out=i + 1 < len(m.decoder))           # next: the following block's norm1
+                                       defer_out=i + 1 < len(m.decoder), ctx_hat=ctx_hat)           # next: the following block's norm1
             if save:
                 st["dec_layers"].append(sv)
         if save:
-            st.update(top=sv_top, x_final=x, y_final=y, ctx=ctx, emask=emask, smask=smask)
+            st.update(top=sv_top, x_final=x, y_final=y, ctx=ctx, emask=emask, smask=smask, ctx_hat=ctx_hat, sv_hat=sv_hat)
         return y, st
 
     def heads_setup(self, dec, y_final, save):
@@ -876,7 +942,9 @@ class FourMEngine:
         self._flush_dW()
         self._ln_bwd(blk.norm1, dh, sv["x_in"], sv, "n1", g, g_bf, R, dres=g)
 
-    def decoder_block_bwd(self, blk, sv, g, g_bf, dctx, dctx_bf, ctx, B, M, N, sa_mask, xa_mask):
+    def decoder_block_bwd(self, blk, sv, g, g_bf, dctx, dctx_bf, ctx, B, M, N, sa_mask, xa_mask, hoist=None):
+        """hoist (context-norm hoist) = (dkv of this layer as a column block of the all-layer buffer, x_hat, fp32 scratch for dL/dW'):
+        the block then leaves d(kv) and dL/d(W diag(gamma)) behind; d(context) and the unfolding follow the decoder loop."""
         bf, D = self.adt, self.D
         Rq, Rqp, Rc, Rcp = B * M, g.shape[0], B * N, ctx.shape[0]
         ws = self.ws
@@ -896,7 +964,7 @@ class FourMEngine:
         do = ws.get("bwd.do", (Rqp, D), bf)
         ops.gemm_nt(g_bf, self.wt(xa.proj.weight), do, M=Rq, N=D, K=D)
         dq = ws.get("bwd.dq", (Rqp, D), bf)
-        dkv = ws.get("bwd.dkv", (Rcp, 2 * D), bf)
+        dkv = ws.get("bwd.dkv", (Rcp, 2 * D), bf) if hoist is None else hoist[0]
         kv = sv["kv"]
         if self.qk_norm:
             dqn = ws.get("bwd.dqn", (Rqp, D), bf)
@@ -914,10 +982,13 @@ class FourMEngine:
         self._ln_bwd(blk.query_norm, dhq, sv["y1"], sv, "nq", g, g_bf, Rq, dres=g)
         if dp:
             ops.scale_rows_bf16(g_bf, dp[0], M, Rq)
-        self._dW(dkv, sv["hc"], xa.kv, Rc)
-        dhc = ws.get("bwd.dhc", (Rcp, D), bf)
-        ops.gemm_nt(dkv, self.wt(xa.kv.weight), dhc, M=Rc, N=D, K=2 * D)
-        self._ln_bwd(blk.context_norm, dhc, ctx, sv, "nc", dctx, dctx_bf, Rc, dres=dctx)     # accumulates over layers
+        if hoist is None:
+            self._dW(dkv, sv["hc"], xa.kv, Rc)
+            dhc = ws.get("bwd.dhc", (Rcp, D), bf)
+            ops.gemm_nt(dkv, self.wt(xa.kv.weight), dhc, M=Rc, N=D, K=2 * D)
+            self._ln_bwd(blk.context_norm, dhc, ctx, sv, "nc", dctx, dctx_bf, Rc, dres=dctx)     # accumulates over layers
+        elif xa.kv.weight.requires_grad:
+            self._dw_jobs.append((dkv, hoist[1], hoist[2], 2 * D, D, Rc))                       # dL/d(W diag(gamma)) = dkv^T x_hat
         # self attention
         dh = self._self_attn_bwd(blk.self_attn, sv, g_bf, B, M, Rq, Rqp, sa_mask)
         self._flush_dW()
@@ -998,14 +1069,33 @@ class FourMEngine:
         # ---- decoder ----------------------------------------------------------------------------------
         dctx = ws.get("bwd.dctx", (Rcp, D), f32)
         dctx_bf = ws.get("bwd.dctx_bf", (Rcp, D), bf)
-        dctx.zero_()
-        for i in reversed(range(len(m.decoder))):
+        Ld = len(m.decoder)
+        ctx_hat = st.get("ctx_hat")
+        if ctx_hat is None:
+            dctx.zero_()
+        else:       # context-norm hoist: the layers' d(kv) side by side, dL/d(W_l diag(gamma_l)) in a zeroed fp32 scratch
+            dkv_all = ws.get("bwd.dkv_all", (Rcp, Ld * 2 * D), bf)
+            dwp = ws.get("bwd.dwp", (Ld, 2 * D, D), f32)
+            dwp.zero_()
+        for i in reversed(range(Ld)):
             sv = st["dec_layers"][i]
             if "ckpt_in" in sv:       # recompute this block's activations from its saved input (one shared set of buffers)
                 y_in, dp, sv = sv["ckpt_in"], sv["dp"], {}
-                self.decoder_block_fwd(m.decoder[i], y_in, st["ctx"], B, Mt, N, st["smask"], st["emask"], sv, "ckpt", out_name="ckpt.out", dp=dp)
-            self.decoder_block_bwd(m.decoder[i], sv, g, g_bf, dctx, dctx_bf, st["ctx"], B, Mt, N, st["smask"], st["emask"])
+                self.decoder_block_fwd(m.decoder[i], y_in, st["ctx"], B, Mt, N, st["smask"], st["emask"], sv, "ckpt", out_name="ckpt.out", dp=dp,
+                                       ctx_hat=ctx_hat)
+            hoist = None if ctx_hat is None else (dkv_all[:, i * 2 * D:(i + 1) * 2 * D], ctx_hat, dwp[i])
+            self.decoder_block_bwd(m.decoder[i], sv, g, g_bf, dctx, dctx_bf, st["ctx"], B, Mt, N, st["smask"], st["emask"], hoist=hoist)
             self._stage(f"dec{i}")
+        if ctx_hat is not None and Ld:
+            # d(x_hat) = sum_l dkv_l (W_l diag(gamma_l)): one GEMM with a reduction over all layers, then ONE LayerNorm backward (no affine part)
+            dxh = ws.get("bwd.dhc", (Rcp, D), bf)
+            ops.gemm_nt(dkv_all, self.wt_fold_stack(), dxh, M=Rc, N=D, K=Ld * 2 * D)
+            self._ln_bwd(self._unit_norm(), dxh, st["ctx"], st["sv_hat"], "ch", dctx, dctx_bf, Rc, dres=None)
+            # dL/dW_l = dL/dW'_l diag(gamma_l);  dL/dgamma_l = column sums of dL/dW'_l * W_l
+            jobs = [(dwp[i], b.cross_attn.kv.weight.detach(), b.context_norm.weight.detach(), self._g(b.cross_attn.kv.weight), self._g(b.context_norm.weight))
+                    for i, b in enumerate(m.decoder) if b.cross_attn.kv.weight.requires_grad]
+            if jobs:
+                ops.fold_colscale_grad(jobs)
         self._embed_bwd(dec, g, None, True)
         self._stage("dec_emb")
         # ---- context projection + encoder -------------------------------------------------------------

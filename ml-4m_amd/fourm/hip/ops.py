@@ -349,20 +349,41 @@ def transpose_cast_pad(src, dst):
 
 
 def shadow_jobs_table(jobs, device):
-    """jobs: list of (src f32 2-D view, dst bf16 2-D view, transpose) -> (device byte tensor of fm_shadow_desc, total tiles)."""
+    """jobs: list of (src f32 2-D view, dst bf16 | f32 2-D view, transpose[, col_scale f32 (cols,) | None]) ->
+    (device byte tensor of fm_shadow_desc, total tiles)."""
     arr = (L.ShadowDesc * len(jobs))()
     tiles = 0
-    for i, (src, dst, tr) in enumerate(jobs):
+    for i, job in enumerate(jobs):
+        src, dst, tr = job[:3]
+        scale = job[3] if len(job) > 3 else None
         rows, cols = src.shape
         need = (cols, rows) if tr else (rows, cols)
-        assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.stride(1) == 1 and dst.stride(1) == 1
+        assert src.dtype == torch.float32 and dst.dtype in (torch.bfloat16, torch.float32) and src.stride(1) == 1 and dst.stride(1) == 1
         assert dst.shape[0] >= need[0] and dst.shape[1] >= need[1], (tuple(dst.shape), need)
         d = arr[i]
         d.src, d.dst, d.ld_src, d.ld_dst = src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0)
         d.rows, d.cols, d.transpose, d.tile_start = rows, cols, 1 if tr else 0, tiles
+        d.dst_f32 = 1 if dst.dtype == torch.float32 else 0
+        if scale is not None:
+            assert scale.dtype == torch.float32 and scale.numel() == cols and scale.is_contiguous()
+            d.col_scale = scale.data_ptr()
         tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
     return raw, tiles
+
+
+def fold_colscale_grad(jobs):
+    """jobs = [(dWp f32 (rows, cols) view, W f32 master, gamma f32 (cols,), gW f32 | None, ggamma f32 (cols,) | None)]:
+    gW += dWp * gamma[None, :];  ggamma += sum_r dWp * W  (csrc/elementwise.hip fold_colscale_grad_kernel)."""
+    for lo in range(0, len(jobs), L.FOLD_MAX_JOBS):
+        part = jobs[lo:lo + L.FOLD_MAX_JOBS]
+        arr = (L.FoldGradJob * len(part))()
+        for j, (dwp, w, gamma, gw, gg) in zip(arr, part):
+            rows, cols = w.shape[0], w[0].numel()
+            assert w.is_contiguous() and (gw is None or gw.is_contiguous()) and dwp.stride(1) == 1
+            j.dWp, j.W, j.gamma, j.gW, j.ggamma = _p(dwp), _p(w), _p(gamma), _p(gw), _p(gg)
+            j.rows, j.cols, j.ld_dwp = rows, cols, dwp.stride(0)
+        L.check(L.fold_colscale_grad(arr, len(part), _stream()))
 
 
 def shadow_refresh(table, n_jobs, tiles):

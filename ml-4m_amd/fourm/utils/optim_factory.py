@@ -140,9 +140,12 @@ class FusedAdamW(optim.AdamW):
                     sh = eng.shadows.get(key) if eng is not None else None
                     if sh is None:
                         continue
-                    for (pp, dst, transposed) in sh.jobs:
+                    for job in sh.jobs:
+                        pp, dst, transposed = job[:3]
                         # (transposed copies keep going through the engine's lazy fm_shadow_refresh: a transposing walk cannot
-                        # stream, and this kernel must)
+                        # stream, and this kernel must; so do images with a folded LayerNorm weight: they depend on a second parameter)
+                        if len(job) > 3 and job[3] is not None:
+                            continue
                         if pp is p and not transposed and plain is None:
                             plain = dst; keys.append((eng, key))
                 if plain is not None or tr is not None:

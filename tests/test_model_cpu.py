@@ -145,7 +145,8 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
     pairs = {"fm_gemm_group": _lib.GemmGroup, "fm_gemm_nt_args": _lib.GemmNTArgs, "fm_gemm_tn_args": _lib.GemmTNArgs, "fm_gemm_tn_job": _lib.GemmTNJob,
              "fm_gemm_f32_args": _lib.GemmF32Args, "fm_adamw_job": _lib.AdamWJob,
              "fm_attn_args": _lib.AttnArgs, "fm_mod_desc": _lib.ModDesc, "fm_select_desc": _lib.SelectDesc,
-             "fm_embed_bwd_mod": _lib.EmbedBwdMod, "fm_embed_bwd_desc": _lib.EmbedBwdDesc, "fm_shadow_desc": _lib.ShadowDesc, "fm_span_mask_args": _lib.SpanMaskArgs}
+             "fm_embed_bwd_mod": _lib.EmbedBwdMod, "fm_embed_bwd_desc": _lib.EmbedBwdDesc, "fm_shadow_desc": _lib.ShadowDesc, "fm_fold_grad_job": _lib.FoldGradJob,
+             "fm_span_mask_args": _lib.SpanMaskArgs}
     header = open(os.path.join(ROOT, "include", "fourm_hip.h")).read()
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "fourm_hip.h"', 'int main(void) {']
     fields = {}
