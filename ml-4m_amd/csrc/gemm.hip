@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
 int g_nt_config = 9, g_nt_prio = 1;
 // experiment knobs (tools/gemm_lab via fm_lab_set): [0] de-phase groups, [1] de-phase step (x 2048 cycles), [2] gemm_nt3 mode (0 off,
 // 1 = 256-wide tiles, 2 = 192-wide, 3 = by shape: the default; FOURM_NT3=0 turns it off), [3] gemm_nt3 experiment flags
-int g_lab[16] = {0, 0, [] { const char* e = getenv("FOURM_NT3"); return e ? atoi(e) : 3; }(), 0};
+int g_lab[16] = {0, 0, [] { const char* e = getenv("FOURM_NT3"); return e ? atoi(e) : 3; }(), [] { const char* e = getenv("FOURM_NT3_LAB"); return e ? atoi(e) : 0; }()};
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 

@@ -35,7 +35,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* base) {
 }
 constexpr uint32_t OOB = 0x80000000u;       // an offset with bit 31 set is outside num_records: the access is dropped / reads 0
 
-template <int TW, int EPI, bool SPLIT = false>
+// STG: the bf16 outputs of a tile leave through a wave-private LDS staging area (the 32 / 48 KB the two operand stages leave of the 160 KB):
+// a wave holds 32 rows x 32 bytes per store instruction in its accumulator layout - 32-byte write requests at the L2, 4.7 M of the 13 M
+// requests of a qkv launch (profiles/r04_pmc_l2_fullline.txt) - and re-reads the staged rows so that consecutive lanes cover whole
+// 128-byte lines: the same store instructions, half the write requests (64 bytes each), bit-identical outputs.
+template <int TW, int EPI, bool SPLIT = false, bool STG = false>
 __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TX = 256, KB = 64, WW = 2, WX = 4, NWAVES = 8, KS = 4;
@@ -144,7 +148,50 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
     auto finish_tile = [&](int j_done) __attribute__((always_inline)) {
         int n0, m0;
         tile_origin(j_done, n0, m0);
-        if constexpr (EPI == EPI_BF16) {
+        if constexpr (EPI == EPI_BF16 && STG) {
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
+            constexpr int CW = (TW / WW) / 8;                                   // 16-byte chunks per staged row: 16 (two rounds of 8) or 12
+            constexpr int RCH = CW == 16 ? 8 : 12, ROWB = RCH * 16, NRND = CW / RCH, SPR = 32 * RCH / 64;     // stores per round
+            char* sc = smem + 2 * STAGE + wave * (32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < FX; ++j)
+#pragma unroll
+                for (int rnd = 0; rnd < NRND; ++rnd) {
+#pragma unroll
+                    for (int ii = 0; ii < RCH / 4; ++ii)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int i = rnd * (RCH / 4) + ii, ch = ii * 4 + g;
+                            const uint2 pv = make_uint2(pack2bf(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
+                            int pos;
+                            if constexpr (RCH == 8) pos = ch ^ (frow & 7);
+                            else { pos = ch + (frow & 7); pos = pos >= 12 ? pos - 12 : pos; }
+                            *(uint2*)(sc + frow * ROWB + pos * 16 + fhi * 8) = pv;
+                        }
+                    wait_lgkmcnt<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    u32x4_t rv[SPR];
+                    int rr[SPR], cc[SPR];
+#pragma unroll
+                    for (int q = 0; q < SPR; ++q) {
+                        const int t = q * 64 + lane;
+                        rr[q] = t / RCH; cc[q] = t % RCH;
+                        int pos;
+                        if constexpr (RCH == 8) pos = cc[q] ^ (rr[q] & 7);
+                        else { pos = cc[q] + (rr[q] & 7); pos = pos >= 12 ? pos - 12 : pos; }
+                        rv[q] = *(const u32x4_t*)(sc + rr[q] * ROWB + pos * 16);
+                    }
+                    wait_lgkmcnt<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < SPR; ++q) {
+                        const int rl = wx * (TX / WX) + j * 32 + rr[q];
+                        const int c = n0 + ww * (TW / WW) + rnd * (RCH * 8) + cc[q] * 8;
+                        const uint32_t so = ((m0 + rl < a.M && c < N) ? 0u : OOB) | ((uint32_t)(rl * a.ldo) * 2u + (uint32_t)c * 2u);
+                        __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out, so, 0, 0);
+                    }
+                }
+        } else if constexpr (EPI == EPI_BF16) {
             const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
             const int c0 = n0 + ww * (TW / WW) + 8 * fhi;                       // this lane's first column (chunk 0)
 #pragma unroll
@@ -262,6 +309,61 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
                 const uint32_t off = src_off(unit, a.ldo);
                 __builtin_amdgcn_raw_buffer_store_b128(vg, rs_out, off, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(vu, rs_out, off + (uint32_t)a.Hp * 2u, 0, 0);
+            }
+        } else if constexpr (EPI == EPI_SWIGLU && STG) {
+            // (g, u) -> gu buffer [g | u], act -> out; per wave and 32-row block: three staged rounds of 32 rows x 64 hidden units (128 bytes per row)
+            const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
+            const __amdgpu_buffer_rsrc_t rs_out2 = rsrc_of((const char*)(a.out2 ? a.out2 : a.out) + (size_t)m0 * (a.out2 ? a.ldo2 : a.ldo) * 2);
+            char* sc = smem + 2 * STAGE + wave * 4096;
+            const int hw0 = n0 + (ww * (TW / WW) / 64) * 32;                    // this wave's first hidden unit
+#pragma unroll
+            for (int j = 0; j < FX; ++j) {
+                // g and u are kept PACKED (32 registers) across the three rounds; act is formed from the packed values (bf16 -> f32 is exact)
+                uint2 qg[FW / 2][4], qu[FW / 2][4];
+#pragma unroll
+                for (int ip = 0; ip < FW / 2; ++ip)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        qg[ip][g] = make_uint2(pack2bf(acc[2 * ip][j][4 * g], acc[2 * ip][j][4 * g + 1]), pack2bf(acc[2 * ip][j][4 * g + 2], acc[2 * ip][j][4 * g + 3]));
+                        qu[ip][g] = make_uint2(pack2bf(acc[2 * ip + 1][j][4 * g], acc[2 * ip + 1][j][4 * g + 1]), pack2bf(acc[2 * ip + 1][j][4 * g + 2], acc[2 * ip + 1][j][4 * g + 3]));
+                        asm volatile("" : "+v"(qg[ip][g].x), "+v"(qg[ip][g].y), "+v"(qu[ip][g].x), "+v"(qu[ip][g].y));      // opaque: no float copies kept alive
+                    }
+#pragma unroll
+                for (int which = 0; which < 3; ++which) {
+                    if (which < 2 && !a.out2) continue;
+#pragma unroll
+                    for (int ip = 0; ip < FW / 2; ++ip)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            uint2 pv = which == 0 ? qg[ip][g] : qu[ip][g];
+                            if (which == 2) {
+                                float gv[4], uv[4];
+                                unpack_bf4(qg[ip][g], gv); unpack_bf4(qu[ip][g], uv);
+                                pv = make_uint2(pack2bf(bfround(silu_f(gv[0])) * uv[0], bfround(silu_f(gv[1])) * uv[1]),
+                                                pack2bf(bfround(silu_f(gv[2])) * uv[2], bfround(silu_f(gv[3])) * uv[3]));
+                            }
+                            const int ch = ip * 4 + g;
+                            *(uint2*)(sc + frow * 128 + ((ch ^ (frow & 7)) * 16) + fhi * 8) = pv;
+                        }
+                    wait_lgkmcnt<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    u32x4_t rv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = q * 8 + (lane >> 3), c = lane & 7;
+                        rv[q] = *(const u32x4_t*)(sc + r * 128 + ((c ^ (r & 7)) * 16));
+                    }
+                    wait_lgkmcnt<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rl = wx * (TX / WX) + j * 32 + q * 8 + (lane >> 3);
+                        const int h = hw0 + (lane & 7) * 8;
+                        const uint32_t ok = (m0 + rl < a.M && h < N) ? 0u : OOB;
+                        if (which == 2) __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out, ok | ((uint32_t)(rl * a.ldo) * 2u + (uint32_t)h * 2u), 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out2, ok | ((uint32_t)(rl * a.ldo2) * 2u + (uint32_t)(h + (which == 1 ? a.Hp : 0)) * 2u), 0, 0);
+                    }
+                }
             }
         } else if constexpr (EPI == EPI_SWIGLU) {
             const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
@@ -432,7 +534,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
 #endif
 }
 
-template <int TW, int EPI, bool SPLIT = false>
+template <int TW, int EPI, bool SPLIT = false, bool STG = false>
 int launch_nt3(NTArgs a, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (a.N + NPT - 1) / NPT;
@@ -441,8 +543,8 @@ int launch_nt3(NTArgs a, hipStream_t s) {
     int grid = a.n_tiles_w * a.n_tiles_x;
     const int cus = fm_grid_cus();
     if (grid > cus) grid = cus;
-    const size_t lds = (size_t)2 * (TW + 256) * 128;
-    auto k = gemm_nt3_kernel<TW, EPI, SPLIT>;
+    const size_t lds = (size_t)2 * (TW + 256) * 128 + (STG ? (TW == 256 ? 32768 : 49152) : 0);
+    auto k = gemm_nt3_kernel<TW, EPI, SPLIT, STG>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
@@ -467,6 +569,8 @@ int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     const bool use192 = mode == 2 ? fits192 : mode == 3 ? (fits192 && (a.N % 256 != 0 || t256 % 256 != 0)) : false;
     if (epilogue == FM_EPI_BF16) {
         if (a.ldo % 8 != 0) return 0;
+        if (!(a.lab & 1024) && !(a.lab & 16) && a.ldo % 64 == 0 && (((uintptr_t)a.out) & 127) == 0)      // staged epilogue (whole-line stores); lab bit 1024: legacy
+            return use192 ? launch_nt3<192, EPI_BF16, true, true>(a, s) : launch_nt3<256, EPI_BF16, true, true>(a, s);
         if (!(a.lab & 16)) return use192 ? launch_nt3<192, EPI_BF16, true>(a, s) : launch_nt3<256, EPI_BF16, true>(a, s);
         return use192 ? launch_nt3<192, EPI_BF16>(a, s) : launch_nt3<256, EPI_BF16>(a, s);
     }
@@ -484,6 +588,8 @@ int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     }
     if (epilogue == FM_EPI_SWIGLU) {
         if (a.N % 64 != 0 || a.Hp % 8 != 0 || a.ldo % 8 != 0 || (a.out2 && a.ldo2 % 8 != 0) || !a.W2) return 0;
+        if (!(a.lab & 1024) && !(a.lab & 16) && a.ldo % 64 == 0 && (!a.out2 || a.ldo2 % 64 == 0) && a.Hp % 64 == 0 && a.N % 64 == 0)
+            return launch_nt3<256, EPI_SWIGLU, true, true>(a, s);
         if (!(a.lab & 16)) return launch_nt3<256, EPI_SWIGLU, true>(a, s);
         return launch_nt3<256, EPI_SWIGLU>(a, s);
     }
