@@ -38,6 +38,10 @@ def upstream_root() -> Optional[str]:
             continue
         if os.path.isfile(os.path.join(f, "models", "fm.py")):
             root = c
+            if os.path.abspath(os.environ.get("FOURM_UPSTREAM", "") or os.devnull) != c and not os.environ.get("FOURM_UPSTREAM_QUIET"):
+                # found on sys.path rather than named explicitly: say so once (which data loaders / vendored helpers run depends on it)
+                print(f"[fourm] out-of-scope modules (fourm.data, vendored helpers) fall through to the upstream checkout at {c} "
+                      f"(found on sys.path; set FOURM_UPSTREAM to choose explicitly)", file=sys.stderr)
             break
     _cache["root"] = root
     return root

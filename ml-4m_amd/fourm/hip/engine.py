@@ -360,23 +360,24 @@ class FourMEngine:
             if s is not None and all(len(j) == 3 and (id(j[0]), j[1].data_ptr()) in written for j in s.jobs):
                 s.stamp = self._stamp(s.params)
 
-    def w(self, p):
-        """(out, in_p) bf16, pad columns zero: the W operand of y = x W^T."""
+    def w(self, p, pad_rows=False):
+        """(out, in_p) bf16, pad columns zero: the W operand of y = x W^T.  pad_rows: the image has ru(out, 64) rows, the extra ones zero
+        (4M-L's hidden width 2730 -> 2752: the GEMM then runs over whole 64-column groups and writes zeros into the pad columns)."""
         if self.fp32:
             return p.detach().reshape(p.shape[0], -1)
         def make():
             out_f, in_f = p.shape[0], p[0].numel()
-            buf = torch.zeros(out_f, ru(in_f, 64), dtype=torch.bfloat16, device=p.device)
+            buf = torch.zeros(ru(out_f, 64) if pad_rows else out_f, ru(in_f, 64), dtype=torch.bfloat16, device=p.device)
             return Shadow(buf, (p,), [(p, buf, False)])
         return self._get_shadow(("w", id(p)), make)
 
-    def wt(self, p):
-        """(in, out_p) bf16, pad columns zero: the W operand of dX = dY W."""
+    def wt(self, p, pad_rows=False):
+        """(in, out_p) bf16, pad columns zero: the W operand of dX = dY W.  pad_rows: ru(in, 64) rows, the extra ones zero."""
         if self.fp32:
             return p.detach().reshape(p.shape[0], -1).t()      # strided view: the fp32 GEMM takes any strides
         def make():
             out_f, in_f = p.shape[0], p[0].numel()
-            buf = torch.zeros(in_f, ru(out_f, 64), dtype=torch.bfloat16, device=p.device)
+            buf = torch.zeros(ru(in_f, 64) if pad_rows else in_f, ru(out_f, 64), dtype=torch.bfloat16, device=p.device)
             return Shadow(buf, (p,), [(p, buf, True)])
         return self._get_shadow(("wt", id(p)), make)
 
@@ -587,8 +588,11 @@ class FourMEngine:
         if self.gated:
             gu = self._buf(sv, tag, "gu", (Rp, 2 * self.Hp), bf) if sv is not None else None       # inference: nothing to save
             act = self._buf(sv, tag, "act", (Rp, self.Hp), bf)
-            ops.gemm_nt(h, self.w(mlp.fc1.weight), act, epilogue=L.EPI_SWIGLU, w2=self.w(mlp.fc3.weight), out2=gu, Hp=self.Hp,
-                        bias=mlp.fc1.bias, bias2=mlp.fc3.bias, M=R, N=self.Hd, K=self.D)
+            # (bias-free, bf16: the weight images carry zero rows up to Hp, so a hidden width like 4M-L's 2730 runs as 2752 on the lock-step kernel;
+            # the pad columns of act / gu receive silu(0) * 0 = 0, what they hold anyway)
+            padN = not self.fp32 and mlp.fc1.bias is None and mlp.fc3.bias is None and self.Hp != self.Hd
+            ops.gemm_nt(h, self.w(mlp.fc1.weight, padN), act, epilogue=L.EPI_SWIGLU, w2=self.w(mlp.fc3.weight, padN), out2=gu, Hp=self.Hp,
+                        bias=mlp.fc1.bias, bias2=mlp.fc3.bias, M=R, N=self.Hp if padN else self.Hd, K=self.D)
         else:
             pre = self._buf(sv, tag, "pre", (Rp, self.Hp), bf) if sv is not None else None     # inference: nothing to save
             act = self._buf(sv, tag, "act", (Rp, self.Hp), bf)
@@ -882,7 +886,8 @@ class FourMEngine:
         fuse = FUSE_ACT_BWD
         if not fuse:
             da = ws.get("bwd.da", (Rp, Hp), bf)
-            ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight), da, M=R, N=Hd, K=D)
+            padN = not self.fp32 and Hp != Hd                   # zero rows up to Hp in the weight image: d(act) of the pad columns is 0
+            ops.gemm_nt(g_bf, self.wt(mlp.fc2.weight, padN), da, M=R, N=Hp if padN else Hd, K=D)
         if self.gated:
             dgu = ws.get("bwd.dgu", (Rp, 2 * Hp), bf)
             if fuse:

@@ -40,6 +40,20 @@ def init_distributed_mode(args):
     dist.init_process_group(backend=args.dist_backend, init_method=getattr(args, "dist_url", "env://"),
                             world_size=args.world_size, rank=args.rank, timeout=datetime.timedelta(minutes=80))
     dist.barrier()
+    setup_for_distributed(args.rank == 0 or bool(getattr(args, "print_all", False)))
+
+
+def setup_for_distributed(is_master: bool):
+    """print() is silent on every rank but the master (or everywhere with --print_all), ``force=True`` overrides
+    (upstream fourm/utils/dist.py setup_for_distributed: 8 ranks otherwise print args, model and every meter line 8 times)."""
+    import builtins
+    builtin_print = getattr(builtins.print, "_fourm_builtin", builtins.print)
+
+    def rank_print(*a, **kw):
+        if kw.pop("force", False) or is_master:
+            builtin_print(*a, **kw)
+    rank_print._fourm_builtin = builtin_print
+    builtins.print = rank_print
 
 
 # names only upstream's same-named module defines (see fourm/_upstream.py)

@@ -173,7 +173,9 @@ class VQVAE(VQ):
         x = self.prepare_input(x)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if needs_grad:
-            return VQVAEStep.apply(self.post_quant_proj.weight, self, x)
+            # the autograd anchor is a parameter that DOES require grad (post_quant_proj may be frozen while the encoder or decoder trains)
+            anchor = next(p for p in self.parameters() if p.requires_grad)
+            return VQVAEStep.apply(anchor, self, x)
         with torch.no_grad():
             dec, code_loss, _ = vqvae_train_forward(self, x) if self.training else (*self._eval_forward(x), None)
         return dec, code_loss

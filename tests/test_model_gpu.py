@@ -111,7 +111,8 @@ def test_loss_and_gradients(name):
 #   micro_swiglu                    7.2e-3               7.6e-3        7.6e-3
 #   ti_mod7  (4M-Ti, 6+6)           5.6e-3               7.4e-3        7.5e-3
 #   b_mod7   (4M-B, 12+12, benched) 5.9e-3               9.7e-3        9.6e-3
-LOGIT_BOUNDS = {"micro_swiglu": (1.4e-2, 1.5e-2), "ti_mod7": (1.1e-2, 1.5e-2), "b_mod7": (1.2e-2, 1.9e-2), "l_mod21": (3e-2, 3e-2)}
+LOGIT_BOUNDS = {"micro_swiglu": (1.4e-2, 1.5e-2), "ti_mod7": (1.1e-2, 1.5e-2), "b_mod7": (1.2e-2, 1.9e-2), "l_mod21": (1.2e-2, 1.9e-2)}
+#   l_mod21  (4M-L, 24+24)          5.9e-3               9.6e-3        9.6e-3      (r03; r04 with the context-norm hoist: see profiles/r04_parity.jsonl)
 
 
 @pytest.mark.parametrize("name", ["micro_swiglu", "ti_mod7", "b_mod7", "l_mod21"])
@@ -472,7 +473,9 @@ def test_activation_checkpointing(name):
     assert set(res[True][1]) == set(res[False][1])
     for n, gr in res[False][1].items():
         assert rel(res[True][1][n], gr) < 2e-5 or float(gr.norm()) < 1e-9, (n, rel(res[True][1][n], gr))
-    assert res[True][2] < 0.8 * res[False][2], (res[True][2], res[False][2])
+    # (r04: the context-norm hoist took the per-layer normalised context copies out of the plain workspace and added the all-layer d(kv)
+    # buffer to both: 0.81 on the 2 + 2 block micro model, where the embeddings dominate)
+    assert res[True][2] < 0.85 * res[False][2], (res[True][2], res[False][2])
     record("model.activation_checkpointing", case=name, workspace_bytes=res[False][2], workspace_bytes_checkpointed=res[True][2])
 
 

@@ -1,0 +1,72 @@
+"""get_image_tokenizer follows upstream's loader (fourm/vq/__init__.py:8-79): renamed arguments, n_labels / n_channels read off the
+checkpoint, domain-specific switches, encoder_only filtering - host logic only (models are built and loaded on the CPU; no kernel runs)."""
+import argparse
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ml-4m_amd"))
+
+
+def _save(tmp_path, name, model, **args):
+    torch.save({"model": model.state_dict(), "args": argparse.Namespace(**args)}, tmp_path / f"{name}.pth")
+
+
+BASE = dict(encoder_type="vit_s_enc", decoder_type="vit_s_dec", quantizer_type="lucid", patch_size=8, codebook_size=64, latent_dim=8,
+            num_codebooks=1, norm_codes=True, norm_latents=False, post_mlp=True, quantizer_ema_decay=0.97, lr=1e-4, batch_size=32)
+
+
+def test_rgb_vqvae_and_encoder_only(tmp_path):
+    from fourm.vq import VQ, VQVAE, get_image_tokenizer
+    m = VQVAE(image_size=32, n_channels=3, enc_type="vit_s_enc", dec_type="vit_s_dec", patch_size=8, codebook_size=64, latent_dim=8, post_mlp=True)
+    _save(tmp_path, "rgb", m, domain="rgb", input_size=32, **BASE)
+    full, a = get_image_tokenizer("rgb", str(tmp_path), device="cpu", verbose=False)
+    assert isinstance(full, VQVAE) and a.model_type == "VQVAE" and a.image_size == 32 and a.n_channels == 3 and a.sync_codebook is False
+    assert full.quantize.decay == 0.97 if hasattr(full.quantize, "decay") else True
+    for k, v in m.state_dict().items():
+        assert torch.equal(full.state_dict()[k], v), k
+    enc, _ = get_image_tokenizer("rgb", str(tmp_path), encoder_only=True, device="cpu", verbose=False)
+    assert type(enc) is VQ and not any("decoder" in k or "post_quant_proj" in k for k in enc.state_dict())
+    assert get_image_tokenizer("absent", str(tmp_path), return_None_on_fail=True) is None
+
+
+def test_semseg_checkpoint_keeps_cls_emb(tmp_path):
+    """n_labels / n_channels come from cls_emb.weight and the table itself is loaded (upstream :49-50)."""
+    from fourm.vq import VQVAE, get_image_tokenizer
+    m = VQVAE(image_size=32, n_channels=16, n_labels=11, enc_type="vit_s_enc", dec_type="vit_s_dec", patch_size=8, codebook_size=64, latent_dim=8, post_mlp=True)
+    _save(tmp_path, "semseg", m, domain="semseg_coco", input_size=32, **BASE)        # (the run's args carry neither n_labels nor n_channels)
+    t, a = get_image_tokenizer("semseg", str(tmp_path), device="cpu", verbose=False)
+    assert (a.n_labels, a.n_channels) == (11, 16) and t.cls_emb is not None
+    assert torch.equal(t.cls_emb.weight, m.cls_emb.weight)
+    assert t.decoder.out_channels == 11 if hasattr(t.decoder, "out_channels") else True
+
+
+def test_feature_map_and_sam_domains(tmp_path):
+    """CLIP / DINO / ImageBind domains: no patch projection (:36-37); sam: every input size becomes mask_size (:38-41)."""
+    from fourm.vq import VQVAE, get_image_tokenizer
+    m = VQVAE(image_size=14, n_channels=24, enc_type="vit_s_enc", dec_type="vit_s_dec", patch_size=1, patch_proj=False, codebook_size=64, latent_dim=8, post_mlp=True)
+    args = dict(BASE, patch_size=1)
+    _save(tmp_path, "clip", m, domain="CLIP-B16", input_size=14, patch_proj=True, **args)       # (stale patch_proj in the args: the loader overrides it)
+    t, a = get_image_tokenizer("clip", str(tmp_path), device="cpu", verbose=False)
+    assert a.patch_proj is False and a.n_channels == 24 and t.patch_proj is False
+    m2 = VQVAE(image_size=16, n_channels=1, enc_type="vit_s_enc", dec_type="vit_s_dec", patch_size=8, codebook_size=64, latent_dim=8, post_mlp=True)
+    _save(tmp_path, "sam", m2, domain="sam_mask", mask_size=16, input_size_min=224, input_size_max=512, **BASE)
+    t2, a2 = get_image_tokenizer("sam", str(tmp_path), device="cpu", verbose=False)
+    assert a2.image_size == 16 and a2.input_size == 16 and t2.image_size == 16
+
+
+def test_missing_weights_and_diffusion_decoders_are_refused(tmp_path):
+    from fourm.vq import VQVAE, get_image_tokenizer
+    m = VQVAE(image_size=32, n_channels=3, enc_type="vit_s_enc", dec_type="vit_s_dec", patch_size=8, codebook_size=64, latent_dim=8, post_mlp=True)
+    sd = {k: v for k, v in m.state_dict().items() if not k.startswith("quant_proj.")}
+    torch.save({"model": sd, "args": argparse.Namespace(domain="rgb", input_size=32, **BASE)}, tmp_path / "holes.pth")
+    with pytest.raises(RuntimeError, match="lacks"):
+        get_image_tokenizer("holes", str(tmp_path), device="cpu", verbose=False)
+    _save(tmp_path, "divae", m, domain="rgb", input_size=32, beta_schedule="linear", **BASE)
+    with pytest.raises(NotImplementedError, match="DiVAE"):
+        get_image_tokenizer("divae", str(tmp_path), device="cpu", verbose=False)
+    enc, _ = get_image_tokenizer("divae", str(tmp_path), encoder_only=True, device="cpu", verbose=False)       # the encoder half still loads
+    assert enc is not None

@@ -109,6 +109,38 @@ int main(int argc, char** argv) {
         printf("sum over a 4M-B step (ms):");
         for (size_t k = 0; k < cfgs.size(); ++k) printf("  c%d: %.2f", cfgs[k], tot[k] / 1e3);
         printf("\n");
+    } else if (mode == "ldpad") {
+        // Do the row strides of the operands / outputs matter (L2 channel or DRAM bank conflicts)?  The same shapes with leading
+        // dimensions K + pad (X, W) and N + pad (out): tools/bin/gemm_lab ldpad <cfg> <pad,pad,...>  (pad in elements, multiples of 64)
+        const int cfg = argc > 2 ? atoi(argv[2]) : 1003;
+        std::vector<int> pads = {0, 64, 128, 192};
+        if (argc > 3) { pads.clear(); char* t = strtok(argv[3], ","); while (t) { pads.push_back(atoi(t)); t = strtok(nullptr, ","); } }
+        NTCase cases[] = {{"qkv      N2304 K768 ", 2304, 768, FM_EPI_BF16}, {"proj/dX  N768  K768 ", 768, 768, FM_EPI_BF16},
+                          {"dX fc2   N2048 K768 ", 2048, 768, FM_EPI_BF16}, {"dX fc13  N768  K4096", 768, 4096, FM_EPI_BF16},
+                          {"dX qkv   N768  K2304", 768, 2304, FM_EPI_BF16}, {"swiglu   N2x2048 K768", 2048, 768, FM_EPI_SWIGLU}};
+        set_cfg(cfg);
+        for (auto& c : cases) {
+            printf("%s |", c.name);
+            for (int variant = 0; variant < 3; ++variant) {      // 0: pad X, W and out; 1: pad X and W only; 2: pad out only
+                for (int pad : pads) {
+                    if (variant && pad == 0) continue;
+                    const int pin = variant == 2 ? 0 : pad, pout = variant == 1 ? 0 : pad;
+                    const int ldk = c.K + pin, ldn = c.N + pout;
+                    void* W = dev_rand_bf16((size_t)c.N * ldk, 1), *W2 = dev_rand_bf16((size_t)c.N * ldk, 2), *X = dev_rand_bf16((size_t)R * ldk, 3);
+                    void* out = dev_zero((size_t)R * ldn * 2);
+                    void* out2 = c.epi == FM_EPI_SWIGLU ? dev_zero((size_t)R * (2 * c.N + pout) * 2) : nullptr;
+                    fm_gemm_nt_args a{};
+                    a.W = W; a.W2 = c.epi == FM_EPI_SWIGLU ? W2 : nullptr; a.X = X; a.out = out; a.out2 = out2;
+                    a.M = R; a.N = c.N; a.K = c.K; a.ldw = ldk; a.ldx = ldk; a.ldo = ldn; a.ldo2 = 2 * c.N + pout; a.Hp = c.N; a.epilogue = c.epi;
+                    if (fm_gemm_nt(&a, 0) != 0) { printf(" %s", fm_last_error()); continue; }
+                    double best = 1e30;
+                    for (int rep = 0; rep < 3; ++rep) { double us = time_us([&] { fm_gemm_nt(&a, 0); }, 20, 2); if (us < best) best = us; }
+                    printf("  %s+%d: %6.1f us", variant == 0 ? "all" : variant == 1 ? "in" : "out", pad, best);
+                    CK(hipFree(W)); CK(hipFree(W2)); CK(hipFree(X)); CK(hipFree(out)); if (out2) CK(hipFree(out2));
+                }
+            }
+            printf("\n"); fflush(stdout);
+        }
     } else if (mode == "dephase") {
         // staggered workgroup start (fm_lab_set 0/1): the store epilogue of one workgroup under the main loop of another
         std::vector<int> cfgs = {266, 267, 268};
