@@ -162,7 +162,16 @@ def pmc_traffic(kernel_regex, timeout_s=240, worker_args=()):
                     "launches_counted": n_launch["FETCH_SIZE"], "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 B, separate --pmc passes"}
 
 
-REFERENCE_TREE = "/root/reference"
+def _reference_tree():
+    """The unmodified upstream checkout the CPU baseline times when one is reachable: FOURM_UPSTREAM (the variable the package's own
+    fall-through uses, fourm/_upstream.py) if it names a tree with fourm/models/fm.py, else /root/reference (the build container)."""
+    for c in (os.environ.get("FOURM_UPSTREAM"), "/root/reference"):
+        if c and os.path.isfile(os.path.join(c, "fourm", "models", "fm.py")):
+            return os.path.abspath(c)
+    return "/root/reference"
+
+
+REFERENCE_TREE = _reference_tree()
 
 
 def cpu_baseline(timeout_s=300, workload="train"):
@@ -499,6 +508,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.dist_backend == "nccl":
+            from fourm.parallel import cap_collective_channels
+            cap_collective_channels()          # before the communicator exists: RCCL's workgroups fit the CUs DataParallel keeps free
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
@@ -586,6 +597,10 @@ def main():
         "mfu": flops_step * a.steps / dt / (BF16_PEAK_TFLOPS * 1e12),
         "algorithmic_tflop_per_step_per_gpu": flops_step / 1e12, "final_loss": last_loss,
     }
+    if dp is not None:         # how the gradients travelled (fourm.parallel.DataParallel): nothing here changes the work counted in `value`
+        out["config"]["data_parallel"] = {"exchange": dp._exchange_mode, "reserved_cus": dp._reserved_cus, "min_launch_mb": dp._min_launch_mb
+                                          if dp._min_launch_mb != float("inf") else None, "wire_dtype": "bf16" if dp._wire is not None else "fp32",
+                                          "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS")}
     if masking_ms is not None:
         out["data"] = "synthetic modalities masked on the device (Dirichlet token budgets, image masks, span masking)"
         out["masking_ms_per_batch"] = masking_ms          # the producer, outside the timed region (batches are resident when it starts)

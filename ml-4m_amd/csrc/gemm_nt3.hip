@@ -563,10 +563,16 @@ int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     if ((size_t)256 * (size_t)a.ldo * 4 >= 0x7fffffffull || (size_t)256 * (size_t)a.ldx * 2 >= 0x7fffffffull || (size_t)256 * (size_t)a.ldw * 2 >= 0x7fffffffull) return 0;
     const bool al16 = (((uintptr_t)a.out | (uintptr_t)a.out2 | (uintptr_t)a.res) & 15) == 0;
     if (!al16) return 0;
-    // 192-wide tiles where they tile N exactly and 256-wide ones do not fill whole rounds (N = 768, 2304 at 32768 rows)
-    const long t256 = (long)((a.N + 255) / 256) * ((a.M + 255) / 256);
+    // Tile width by cost: a persistent workgroup per CU walks ceil(tiles / CUs) tiles, each costing ~ its width, so the launch costs
+    // rounds x width; 192-wide tiles only where they tile N exactly.  On all 256 CUs this picks 192 for N = 768 / 2304 (512 / 1536 tiles =
+    // 2 / 6 whole rounds; 256-wide: 384 / 1152 tiles = 1.5 / 4.5) and 256 elsewhere, as the fixed rule of round 3 did; with CUs reserved for
+    // RCCL (fm_set_reserved_cus: 248 CUs) it moves N = 768 / 2304 to 256-wide tiles (2 / 5 rounds instead of 3 / 7 of the 192-wide ones).
+    const int cus = fm_grid_cus();
+    const long xt = (a.M + 255) / 256;
+    const long t256 = (long)((a.N + 255) / 256) * xt, t192 = (long)((a.N + 191) / 192) * xt;
     const bool fits192 = a.N % 192 == 0;
-    const bool use192 = mode == 2 ? fits192 : mode == 3 ? (fits192 && (a.N % 256 != 0 || t256 % 256 != 0)) : false;
+    const long c256 = (t256 + cus - 1) / cus * 256, c192 = (t192 + cus - 1) / cus * 192;
+    const bool use192 = mode == 2 ? fits192 : mode == 3 ? (fits192 && c192 < c256) : false;
     if (epilogue == FM_EPI_BF16) {
         if (a.ldo % 8 != 0) return 0;
         if (!(a.lab & 1024) && !(a.lab & 16) && a.ldo % 64 == 0 && (((uintptr_t)a.out) & 127) == 0)      // staged epilogue (whole-line stores); lab bit 1024: legacy

@@ -279,7 +279,30 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(fm_embed_bwd_desc d) {
     __shared__ int used[FM_MAX_MODS + 1];
     if (threadIdx.x <= FM_MAX_MODS) used[threadIdx.x] = 0;
     __syncthreads();
-    for (int s = wave + 4 * blockIdx.y; s < d.Nt; s += 4 * gridDim.y) {       // gridDim.y workgroups share a sample's slots
+    // Kept slots keep the concatenation order, so a sample's slots are grouped by modality: every wave walks a CONTIGUOUS run of slots and
+    // carries the column sums of the current modality in registers (round 4; one LDS atomic per column and slot before: ds_add_f32
+    // serialises - 250 us per launch at 0.4 TB/s); they reach LDS once per (wave, modality run).
+    constexpr int MAXQ = 8;                                      // float4 chunks per lane: D <= 2048
+    const int parts = 4 * gridDim.y, part = wave + 4 * blockIdx.y;
+    const int per = (d.Nt + parts - 1) / parts, s_lo = part * per, s_hi = min(d.Nt, s_lo + per);
+    float4 racc[MAXQ];
+    int cur = -1;
+    bool cur_mask = false;
+    auto flush = [&]() {
+        if (cur < 0) return;
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int c = lane + 64 * q;
+            if (c >= nch) break;
+            float* a0 = acc + (size_t)cur * D + c * 4;
+            atomicAdd(a0, racc[q].x); atomicAdd(a0 + 1, racc[q].y); atomicAdd(a0 + 2, racc[q].z); atomicAdd(a0 + 3, racc[q].w);
+            if (cur_mask) {
+                float* a1 = acc + (size_t)d.n_mods * D + c * 4;
+                atomicAdd(a1, racc[q].x); atomicAdd(a1 + 1, racc[q].y); atomicAdd(a1 + 2, racc[q].z); atomicAdd(a1 + 3, racc[q].w);
+            }
+        }
+    };
+    for (int s = s_lo; s < s_hi; ++s) {
         const size_t row = (size_t)b * d.Nt + s;
         const int m = ((const int32_t*)d.slot_mod)[row];
         if (m == -1) continue;                                   // masked slot: both inputs were zeroed
@@ -292,22 +315,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(fm_embed_bwd_desc d) {
         const fm_embed_bwd_mod& md = d.mods[m];
         const int src = ((const int32_t*)d.slot_src)[row];
         const int posrow = ((const int32_t*)d.slot_pos)[row];
-        if (lane == 0) used[m] = 1;
+        const bool to_mask_token = d.is_decoder && md.kind == FM_KIND_TOK;
+        if (m != cur) {
+            flush();
+            cur = m; cur_mask = to_mask_token;
+#pragma unroll
+            for (int q = 0; q < MAXQ; ++q) racc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane == 0) { used[m] = 1; if (to_mask_token) used[d.n_mods] = 1; }
+        }
         float* trow = nullptr;
-        bool to_mask_token = false;
-        if (d.is_decoder && md.kind == FM_KIND_TOK) { to_mask_token = true; if (lane == 0) used[d.n_mods] = 1; }
+        if (to_mask_token) {}
         else if ((md.kind == FM_KIND_TOK || md.kind == FM_KIND_SEQ) && md.d_table && !(md.has_padding_idx && src == md.padding_idx))
             trow = (float*)md.d_table + (size_t)src * D;
         else if (md.kind == FM_KIND_SEQ_EMB && md.d_proj_bias) trow = (float*)md.d_proj_bias;
         float* prow = md.d_pos ? (float*)md.d_pos + (size_t)posrow * D : nullptr;
-        for (int c = lane; c < nch; c += 64) {
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) {
+            const int c = lane + 64 * q;
+            if (c >= nch) break;
             const float4 v = *(const float4*)(g + c * 4);
-            float* a0 = acc + (size_t)m * D + c * 4;
-            atomicAdd(a0, v.x); atomicAdd(a0 + 1, v.y); atomicAdd(a0 + 2, v.z); atomicAdd(a0 + 3, v.w);
-            if (to_mask_token) {
-                float* a1 = acc + (size_t)d.n_mods * D + c * 4;
-                atomicAdd(a1, v.x); atomicAdd(a1 + 1, v.y); atomicAdd(a1 + 2, v.z); atomicAdd(a1 + 3, v.w);
-            }
+            racc[q].x += v.x; racc[q].y += v.y; racc[q].z += v.z; racc[q].w += v.w;
             if (trow) {
                 unsafeAtomicAdd(trow + c * 4, v.x); unsafeAtomicAdd(trow + c * 4 + 1, v.y);
                 unsafeAtomicAdd(trow + c * 4 + 2, v.z); unsafeAtomicAdd(trow + c * 4 + 3, v.w);
@@ -318,6 +345,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(fm_embed_bwd_desc d) {
             }
         }
     }
+    flush();
     __syncthreads();
     for (int m = 0; m < d.n_mods; ++m) {
         if (!used[m] || !d.mods[m].d_mod_emb) continue;
@@ -379,7 +407,7 @@ extern "C" int fm_select_embed(const fm_select_desc* d, void* stream) {
 
 extern "C" int fm_embed_bwd(const fm_embed_bwd_desc* d, void* stream) {
     FM_CHECK_ARG(d && d->dx && d->slot_mod && d->slot_src && d->slot_pos, "fm_embed_bwd: null pointer");
-    FM_CHECK_ARG(d->n_mods > 0 && d->n_mods <= FM_MAX_MODS && d->dim % 4 == 0 && d->lddx % 4 == 0, "fm_embed_bwd: bad shape");
+    FM_CHECK_ARG(d->n_mods > 0 && d->n_mods <= FM_MAX_MODS && d->dim % 4 == 0 && d->dim <= 2048 && d->lddx % 4 == 0, "fm_embed_bwd: bad shape (dim <= 2048)");
     const size_t lds = (size_t)(d->n_mods + 1) * d->dim * sizeof(float);
     FM_CHECK_ARG(lds <= 150 * 1024, "fm_embed_bwd: %zu bytes of LDS needed", lds);
     static bool once = (hipFuncSetAttribute((const void*)embed_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess);

@@ -55,7 +55,7 @@ class GradReducer:
         self._pending = []
         self._done = set()
         self._waiting = []
-        self.min_launch_elems = int(min_launch_mb * 1024 * 1024 // 4)
+        self.min_launch_elems = (1 << 62) if min_launch_mb == float("inf") else int(min_launch_mb * 1024 * 1024 // 4)
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"          # RCCL averages in the collective; gloo has no AVG
         self._wire_bufs = {}                   # (offset, length) -> bf16 staging buffer, allocated once
@@ -139,6 +139,23 @@ class GradReducer:
         self._pending = []
 
 
+# Compute units the persistent GEMM grids leave to the collectives in "overlap" mode: 16 = two per XCD.  Measured on one MI355X
+# (profiles/r04_reserved_cus.txt): 61.4 ms per 4M-B step on 256 CUs, 62.5 on 240, 62.7 on 248 (the tile-width choice of the NT GEMM and the
+# cut of the weight-gradient lists follow the grid).  ``cap_collective_channels`` bounds RCCL to as many channels (= resident workgroups).
+DEFAULT_RESERVED_CUS = 16
+
+
+def cap_collective_channels(n: Optional[int] = None):
+    """Call BEFORE the process group's first collective (RCCL reads it when the communicator is created): at most ``n`` channels, so that a
+    collective's workgroups fit the CUs DataParallel reserves.  4M-B needs ~2.5 GB over each GPU's links per ~45 ms of backward = 56 GB/s:
+    a fraction of what 16 channels move.  An explicit NCCL_MAX_NCHANNELS in the environment wins."""
+    import os
+    if n is None:
+        n = int(os.environ.get("FOURM_DP_RESERVED_CUS", str(DEFAULT_RESERVED_CUS)))
+    if n > 0 and os.environ.get("FOURM_DP_EXCHANGE", "overlap").lower() == "overlap":
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+
+
 class DataParallel(nn.Module):
     """Drop-in for the way the trainer uses DDP: callable like the module, ``.module``, ``.no_sync()``,
     ``.parameters()``, ``.train()/.eval()`` (run_training_4m.py:512-513, :721, :736).
@@ -148,12 +165,21 @@ class DataParallel(nn.Module):
 
     def __init__(self, module: nn.Module, device_ids=None, find_unused_parameters: bool = False, process_group=None,
                  bucket_mb: int = 256, algorithm: str = "all_reduce", wire_dtype=None, reserved_cus: Optional[int] = None,
-                 force_collectives: bool = False, min_launch_mb: Optional[float] = None):
-        """``reserved_cus``: compute units the persistent GEMM grids leave to RCCL while gradients are exchanged under the backward
-        (env FOURM_DP_RESERVED_CUS).  Default 0: a persistent GEMM workgroup uses 512 of a CU's 2048 thread slots, <= 144 of 160 KB
-        of LDS and ~400 of 512 VGPRs per SIMD, so RCCL's small workgroups can be co-resident on the same CUs; reserving whole CUs
-        breaks the tile quantisation of the 4M-B shapes (768 tiles on 256 CUs = 3 rounds, on 248 CUs = 4): measured +5.5 % step
-        time at 8 reserved CUs, +6.4 % at 16 on one GPU (profiles/r02_reserved_cus.txt)."""
+                 force_collectives: bool = False, min_launch_mb: Optional[float] = None, exchange: Optional[str] = None):
+        """``exchange`` (env FOURM_DP_EXCHANGE): "overlap" (default) - a stage's gradient slices are exchanged while the next stage computes;
+        "tail" - nothing is exchanged under the backward, the whole gradient store goes out in bucket-sized collectives when the backward
+        has finished (4M-B: 1.44 GB fp32; a ring all-reduce moves 2 (N - 1) / N of it over each GPU's links).
+
+        ``reserved_cus`` (env FOURM_DP_RESERVED_CUS; only meaningful with "overlap"): compute units the persistent GEMM grids leave free
+        while gradients are exchanged.  What can share a CU is a question of registers and LDS (profiles/r04_kernel_resources.txt,
+        tools/kernel_resources.py): a workgroup of the dense NT GEMM (gemm_nt3: 201 - 256 VGPRs x 2 waves per SIMD, 160 KB of LDS with its
+        staged epilogue) or of the weight-gradient GEMM (gemm_tn_multi: 256 VGPRs x 2, 96 KB) owns its CU outright - nothing of another
+        stream can be co-resident with it (round 3's docstring said otherwise; it was wrong).  A collective's workgroups are long-lived
+        (one per channel for the whole message), so while a collective is resident every persistent GEMM grid of 256 workgroups finds some
+        CUs taken and runs those workgroups in a second round: reserved_cus >= the collective's channel count (bound it with
+        NCCL_MAX_NCHANNELS) keeps the grids and the collective on disjoint CUs.  The price on one GPU is what the tilings lose on 248 CUs
+        (profiles/r04_reserved_cus.txt); the streaming kernels (LayerNorm, activation backward, AdamW: <= 152 VGPRs, no LDS) share CUs
+        freely.  No N > 1 hardware was available to choose between "overlap" + reservation and "tail": both are one environment variable."""
         super().__init__()
         import os
         self.module = module
@@ -161,11 +187,16 @@ class DataParallel(nn.Module):
         self._sync = True
         self._bucket_elems = bucket_mb * 1024 * 1024 // 4
         self._algorithm, self._wire, self._force = algorithm, wire_dtype, force_collectives
+        self._exchange_mode = (exchange or os.environ.get("FOURM_DP_EXCHANGE", "overlap")).lower()
+        if self._exchange_mode not in ("overlap", "tail"):
+            raise ValueError(f"exchange {self._exchange_mode!r}: 'overlap' or 'tail'")
         # launch a collective only when this much gradient is waiting (env FOURM_DP_MIN_LAUNCH_MB; default 192 MB: ~8 per 4M-B step)
         self._min_launch_mb = float(os.environ.get("FOURM_DP_MIN_LAUNCH_MB", "192")) if min_launch_mb is None else float(min_launch_mb)
+        if self._exchange_mode == "tail":
+            self._min_launch_mb = float("inf")           # everything waits for GradReducer.finish()
         if reserved_cus is None:
-            reserved_cus = int(os.environ.get("FOURM_DP_RESERVED_CUS", "0"))
-        self._reserved_cus = reserved_cus
+            reserved_cus = int(os.environ.get("FOURM_DP_RESERVED_CUS", str(DEFAULT_RESERVED_CUS)))
+        self._reserved_cus = 0 if self._exchange_mode == "tail" else reserved_cus
         self._reducer: Optional[GradReducer] = None
         self._reducer_for = None
         if dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force_collectives):

@@ -37,6 +37,9 @@ def init_distributed_mode(args):
         torch.cuda.set_device(args.gpu)
     args.dist_backend = "nccl" if use_gpu else "gloo"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if use_gpu:
+        from fourm.parallel import cap_collective_channels
+        cap_collective_channels()             # RCCL's workgroups fit the CUs fourm.parallel.DataParallel keeps free of GEMM grids
     dist.init_process_group(backend=args.dist_backend, init_method=getattr(args, "dist_url", "env://"),
                             world_size=args.world_size, rank=args.rank, timeout=datetime.timedelta(minutes=80))
     dist.barrier()

@@ -298,6 +298,48 @@ def test_fused_adamw_step_matches_torch():
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 2.0
 
 
+def test_trainer_step_trajectory_b_mod7():
+    """The trainer's update - NativeScalerWithGradNormCount(loss, FusedAdamW, clip_grad=...) as run_training_4m.py:727-733 calls it - against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over THREE steps of 4M-B with a changing learning rate: the weight trajectory, not
+    only the first step.  The torch side receives the HIP gradients of every step (copied between the backward and the update: the
+    fp32 atomics of the weight-gradient GEMMs are not bit-reproducible, and Adam turns a sign flip of a noise-level gradient into a full
+    +-lr step), so the two trajectories can only separate through the clip / AdamW arithmetic itself."""
+    from fourm.utils.native_scaler import NativeScalerWithGradNormCount
+    from fourm.utils.optim_factory import FusedAdamW
+    g, case, model = setup("b_mod7")
+    md = to_device(case["mod_dict"])
+    ref = {n: p.detach().clone().requires_grad_(True) for n, p in model.named_parameters()}
+    groups = lambda named: [{"params": [p for n, p in named if p.dim() > 1], "weight_decay": 0.05},
+                            {"params": [p for n, p in named if p.dim() <= 1], "weight_decay": 0.0}]
+    opt = FusedAdamW(groups(list(model.named_parameters())), lr=1e-3, betas=(0.9, 0.95))
+    ropt = torch.optim.AdamW(groups(list(ref.items())), lr=1e-3, betas=(0.9, 0.95))
+    fused_norm = opt.fused_grad_norm
+
+    def norm_and_hand_over(clip=None):              # called by the scaler between backward and step: the same gradients go to the torch side
+        for n, p in model.named_parameters():
+            ref[n].grad = None if p.grad is None else p.grad.clone()
+        return fused_norm(clip=clip)
+    opt.fused_grad_norm = norm_and_hand_over
+    scaler = NativeScalerWithGradNormCount(enabled=False)
+    clip = 0.5                                   # below the gradient norm of the seeded model: the clip is active on every step
+    norms, losses = [], []
+    for step, lr in enumerate((1e-3, 7e-4, 3e-4)):
+        for o in (opt, ropt):
+            for gr in o.param_groups:
+                gr["lr"] = lr
+        random.seed(step); loss, _ = model(md, case["N"], case["M"])
+        norm = scaler(loss, opt, clip_grad=clip, parameters=model.parameters())
+        opt.zero_grad()
+        rnorm = torch.nn.utils.clip_grad_norm_([p for p in ref.values() if p.grad is not None], clip)
+        ropt.step(); ropt.zero_grad()
+        norms.append((float(norm), float(rnorm))); losses.append(float(loss))
+        assert abs(float(norm) - float(rnorm)) < 1e-4 * float(rnorm) and float(rnorm) > clip, norms
+    worst = max((float((p - ref[n]).abs().max()), n) for n, p in model.named_parameters())
+    moved = max(float((p.detach().cpu() - case["sd"][n]).abs().max()) for n, p in model.named_parameters() if n in case["sd"])
+    record("model.trainer_trajectory", case="b_mod7", steps=3, worst_abs_diff=worst[0], worst_name=worst[1], largest_move=moved, norms=norms, losses=losses)
+    assert moved > 1e-3 and worst[0] < 5e-6 and losses[2] < losses[0], (worst, moved, losses)
+
+
 def test_fused_adamw_rewrites_weight_shadows():
     """FusedAdamW.step() updates the weight matrices and rewrites their plain bf16 GEMM-operand copies in the same streaming
     kernel (fm_adamw_shadow): after a step those shadows are marked current AND equal the cast of their fp32 master; the

@@ -18,18 +18,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, stages, bucket, out_dir):
+def _worker(rank, world, port, n, stages, bucket, out_dir, min_launch_mb=0.0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from fourm.parallel import GradReducer
     flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
-    red = GradReducer(flat, stages, bucket_elems=bucket)
+    red = GradReducer(flat, stages, bucket_elems=bucket, min_launch_mb=min_launch_mb)
     for window in range(2):                      # two optimizer steps reuse the reducer
         if window:
             flat.copy_(torch.arange(n, dtype=torch.float32) * (rank + 1) + window)
         red.begin()
         for s in ["b", "a"]:                     # backward order; "c" is left to finish()
             red.stage_done(s)
+            if min_launch_mb == float("inf"):    # "tail" exchange: nothing leaves before finish()
+                assert not red._pending
         red.finish()
         torch.save(flat.clone(), os.path.join(out_dir, f"r{rank}_w{window}.pt"))
     dist.destroy_process_group()
@@ -47,6 +49,17 @@ def test_grad_reducer_mean_gloo(tmp_path):
             assert torch.allclose(got[:950], mean[:950]), (window, rank)
             own = base * (rank + 1) + (window if window else 0)
             assert torch.equal(got[950:], own[950:])          # untouched outside every stage
+
+
+def test_grad_reducer_tail_exchange_gloo(tmp_path):
+    """exchange="tail" (DataParallel) = an infinite launch threshold: every slice goes out in finish(), same means."""
+    n, world = 1000, 2
+    stages = {"a": [(0, 100), (100, 200)], "b": [(300, 500)], "c": [(800, 150)]}
+    mp.spawn(_worker, args=(world, _free_port(), n, stages, 128, str(tmp_path), float("inf")), nprocs=world, join=True)
+    base = torch.arange(n, dtype=torch.float32)
+    for rank in range(world):
+        assert torch.allclose(torch.load(tmp_path / f"r{rank}_w0.pt")[:950], (base * 1.5)[:950])
+        assert torch.allclose(torch.load(tmp_path / f"r{rank}_w1.pt")[:950], (base * 1.5 + 1)[:950])
 
 
 def test_reducer_rejects_overlapping_stages():
