@@ -4,7 +4,8 @@
     python tools/kernel_resources.py [file.hip ...] > profiles/rNN_kernel_resources.txt
 
 Compiles the device side of each csrc/*.hip with -Rpass-analysis=kernel-resource-usage and prints one line per kernel:
-VGPRs, AGPRs, SGPRs, waves per SIMD the allocation allows, LDS bytes per workgroup, scratch.  The allocation granule is 8
+VGPRs, AGPRs, SGPRs, waves per SIMD the allocation allows, STATIC LDS bytes per workgroup (the GEMM / attention kernels size their
+LDS dynamically at launch: 160 KB for gemm_nt3 with its staged epilogue, 96 KB for gemm_tn_multi, 36 - 68 KB for attention), scratch.  The allocation granule is 8
 registers per lane and waves/SIMD = min(8, 512 // alloc) (MI355X_MICROARCH.md, register files): a second kernel can share a
 CU with a resident workgroup only inside what these numbers leave (512 registers per lane and SIMD, 160 KB of LDS, 32 waves)."""
 import os
@@ -39,10 +40,11 @@ def main():
         print(f"== {os.path.basename(f)}")
         rows = []
         for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
-            name = b.split("\n")[0].strip()
+            name = b.split("\n")[0].strip().split(" ")[0]
             dn = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
             dn = re.sub(r"\(anonymous namespace\)::", "", dn)
-            dn = re.sub(r"\((fmk::|unsigned|float|int|void|fm_|NTArgs|TNArgs|AttnArgs|TNMultiArgs|SelArgs).*$", "", dn)
+            dn = re.sub(r"\((fmk::|unsigned|float|int|void|fm_|NTArgs|TNArgs|AttnArgs|TNMultiArgs|SelArgs|FoldArgs|fm_).*$", "", dn)
+            dn = dn.replace("void ", "")
             vals = {}
             for k, pat in KEYS:
                 m = re.search(pat + r": (\S+)", b)
