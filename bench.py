@@ -617,9 +617,9 @@ def main():
     if rank == 0 and not a.no_kernel_profile:
         agg = prof.summary()
         tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
-        symbol = {"gemm_nt": "FAMILY of two template instantiations, gemm_nt3_kernel<TW=192|256, EPI={epi}, SPLIT=true>  (csrc/gemm_nt3.hip: lock-step "
-                             "256 x 256 / 192 x 256 tiles; 192-wide where N % 192 == 0 and 256-wide tiles would not fill whole rounds of 256 CUs) - every "
-                             "dense bf16 Linear of the trunk, forward and dX",
+        symbol = {"gemm_nt": "FAMILY of two template instantiations, gemm_nt3_kernel<TW=192|256, EPI={epi}, SPLIT=true, STG=true>  (csrc/gemm_nt3.hip: lock-step "
+                             "256 x 256 / 192 x 256 tiles, tile width by rounds x width on the CUs in use, outputs staged through LDS into whole-line stores) - "
+                             "every dense bf16 Linear of the trunk, forward and dX",
                   "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,64,3,PP=true>  (csrc/gemm.hip)",
                   "gemm_tn_multi": "gemm_tn_multi_kernel<MASKED=false>  (csrc/gemm.hip; all dW GEMMs of a layer per launch)",
                   "attn_fwd": "attn_fwd_kernel<true,MASK>", "attn_bwd": "attn_bwd_kernel<true,MASK>",

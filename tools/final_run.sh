@@ -23,8 +23,8 @@ rm -rf gpurun_out/prof_final
 head -12 gpurun_out/final_kernel_stats.csv | cut -c1-160
 { echo "# tools/gemm_lab nt 265,268,1001,1002,1003: round-2 automatic choice (265), round-2 256x256 ping-pong (268), gemm_nt3 256-wide / 192-wide / by shape (the default)";
   timeout 200 tools/bin/gemm_lab nt 265,268,1001,1002,1003;
-  echo "# the same with experiment flags on gemm_nt3 (by shape): 1013 no wait for the DMA, 1023 no main-loop DMA, 1043 no stores, 1063 no DMA + no stores";
-  timeout 200 tools/bin/gemm_lab nt 1003,1013,1023,1043,1063 | sed "s/\[c[0-9]*: [0-9]* of [0-9]* halfwords differ from c[0-9]*\]//g";
+  echo "# the same with experiment flags on gemm_nt3 (by shape): 10243 legacy epilogue (32-byte-per-row stores), 1013 no wait for the DMA, 1023 no main-loop DMA, 1043 no stores, 1063 no DMA + no stores";
+  timeout 200 tools/bin/gemm_lab nt 1003,10243,1013,1023,1043,1063 | sed "s/\[c[0-9]*: [0-9]* of [0-9]* halfwords differ from c[0-9]*\]//g";
   echo "# T(K) at fixed M, N (operands with leading dimension 6144)";
   timeout 200 tools/bin/gemm_lab ksweep 266,1001,1002;
   echo "# all dW GEMMs of a layer: one fm_gemm_tn launch each vs ONE fm_gemm_tn_multi launch";
