@@ -147,6 +147,8 @@ class DeviceUnifiedMasking:
         self.input_tokens_range = two(input_tokens_range)
         self.target_tokens_range = two(target_tokens_range) if target_tokens_range is not None else None
         self.modality_info, self.num_modalities, self.max_tries = modality_info, len(modality_info), max_tries
+        import os as _os
+        self.check_every = int(_os.environ.get("FOURM_MASKING_CHECK_EVERY", "0"))      # batches between synchronising retry checks (0: only on .check())
         self.device = torch.device(device)
         info = list(modality_info.values())
         self.min_tokens = torch.tensor([m["min_tokens"] for m in info], dtype=torch.int32, device=self.device)
@@ -205,12 +207,14 @@ class DeviceUnifiedMasking:
         n_in = torch.randint(self.input_tokens_range[0], self.input_tokens_range[1] + 1, (B,), device=dev, generator=g, dtype=torch.int32)
         T, E = self.max_tries, M
         main, extra = self._draws(self.input_alphas[dir_idx], T, E, g)
-        in_budget, _ = token_budgets_batched(main, extra, n_in, self.min_tokens, self.max_tokens)
+        in_budget, tr = token_budgets_batched(main, extra, n_in, self.min_tokens, self.max_tokens)
+        self._note_tries(tr, T)
         tgt_budget = None
         if self.target_tokens_range is not None:
             n_tgt = torch.randint(self.target_tokens_range[0], self.target_tokens_range[1] + 1, (B,), device=dev, generator=g, dtype=torch.int32)
             main, extra = self._draws(self.target_alphas[dir_idx], T, E, g)
-            tgt_budget, _ = token_budgets_batched(main, extra, n_tgt, self.min_tokens, self.max_tokens, is_img=self.mod_is_img, input_budget=in_budget)
+            tgt_budget, tr = token_budgets_batched(main, extra, n_tgt, self.min_tokens, self.max_tokens, is_img=self.mod_is_img, input_budget=in_budget)
+            self._note_tries(tr, T)
         out = {}
         for m, (name, info) in enumerate(self.modality_info.items()):
             key = name if name in mod_dict else name.split("@")[0]                 # get_transform_key (modality_transforms.py:39-40)
@@ -234,7 +238,37 @@ class DeviceUnifiedMasking:
                                                   vocab_offset=info.get("vocab_offset", 0) if typ == "seq_token" else 0)
             else:
                 raise ValueError(f"Invalid modality type: {typ}")
+            self._note_tries(out[name]["tries"], tries)
+        self._calls = getattr(self, "_calls", 0) + 1
+        every = getattr(self, "check_every", 0)
+        if every and self._calls % every == 0:
+            self.check()
         return out
+
+    def _note_tries(self, tries: torch.Tensor, limit: int):
+        """Device-side bookkeeping of the retry counters (no host synchronisation): how many samples ran out of sentinel ids (tries == -1,
+        where upstream raises KeyError) and how many exhausted their retries (upstream's loops are unbounded and print 'More than max
+        tries')."""
+        st = getattr(self, "_tries_stat", None)
+        if st is None or st.device != tries.device:
+            st = self._tries_stat = torch.zeros(2, dtype=torch.int64, device=tries.device)
+        st[0] += (tries < 0).sum()
+        st[1] += (tries >= limit).sum()
+
+    def check(self, raise_on_overflow: bool = True):
+        """Synchronise once and report what the retry counters saw since the last check: raises on sentinel overflow (a batch with
+        invalid sentinel ids was produced), warns about exhausted retries (a sample that may exceed its budget).  Called every
+        ``check_every`` batches when that attribute is set (FOURM_MASKING_CHECK_EVERY), or by the trainer at epoch ends."""
+        st = getattr(self, "_tries_stat", None)
+        if st is None:
+            return (0, 0)
+        overflow, exhausted = (int(v) for v in st.tolist())
+        st.zero_()
+        if exhausted:
+            print(f"[DeviceUnifiedMasking] {exhausted} samples exhausted their retries (upstream: 'More than max tries')")
+        if overflow and raise_on_overflow:
+            raise KeyError(f"{overflow} samples needed more sentinel ids than the tokenizer provides (upstream raises KeyError in the masking transform)")
+        return (overflow, exhausted)
 
 
 # the host-side masking classes (UnifiedMasking, TransferMasking, ...) stay upstream's
