@@ -82,7 +82,8 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
     const int gw = a.group_w;
     const bool grouped_order = gw > 0 && total % 8 == 0 && a.n_tiles_x % 8 == 0 && a.n_tiles_w % gw == 0;
     auto tile_origin = [&](int j, int& n0, int& m0) {
-        const int tile = xcd_remap((int)blockIdx.x + j * (int)gridDim.x, total);
+        int tile = xcd_remap((int)blockIdx.x + j * (int)gridDim.x, total);
+        if (a.reverse) tile = total - 1 - tile;      // newest rows of the producer first (see NTArgs::reverse)
         int tw = tile % a.n_tiles_w, tx = tile / a.n_tiles_w;
         if (grouped_order) {
             const int per_xcd = total / 8, xr = a.n_tiles_x / 8;
@@ -548,6 +549,11 @@ int launch_nt3(NTArgs a, hipStream_t s) {
     int grid = a.n_tiles_w * a.n_tiles_x;
     const int cus = fm_grid_cus();
     if (grid > cus) grid = cus;
+    // Tiles are walked from the LAST row block to the first: the rows the producer kernel wrote last are the ones still in the Infinity
+    // Cache (a forward walk over freshly written data larger than the cache meets the oldest, evicted rows first), and this launch's own
+    // outputs are then written last-rows-first for the ascending streaming kernel behind it.  62.0 -> 61.85 ms per 4M-B step, same box
+    // (profiles/r04_ab_reverse_walk.txt); FOURM_NT3_LAB bit 2048: forward walk.
+    a.reverse = (a.lab & 2048) ? 0 : 1;
     const size_t lds = (size_t)2 * (TW + 256) * 128 + (STG ? (TW == 256 ? 32768 : 49152) : 0);
     auto k = gemm_nt3_kernel<TW, EPI, SPLIT, STG>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
