@@ -418,6 +418,20 @@ int fm_vq_code_stats(const void* z, int ldz, const int64_t* tokens, int R, int D
 /* EMA update (quantize_lucid.py:413, :421-425): cluster_size = cluster_size * decay + bins * (1 - decay);
  * embed = embed * decay + target * (1 - decay), target = l2norm(sums / bins) where bins > 0, l2norm(embed) elsewhere. */
 int fm_vq_ema_update(const void* bins, const void* sums, void* embed, void* cluster_size, int K, int D, float decay, void* stream);
+/* Euclidean codebook (EuclideanCodebook, quantize_lucid.py:181-301; VectorQuantize(use_cosine_sim=False), i.e. norm_codes=False):
+ *   fm_vq_code_bias:   bias[k] = -|embed[k]|^2 / 2;
+ *   fm_vq_assign_bias: fm_vq_assign with the score of code c starting at code_bias[c] (NULL: 0): with `codes` = embed (not normalised),
+ *       normalize_latents = 0 and that bias the arg-max is the nearest code in Euclidean distance (:272-280);
+ *   fm_vq_code_stats_raw: fm_vq_code_stats on the latents as they are (no L2 normalisation; :283-289);
+ *   fm_vq_ema_update_euclid: cluster_size and embed_avg EMAs, then embed = embed_avg / Laplace-smoothed cluster size (:286-296).
+ *       total_scratch: one DEVICE float (zeroed here). */
+int fm_vq_code_bias(const void* embed, int K, int D, void* bias, void* stream);
+int fm_vq_assign_bias(const void* z, int ldz, const void* codes, const void* code_bias, const void* embed, int K, int D, int R,
+                      int tokens_per_image, int normalize_latents, void* ws_val, void* ws_idx, int splits, int64_t* tokens,
+                      void* quant, void* stream);
+int fm_vq_code_stats_raw(const void* z, int ldz, const int64_t* tokens, int R, int D, int K, void* bins, void* sums, void* stream);
+int fm_vq_ema_update_euclid(const void* bins, const void* sums, void* embed, void* embed_avg, void* cluster_size, void* total_scratch,
+                            int K, int D, float decay, float eps, void* stream);
 
 /* Tokenizer training path (fourm/vq/vqvae.py:454-481 VQVAE, vq/models/vit_models.py:504-648 ViTDecoder,
  * vq/quantizers/quantize_lucid.py:533-541).

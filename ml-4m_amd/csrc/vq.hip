@@ -46,10 +46,13 @@ constexpr int VQ_D = 32;          // latent dimension handled by the register-re
 constexpr int VQ_CHUNK = 256;     // codes staged in LDS at a time (32 KB)
 
 // grid (ceil(R/256), splits): thread = latent row, codes [split*K/splits, ...) scanned in ascending order
+// code_bias (optional, K floats): the score of code c starts at code_bias[c] instead of 0 - with -|e_c|^2 / 2 the arg-max of
+// <z, e_c> - |e_c|^2 / 2 is the nearest code in EUCLIDEAN distance (EuclideanCodebook, quantize_lucid.py:272-278: argmax of -(|z|^2 - 2 z e + |e|^2))
 __global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ En, int K,
                                                         int R, int codes_per_split, float* __restrict__ best_val, int* __restrict__ best_idx,
-                                                        int normalize_latents) {
+                                                        int normalize_latents, const float* __restrict__ code_bias) {
     __shared__ __attribute__((aligned(16))) float code[VQ_CHUNK * VQ_D];
+    __shared__ float cbias[VQ_CHUNK];
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int rc = r < R ? r : R - 1;
     float zr[VQ_D];
@@ -72,10 +75,11 @@ __global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict_
         const int n = min(VQ_CHUNK, c_end - c0);
         __syncthreads();
         for (int i = threadIdx.x; i < n * VQ_D / 4; i += 256) *(float4*)(code + i * 4) = *(const float4*)(En + (size_t)c0 * VQ_D + i * 4);
+        if (threadIdx.x < n) cbias[threadIdx.x] = code_bias ? code_bias[c0 + threadIdx.x] : 0.f;
         __syncthreads();
         for (int c = 0; c < n; ++c) {
             const float* e = code + c * VQ_D;          // same address in every lane: LDS broadcast
-            float acc = 0.f;
+            float acc = cbias[c];
 #pragma unroll
             for (int d = 0; d < VQ_D; ++d) acc = fmaf(zr[d], e[d], acc);
             if (acc > bv) { bv = acc; bi = c0 + c; }   // strict: the first maximum wins (torch.argmax)
@@ -134,11 +138,11 @@ extern "C" int fm_l2norm_rows(const void* x, int ldx, void* y, int ldy, int R, i
 // ------------------------------------------------------------------------------------------------
 // bins[tok[r]] += 1;  sums[tok[r]][:] += l2norm(z[r])     (fp32 atomics; a wave per latent row, lane = feature)
 __global__ __launch_bounds__(256) void vq_code_stats_kernel(const float* __restrict__ z, int ldz, const long long* __restrict__ tokens, int R, int D,
-                                                            float* __restrict__ bins, float* __restrict__ sums) {
+                                                            float* __restrict__ bins, float* __restrict__ sums, int normalize) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
         const float v = lane < D ? z[(size_t)r * ldz + lane] : 0.f;
-        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);
+        const float inv = normalize ? 1.0f / fmaxf(sqrtf(wave_sum(v * v)), 1e-12f) : 1.0f;
         const long long k = tokens[r];
         if (lane < D) unsafeAtomicAdd(sums + (size_t)k * D + lane, v * inv);
         if (lane == 0) unsafeAtomicAdd(bins + k, 1.0f);
@@ -162,23 +166,55 @@ __global__ __launch_bounds__(256) void vq_ema_finalize_kernel(const float* __res
     }
 }
 
+extern "C" int fm_vq_assign_bias(const void* z, int ldz, const void* codes, const void* code_bias, const void* embed, int K, int D, int R,
+                                 int tokens_per_image, int normalize_latents, void* ws_val, void* ws_idx, int splits, int64_t* tokens,
+                                 void* quant, void* stream);
 extern "C" int fm_vq_assign(const void* z, int ldz, const void* codes_normalized, const void* embed, int K, int D, int R,
                             int tokens_per_image, int normalize_latents, void* ws_val, void* ws_idx, int splits, int64_t* tokens,
                             void* quant, void* stream) {
+    return fm_vq_assign_bias(z, ldz, codes_normalized, nullptr, embed, K, D, R, tokens_per_image, normalize_latents, ws_val, ws_idx, splits, tokens, quant, stream);
+}
+
+// bias[k] = -|embed[k]|^2 / 2  (one thread per code)
+__global__ void vq_code_bias_kernel(const float* __restrict__ embed, int K, int D, float* __restrict__ bias) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) { const float v = embed[(size_t)k * D + d]; s = fmaf(v, v, s); }
+    bias[k] = -0.5f * s;
+}
+
+extern "C" int fm_vq_code_bias(const void* embed, int K, int D, void* bias, void* stream) {
+    FM_CHECK_ARG(embed && bias && K > 0 && D > 0, "fm_vq_code_bias: bad argument");
+    hipLaunchKernelGGL(vq_code_bias_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)embed, K, D, (float*)bias);
+    FM_CHECK_LAUNCH("fm_vq_code_bias");
+    return 0;
+}
+
+extern "C" int fm_vq_assign_bias(const void* z, int ldz, const void* codes_normalized, const void* code_bias, const void* embed, int K, int D, int R,
+                                 int tokens_per_image, int normalize_latents, void* ws_val, void* ws_idx, int splits, int64_t* tokens,
+                                 void* quant, void* stream) {
     FM_CHECK_ARG(z && codes_normalized && embed && ws_val && ws_idx && tokens, "fm_vq_assign: null pointer");
     FM_CHECK_ARG(D == VQ_D, "fm_vq_assign: latent_dim=%d unsupported (this build handles %d)", D, VQ_D);
     FM_CHECK_ARG(K > 0 && R > 0 && splits > 0 && splits <= 64 && ldz % 4 == 0 && tokens_per_image > 0, "fm_vq_assign: bad shape");
     const int per = ((K + splits - 1) / splits + 3) / 4 * 4;
     dim3 grid((R + 255) / 256, splits);
     hipLaunchKernelGGL(vq_search_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)z, ldz, (const float*)codes_normalized, K, R, per,
-                       (float*)ws_val, (int*)ws_idx, normalize_latents);
+                       (float*)ws_val, (int*)ws_idx, normalize_latents, (const float*)code_bias);
     hipLaunchKernelGGL(vq_merge_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws_val, (const int*)ws_idx, splits,
                        (const float*)embed, (long long*)tokens, (float*)quant, R, D, tokens_per_image);
     FM_CHECK_LAUNCH("fm_vq_assign");
     return 0;
 }
 
+static int vq_code_stats_impl(const void* z, int ldz, const int64_t* tokens, int R, int D, int K, void* bins, void* sums, int normalize, void* stream);
 extern "C" int fm_vq_code_stats(const void* z, int ldz, const int64_t* tokens, int R, int D, int K, void* bins, void* sums, void* stream) {
+    return vq_code_stats_impl(z, ldz, tokens, R, D, K, bins, sums, 1, stream);
+}
+extern "C" int fm_vq_code_stats_raw(const void* z, int ldz, const int64_t* tokens, int R, int D, int K, void* bins, void* sums, void* stream) {
+    return vq_code_stats_impl(z, ldz, tokens, R, D, K, bins, sums, 0, stream);
+}
+static int vq_code_stats_impl(const void* z, int ldz, const int64_t* tokens, int R, int D, int K, void* bins, void* sums, int normalize, void* stream) {
     FM_CHECK_ARG(z && tokens && bins && sums && R > 0 && K > 0 && D > 0 && D <= 64, "fm_vq_code_stats: bad argument (latent_dim <= 64)");
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(bins, 0, (size_t)K * 4, s) != hipSuccess || hipMemsetAsync(sums, 0, (size_t)K * D * 4, s) != hipSuccess) {
@@ -187,8 +223,49 @@ extern "C" int fm_vq_code_stats(const void* z, int ldz, const int64_t* tokens, i
     }
     int grid = (R + 3) / 4;
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(vq_code_stats_kernel, dim3(grid), dim3(256), 0, s, (const float*)z, ldz, (const long long*)tokens, R, D, (float*)bins, (float*)sums);
+    hipLaunchKernelGGL(vq_code_stats_kernel, dim3(grid), dim3(256), 0, s, (const float*)z, ldz, (const long long*)tokens, R, D, (float*)bins, (float*)sums, normalize);
     FM_CHECK_LAUNCH("fm_vq_code_stats");
+    return 0;
+}
+
+// EuclideanCodebook EMA (quantize_lucid.py:286-296): cluster_size and embed_avg move towards the batch counts / sums; then
+// embed = embed_avg / smoothed, smoothed[k] = (cluster_size[k] + eps) / (S + K eps) * S with S = sum_k cluster_size[k] (Laplace smoothing).
+// Pass 1 (a wave per code): the two EMAs and S (one atomic per wave);  pass 2: the division.
+__global__ __launch_bounds__(256) void vq_ema_euclid_pass1(const float* __restrict__ bins, const float* __restrict__ sums, float* __restrict__ embed_avg,
+                                                           float* __restrict__ cluster, float* __restrict__ total, int K, int D, float decay) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float alpha = 1.0f - decay;
+    float part = 0.f;
+    for (int k = blockIdx.x * 4 + wave; k < K; k += gridDim.x * 4) {
+        if (lane < D) embed_avg[(size_t)k * D + lane] = __fmaf_rn(alpha, sums[(size_t)k * D + lane], embed_avg[(size_t)k * D + lane] * decay);
+        const float c = __fmaf_rn(alpha, bins[k], cluster[k] * decay);
+        if (lane == 0) { cluster[k] = c; part += c; }
+    }
+    if (lane == 0 && part != 0.f) unsafeAtomicAdd(total, part);
+}
+__global__ __launch_bounds__(256) void vq_ema_euclid_pass2(const float* __restrict__ embed_avg, const float* __restrict__ cluster, const float* __restrict__ total,
+                                                           float* __restrict__ embed, int K, int D, float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= K * D) return;
+    const int k = i / D;
+    const float S = *total;
+    const float smoothed = (cluster[k] + eps) / (S + (float)K * eps) * S;
+    embed[i] = embed_avg[i] / smoothed;
+}
+
+extern "C" int fm_vq_ema_update_euclid(const void* bins, const void* sums, void* embed, void* embed_avg, void* cluster_size, void* total_scratch,
+                                       int K, int D, float decay, float eps, void* stream) {
+    FM_CHECK_ARG(bins && sums && embed && embed_avg && cluster_size && total_scratch && K > 0 && D > 0 && D <= 64 && decay >= 0.f && decay <= 1.f,
+                 "fm_vq_ema_update_euclid: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(total_scratch, 0, 4, s) != hipSuccess) { fm_set_error("fm_vq_ema_update_euclid: memset failed"); return -2; }
+    int grid = (K + 3) / 4;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(vq_ema_euclid_pass1, dim3(grid), dim3(256), 0, s, (const float*)bins, (const float*)sums, (float*)embed_avg, (float*)cluster_size,
+                       (float*)total_scratch, K, D, decay);
+    hipLaunchKernelGGL(vq_ema_euclid_pass2, dim3((K * D + 255) / 256), dim3(256), 0, s, (const float*)embed_avg, (const float*)cluster_size,
+                       (const float*)total_scratch, (float*)embed, K, D, eps);
+    FM_CHECK_LAUNCH("fm_vq_ema_update_euclid");
     return 0;
 }
 

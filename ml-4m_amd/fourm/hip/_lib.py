@@ -199,6 +199,10 @@ lib.fm_set_attn_transpose_read.argtypes = [C.c_int]
 lib.fm_set_gemm_nt_config.argtypes = [C.c_int]
 vq_code_stats = _sig("fm_vq_code_stats", vp, i32, vp, i32, i32, i32, vp, vp, vp)
 vq_ema_update = _sig("fm_vq_ema_update", vp, vp, vp, vp, i32, i32, f32, vp)
+vq_code_bias = _sig("fm_vq_code_bias", vp, i32, i32, vp, vp)
+vq_assign_bias = _sig("fm_vq_assign_bias", vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp)
+vq_code_stats_raw = _sig("fm_vq_code_stats_raw", vp, i32, vp, i32, i32, i32, vp, vp, vp)
+vq_ema_update_euclid = _sig("fm_vq_ema_update_euclid", vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, vp)
 vq_unpatchify = _sig("fm_vq_unpatchify", vp, i32, vp, i32, i32, i32, i32, i32, vp)
 vq_latent_grad = _sig("fm_vq_latent_grad", vp, i32, vp, vp, vp, i32, vp, f32, vp, i32, vp, i32, i32, vp)
 tanh_bwd_f32 = _sig("fm_tanh_bwd_f32", vp, vp, vp, i32, i32, i32, vp)
@@ -215,7 +219,7 @@ unpack_image_u8 = _sig("fm_unpack_image_u8", vp, vp, i32, i32, i32, i32, P(C.c_f
 unpack_ids_u16 = _sig("fm_unpack_ids_u16", vp, vp, i64, vp)
 unpack_mask_bits = _sig("fm_unpack_mask_bits", vp, vp, i32, i32, vp)
 decoder_attention_from_target = _sig("fm_decoder_attention_from_target", vp, vp, i32, i32, vp)
-EXPORTS = ["fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_token_budgets", "fm_span_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_vq_unpatchify", "fm_vq_latent_grad", "fm_tanh_bwd_f32", "fm_embed_rows_f32", "fm_vq_patchify_ex", "fm_vq_cls_emb_bwd", "fm_vq_latent_grad_normalized", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_add_bf16_f32", "fm_scale_rows_bf16", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
+EXPORTS = ["fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_token_budgets", "fm_span_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_vq_code_bias", "fm_vq_assign_bias", "fm_vq_code_stats_raw", "fm_vq_ema_update_euclid", "fm_vq_unpatchify", "fm_vq_latent_grad", "fm_tanh_bwd_f32", "fm_embed_rows_f32", "fm_vq_patchify_ex", "fm_vq_cls_emb_bwd", "fm_vq_latent_grad_normalized", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_add_bf16_f32", "fm_scale_rows_bf16", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_fwd_res", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",

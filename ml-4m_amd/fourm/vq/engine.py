@@ -162,6 +162,16 @@ def _assign(vq, eng, z, R, G, B, nh, nw, want_quant):
     ws, Ld = eng.ws, vq.latent_dim
     cb = vq.quantize._codebook
     K = cb.embed.shape[0]
+    if getattr(cb, "euclidean", False):
+        # Euclidean codebook (norm_codes=False): arg-max of <z, e> - |e|^2 / 2 over the raw codes; norm_latents normalises z first (:525-527)
+        splits = max(1, min(16, K // 1024))
+        wv = ws.get("vq.wv", (R, splits), torch.float32)
+        wi = ws.get("vq.wi", (R, splits), torch.int32)
+        tokens = torch.empty(B, nh, nw, dtype=torch.int64, device=z.device)
+        quant = torch.empty(B, Ld, nh, nw, dtype=torch.float32, device=z.device) if want_quant else None
+        L.check(L.vq_assign_bias(ops._p(z), z.stride(0), ops._p(cb.embed), ops._p(cb.code_bias()), ops._p(cb.embed), K, Ld, R, G,
+                                 1 if vq.quantize.norm_latents else 0, ops._p(wv), ops._p(wi), splits, ops._p(tokens), ops._p(quant), ops._stream()))
+        return (tokens, quant) if want_quant else tokens
     if not bool(cb.initted):                                 # kmeans_init=True: the first batch initialises the codebook (quantize_lucid.py:394)
         cb.init_embed_(z[:R])
     # ONE buffer of l2-normalised codes, recomputed in place when the codebook changed (in training mode every encode() moves the

@@ -1,7 +1,7 @@
 """Codebook containers in the upstream layout (``fourm/vq/quantizers/quantize_lucid.py``: ``CosineSimCodebook``
 :303-428, ``VectorQuantize`` :432-568): nearest code by cosine similarity, ``quantize = embed[index]``, and in training mode the
 EMA codebook update with dead-code replacement (``CosineSimCodebook.ema_update_``: fm_vq_code_stats + fm_vq_ema_update) and the k-means
-codebook initialisation (``init_embed_``, upstream ``kmeans`` :137-167).  The straight-through / commitment gradient of tokenizer training
+codebook initialisation (``init_embed_``, upstream ``kmeans`` :137-167); ``EuclideanCodebook`` (:181-301, ``norm_codes=False``).  The straight-through / commitment gradient of tokenizer training
 lives in fourm/vq/engine.py (fm_vq_latent_grad)."""
 import torch
 import torch.nn as nn
@@ -120,6 +120,88 @@ class CosineSimCodebook(nn.Module):
         return bins
 
 
+class EuclideanCodebook(nn.Module):
+    """Nearest code by Euclidean distance, EMA codebook (upstream ``EuclideanCodebook``, quantize_lucid.py:181-301; ``VectorQuantize(use_cosine_sim=False)``
+    = ``VQ(norm_codes=False)``).  Same buffers as upstream (``initted``, ``cluster_size``, ``embed_avg``, ``embed``), so checkpoints load.
+    Kernels: fm_vq_assign_bias with the bias -|e|^2 / 2 (arg-max of <z, e> - |e|^2 / 2 = arg-min of |z - e|^2), fm_vq_code_stats_raw,
+    fm_vq_ema_update_euclid; dead-code replacement as upstream (which L2-normalises the replacement samples here too, :343-349)."""
+
+    def __init__(self, dim, codebook_size, kmeans_init=False, kmeans_iters=10, decay=0.8, eps=1e-5, threshold_ema_dead_code=2,
+                 code_replacement_policy="batch_random", use_ddp=False, learnable_codebook=False, sample_codebook_temp=0.):
+        super().__init__()
+        if learnable_codebook or sample_codebook_temp:
+            raise NotImplementedError("learnable / sampled codebooks are not implemented")
+        if kmeans_init:
+            raise NotImplementedError("k-means initialisation is implemented for the cosine-similarity codebook only")
+        self.decay, self.codebook_size, self.eps, self.kmeans_iters = decay, codebook_size, eps, kmeans_iters
+        self.threshold_ema_dead_code, self.code_replacement_policy, self.use_ddp = threshold_ema_dead_code, code_replacement_policy, use_ddp
+        self.epoch = 0
+        embed = torch.empty(codebook_size, dim)
+        nn.init.kaiming_uniform_(embed)                      # upstream uniform_init (:58-61)
+        self.register_buffer("initted", torch.Tensor([True]))
+        self.register_buffer("cluster_size", torch.zeros(codebook_size))
+        self.register_buffer("embed_avg", embed.clone())
+        self.register_buffer("embed", embed)
+
+    euclidean = True
+
+    def init_embed_(self, z, generator=None, init_index=None):
+        return                                               # (initted from construction: no k-means path)
+
+    @torch.no_grad()
+    def code_bias(self):
+        """-|embed[k]|^2 / 2, recomputed when the codebook moved."""
+        from fourm.hip import _lib as L, ops
+        stamp = (self.embed._version, self.embed.data_ptr(), self.epoch)
+        c = getattr(self, "_bias", None)
+        if c is None or c[0] != stamp or c[1].device != self.embed.device:
+            b = torch.empty(self.embed.shape[0], dtype=torch.float32, device=self.embed.device)
+            L.check(L.vq_code_bias(ops._p(self.embed), self.embed.shape[0], self.embed.shape[1], ops._p(b), ops._stream()))
+            c = self._bias = (stamp, b)
+        return c[1]
+
+    @torch.no_grad()
+    def ema_update_(self, z, tokens, generator=None):
+        """Training branch of upstream ``forward`` (:282-297): counts and sums of the (un-normalised) latents per code, EMAs of ``cluster_size``
+        and ``embed_avg``, ``embed = embed_avg / Laplace-smoothed cluster size``, then ``expire_codes_``."""
+        import torch.distributed as dist
+        from fourm.hip import _lib as L, ops
+        z = z.reshape(-1, z.shape[-1])
+        if z.dtype != torch.float32 or z.stride(1) != 1:
+            z = z.float().contiguous()
+        tokens = tokens.reshape(-1).contiguous()
+        K, D = self.embed.shape
+        R = z.shape[0]
+        bins = torch.empty(K, dtype=torch.float32, device=z.device)
+        sums = torch.empty(K, D, dtype=torch.float32, device=z.device)
+        total = torch.empty(1, dtype=torch.float32, device=z.device)
+        L.check(L.vq_code_stats_raw(ops._p(z), z.stride(0), ops._p(tokens), R, D, K, ops._p(bins), ops._p(sums), ops._stream()))
+        multi = self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi:
+            dist.all_reduce(bins)
+            dist.all_reduce(sums)
+        L.check(L.vq_ema_update_euclid(ops._p(bins), ops._p(sums), ops._p(self.embed), ops._p(self.embed_avg), ops._p(self.cluster_size), ops._p(total),
+                                       K, D, float(self.decay), float(self.eps), ops._stream()))
+        self.epoch += 1
+        if self.threshold_ema_dead_code > 0:
+            dead = self.cluster_size < self.threshold_ema_dead_code
+            n_dead = int(dead.sum())
+            if n_dead and self.code_replacement_policy == "linde_buzo_gray":
+                most_used = self.cluster_size.argsort(descending=True)[:n_dead]
+                codes = self.embed[most_used]
+                self.embed[dead] = F.normalize(codes + torch.randn(codes.shape, device=codes.device, generator=generator) * 1e-10, p=2, dim=-1)
+            elif n_dead:
+                if self.code_replacement_policy != "batch_random":
+                    raise ValueError(f"{self.code_replacement_policy} is not a valid dead code replacement strategy.")
+                if multi:
+                    raise NotImplementedError("distributed dead-code sampling (sample_vectors_distributed) is not implemented")
+                idx = torch.randperm(R, device=z.device, generator=generator)[:n_dead] if R >= n_dead else torch.randint(0, R, (n_dead,), device=z.device, generator=generator)
+                self.embed[dead] = F.normalize(z[idx], p=2, dim=-1)
+            if n_dead:
+                self.epoch += 1
+        return bins
+
+
 class VectorQuantize(nn.Module):
     def __init__(self, dim, codebook_size, codebook_dim=None, heads=1, decay=0.8, eps=1e-5, kmeans_init=False, kmeans_iters=10,
                  use_cosine_sim=False, threshold_ema_dead_code=0, code_replacement_policy="batch_random", channel_last=False,
@@ -128,13 +210,12 @@ class VectorQuantize(nn.Module):
         super().__init__()
         if heads != 1 or (codebook_dim or dim) != dim:
             raise NotImplementedError("multi-head codebooks / codebook projections are not implemented")
-        if not use_cosine_sim:
-            raise NotImplementedError("only the cosine-similarity codebook (norm_codes=True) has a HIP kernel")
         self.heads, self.codebook_size, self.norm_latents, self.commitment_weight = heads, codebook_size, norm_latents, commitment_weight
         self.project_in, self.project_out = nn.Identity(), nn.Identity()
-        self._codebook = CosineSimCodebook(dim=dim, codebook_size=codebook_size, kmeans_init=kmeans_init, kmeans_iters=kmeans_iters,
-                                           decay=decay, eps=eps, threshold_ema_dead_code=threshold_ema_dead_code,
-                                           code_replacement_policy=code_replacement_policy, use_ddp=sync_codebook)
+        codebook_class = CosineSimCodebook if use_cosine_sim else EuclideanCodebook          # (quantize_lucid.py:474)
+        self._codebook = codebook_class(dim=dim, codebook_size=codebook_size, kmeans_init=kmeans_init, kmeans_iters=kmeans_iters,
+                                        decay=decay, eps=eps, threshold_ema_dead_code=threshold_ema_dead_code,
+                                        code_replacement_policy=code_replacement_policy, use_ddp=sync_codebook)
 
     @property
     def codebook(self):

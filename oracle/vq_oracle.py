@@ -190,6 +190,40 @@ def codebook_ema_update(embed: Tensor, cluster_size: Tensor, z: Tensor, ind: Ten
     return new_embed, cluster
 
 
+def assign_codes_euclid(z: Tensor, embed: Tensor):
+    """Nearest code by Euclidean distance (upstream ``EuclideanCodebook.forward``, quantize_lucid.py:272-281): arg-max of
+    -(|z|^2 - 2 z e^T + |e|^2), first index on ties; quantised vector = the codebook row.  -> (ind, quantize, dist (R, K))."""
+    z = z.float().reshape(-1, z.shape[-1])
+    et = embed.t()
+    dist = -(z.pow(2).sum(1, keepdim=True) - 2 * z @ et + et.pow(2).sum(0, keepdim=True))
+    ind = dist.argmax(-1)
+    return ind, embed[ind], dist
+
+
+def codebook_ema_update_euclid(embed_avg: Tensor, cluster_size: Tensor, z: Tensor, ind: Tensor, decay: float, eps: float = 1e-5,
+                               threshold_dead: float = 0.0, replace_rows: Tensor = None):
+    """Training-mode branch of upstream ``EuclideanCodebook.forward`` (quantize_lucid.py:282-297) after the code assignment:
+        cluster_size = cluster_size * decay + bins * (1 - decay)                                  (:286, ema_inplace)
+        embed_avg    = embed_avg * decay + (sum of the raw latents per code) * (1 - decay)        (:288-292)
+        embed        = embed_avg / ((cluster_size + eps) / (sum(cluster_size) + K eps) * sum(cluster_size))    (:293-295, laplace_smoothing)
+        expire_codes_ (:358-375): codes with cluster_size < threshold_dead take ``replace_rows`` (upstream L2-normalises its samples, :343-345).
+    -> (new embed, new embed_avg, new cluster_size)."""
+    K = embed_avg.shape[0]
+    z = z.float().reshape(-1, z.shape[-1])
+    ind = ind.reshape(-1).long()
+    bins = torch.bincount(ind, minlength=K).float()
+    sums = torch.zeros(K, z.shape[1]).index_add_(0, ind, z)
+    cluster = cluster_size.clone().mul_(decay).add_(bins, alpha=1 - decay)
+    avg = embed_avg.clone().mul_(decay).add_(sums, alpha=1 - decay)
+    smoothed = (cluster + eps) / (cluster.sum() + K * eps) * cluster.sum()
+    new_embed = avg / smoothed.unsqueeze(1)
+    if threshold_dead > 0:
+        dead = cluster < threshold_dead
+        if bool(dead.any()):
+            new_embed[dead] = replace_rows
+    return new_embed, avg, cluster
+
+
 # ---- VQ-VAE: decoder + training-mode quantizer (SURVEY §8 f4) ---------------------------------------------------------------------
 DEC_DIMS = {"vit_s_dec": (512, 8, 8), "vit_b_dec": (768, 12, 12), "vit_l_dec": (1024, 24, 16)}
 
