@@ -39,7 +39,9 @@ constexpr uint32_t OOB = 0x80000000u;       // an offset with bit 31 set is outs
 // a wave holds 32 rows x 32 bytes per store instruction in its accumulator layout - 32-byte write requests at the L2, 4.7 M of the 13 M
 // requests of a qkv launch (profiles/r04_pmc_l2_fullline.txt) - and re-reads the staged rows so that consecutive lanes cover whole
 // 128-byte lines: the same store instructions, half the write requests (64 bytes each), bit-identical outputs.
-template <int TW, int EPI, bool SPLIT = false, bool STG = false>
+// BIAS (staged dense epilogues only): out = bf16(acc + bf16(bias[n])); EPI_GELU: pre = that value (out2, optional), out = bf16(gelu(pre)) -
+// the biased Linears of the tokenizers' ViTs and of the *_gelu 4M variants (gemm.hip's epilogue arithmetic, bit for bit).
+template <int TW, int EPI, bool SPLIT = false, bool STG = false, bool BIAS = false>
 __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TX = 256, KB = 64, WW = 2, WX = 4, NWAVES = 8, KS = 4;
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     constexpr int NMF = FW * FX;                                    // MFMAs per k-step
     // stores per wave and tile (16 bytes per lane each)
-    constexpr int NST = EPI == EPI_BF16 ? FW * FX * 2 : EPI == EPI_SWIGLU ? FX * (FW / 2) * 2 * 3 : EPI == EPI_SWIGLU_BWD ? 60 : FW * FX * 4;
+    constexpr int NST = (EPI == EPI_BF16 || EPI == EPI_GELU) ? FW * FX * 2 : EPI == EPI_SWIGLU ? FX * (FW / 2) * 2 * 3 : EPI == EPI_SWIGLU_BWD ? 60 : FW * FX * 4;
     static_assert(TW % (RPP * NWAVES) == 0, "tile rows must split evenly over the DMA pieces");
     static_assert(EPI != EPI_SWIGLU || FW % 2 == 0, "SwiGLU needs (g,u) fragment pairs per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,21 +151,39 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
     auto finish_tile = [&](int j_done) __attribute__((always_inline)) {
         int n0, m0;
         tile_origin(j_done, n0, m0);
-        if constexpr (EPI == EPI_BF16 && STG) {
+        if constexpr ((EPI == EPI_BF16 || EPI == EPI_GELU) && STG) {
             const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
+            const __amdgpu_buffer_rsrc_t rs_pre = rsrc_of((const char*)(a.out2 ? a.out2 : a.out) + (size_t)m0 * (a.out2 ? a.ldo2 : a.ldo) * 2);
+            (void)rs_pre;
             constexpr int CW = (TW / WW) / 8;                                   // 16-byte chunks per staged row: 16 (two rounds of 8) or 12
             constexpr int RCH = CW == 16 ? 8 : 12, ROWB = RCH * 16, NRND = CW / RCH, SPR = 32 * RCH / 64;     // stores per round
             char* sc = smem + 2 * STAGE + wave * (32 * ROWB);
+            constexpr int NWHICH = EPI == EPI_GELU ? 2 : 1;                     // GELU: the pre-activation (when asked for), then the activation
 #pragma unroll
             for (int j = 0; j < FX; ++j)
 #pragma unroll
-                for (int rnd = 0; rnd < NRND; ++rnd) {
+                for (int rnd = 0; rnd < NRND; ++rnd)
+#pragma unroll
+                for (int which = 0; which < NWHICH; ++which) {
+                    if (EPI == EPI_GELU && which == 0 && !a.out2) continue;
 #pragma unroll
                     for (int ii = 0; ii < RCH / 4; ++ii)
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int i = rnd * (RCH / 4) + ii, ch = ii * 4 + g;
-                            const uint2 pv = make_uint2(pack2bf(acc[i][j][4 * g], acc[i][j][4 * g + 1]), pack2bf(acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]));
+                            float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            if constexpr (BIAS) {
+                                const int cb = n0 + ww * (TW / WW) + i * 32 + 8 * g + 4 * fhi;
+                                if (cb < N) {
+                                    const float4 t = *(const float4*)(a.bias + cb);
+                                    v[0] += bfround(t.x); v[1] += bfround(t.y); v[2] += bfround(t.z); v[3] += bfround(t.w);
+                                }
+                            }
+                            if (EPI == EPI_GELU && which == 1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = gelu_f(bfround(v[e]));
+                            }
+                            const uint2 pv = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                             int pos;
                             if constexpr (RCH == 8) pos = ch ^ (frow & 7);
                             else { pos = ch + (frow & 7); pos = pos >= 12 ? pos - 12 : pos; }
@@ -188,8 +208,13 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
                     for (int q = 0; q < SPR; ++q) {
                         const int rl = wx * (TX / WX) + j * 32 + rr[q];
                         const int c = n0 + ww * (TW / WW) + rnd * (RCH * 8) + cc[q] * 8;
-                        const uint32_t so = ((m0 + rl < a.M && c < N) ? 0u : OOB) | ((uint32_t)(rl * a.ldo) * 2u + (uint32_t)c * 2u);
-                        __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out, so, 0, 0);
+                        if (EPI == EPI_GELU && which == 0) {
+                            const uint32_t so = ((m0 + rl < a.M && c < N) ? 0u : OOB) | ((uint32_t)(rl * a.ldo2) * 2u + (uint32_t)c * 2u);
+                            __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_pre, so, 0, 0);
+                        } else {
+                            const uint32_t so = ((m0 + rl < a.M && c < N) ? 0u : OOB) | ((uint32_t)(rl * a.ldo) * 2u + (uint32_t)c * 2u);
+                            __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out, so, 0, 0);
+                        }
                     }
                 }
         } else if constexpr (EPI == EPI_BF16) {
@@ -535,7 +560,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
 #endif
 }
 
-template <int TW, int EPI, bool SPLIT = false, bool STG = false>
+template <int TW, int EPI, bool SPLIT = false, bool STG = false, bool BIAS = false>
 int launch_nt3(NTArgs a, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (a.N + NPT - 1) / NPT;
@@ -555,7 +580,7 @@ int launch_nt3(NTArgs a, hipStream_t s) {
     // (profiles/r04_ab_reverse_walk.txt); FOURM_NT3_LAB bit 2048: forward walk.
     a.reverse = (a.lab & 2048) ? 0 : 1;
     const size_t lds = (size_t)2 * (TW + 256) * 128 + (STG ? (TW == 256 ? 32768 : 49152) : 0);
-    auto k = gemm_nt3_kernel<TW, EPI, SPLIT, STG>;
+    auto k = gemm_nt3_kernel<TW, EPI, SPLIT, STG, BIAS>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
@@ -569,7 +594,9 @@ int launch_nt3(NTArgs a, hipStream_t s) {
 // outside what it handles, < 0 on a launch error.
 int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     using namespace fmk;
-    if (!mode || a.groups || a.bias || a.bias2) return 0;
+    if (!mode || a.groups || a.bias2) return 0;
+    if (a.bias && !(epilogue == FM_EPI_BF16 || epilogue == FM_EPI_GELU)) return 0;
+    if (a.bias && ((((uintptr_t)a.bias) & 15) != 0 || (a.lab & (16 | 1024)))) return 0;       // (biased launches exist in the staged form only)
     if (a.M < 2048 || a.K % 64 != 0 || a.K < 128 || a.N % 8 != 0) return 0;
     if ((size_t)256 * (size_t)a.ldo * 4 >= 0x7fffffffull || (size_t)256 * (size_t)a.ldx * 2 >= 0x7fffffffull || (size_t)256 * (size_t)a.ldw * 2 >= 0x7fffffffull) return 0;
     const bool al16 = (((uintptr_t)a.out | (uintptr_t)a.out2 | (uintptr_t)a.res) & 15) == 0;
@@ -584,8 +611,20 @@ int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     const bool fits192 = a.N % 192 == 0;
     const long c256 = (t256 + cus - 1) / cus * 256, c192 = (t192 + cus - 1) / cus * 192;
     const bool use192 = mode == 2 ? fits192 : mode == 3 ? (fits192 && c192 < c256) : false;
+    if (epilogue == FM_EPI_GELU) {      // biased (or not) Linear + exact GELU, optional pre-activation copy: staged form only
+        // Off unless asked for (FOURM_NT3_LAB bit 131072): the erf polynomial on top of 128 accumulator registers spills (8 - 104 bytes per lane)
+        // and the launch is slower than gemm.hip's GELU epilogue (tokenizer fc1, M = 12544, N = 3072: 98 vs 86 us).
+        if (!(a.lab & 131072)) return 0;
+        if (a.ldo % 64 != 0 || (((uintptr_t)a.out) & 127) != 0 || (a.out2 && (a.ldo2 % 64 != 0 || (((uintptr_t)a.out2) & 127) != 0)) || (a.lab & (16 | 1024))) return 0;
+        if (a.bias) return use192 ? launch_nt3<192, EPI_GELU, true, true, true>(a, s) : launch_nt3<256, EPI_GELU, true, true, true>(a, s);
+        return use192 ? launch_nt3<192, EPI_GELU, true, true, false>(a, s) : launch_nt3<256, EPI_GELU, true, true, false>(a, s);
+    }
     if (epilogue == FM_EPI_BF16) {
         if (a.ldo % 8 != 0) return 0;
+        if (a.bias) {
+            if (a.ldo % 64 != 0 || (((uintptr_t)a.out) & 127) != 0) return 0;
+            return use192 ? launch_nt3<192, EPI_BF16, true, true, true>(a, s) : launch_nt3<256, EPI_BF16, true, true, true>(a, s);
+        }
         if (!(a.lab & 1024) && !(a.lab & 16) && a.ldo % 64 == 0 && (((uintptr_t)a.out) & 127) == 0)      // staged epilogue (whole-line stores); lab bit 1024: legacy
             return use192 ? launch_nt3<192, EPI_BF16, true, true>(a, s) : launch_nt3<256, EPI_BF16, true, true>(a, s);
         if (!(a.lab & 16)) return use192 ? launch_nt3<192, EPI_BF16, true>(a, s) : launch_nt3<256, EPI_BF16, true>(a, s);

@@ -90,7 +90,9 @@ def _blocks_fwd(eng, vit, stream, B, G, st, prefix):
     none = dict(mask_kind=L.MASK_NONE)
     for i, blk in enumerate(vit.blocks):
         sv = {} if st is not None else None
-        stream = eng.encoder_block_fwd(blk, stream, B, G, none, sv, f"{prefix}{i}" if st is not None else f"{prefix}{i % 2}")
+        # (the last residual sum of every block but the final one is left to the next block's norm1: a bf16 GEMM + fm_layernorm_fwd_res)
+        stream = eng.encoder_block_fwd(blk, stream, B, G, none, sv, f"{prefix}{i}" if st is not None else f"{prefix}{i % 2}",
+                                       defer_out=i + 1 < len(vit.blocks))
         if st is not None:
             st["layers"].append(sv)
     return stream
