@@ -1286,6 +1286,11 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     a.dephase_groups = g_lab[0]; a.dephase_step = g_lab[1]; a.lab = g_lab[3];
     hipStream_t s = (hipStream_t)stream;
     const int max_n = grouped ? p->max_N : p->N;
+    if (!grouped && p->M <= 32) {             // a handful of rows (a decoding step): the weight-streaming kernel of gemm_skinny.hip
+        const int r = fm_launch_nt_skinny(a, p->epilogue, s);
+        if (r < 0) { fm_set_error("fm_gemm_nt (skinny): launch failed"); return -2; }
+        if (r > 0) return 0;
+    }
     if (!grouped && g_lab[2]) {               // the lock-step large-tile kernel (gemm_nt3.hip) takes the dense launches it handles
         const int r = fm_launch_nt3(a, p->epilogue, g_lab[2], s);
         if (r < 0) { fm_set_error("fm_gemm_nt (nt3): launch failed"); return -2; }

@@ -37,6 +37,41 @@ def randn(*shape, scale=1.0, seed=None):
 # ------------------------------------------------------------------------------------------------
 # GEMM
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M", [1, 5, 16, 32])
+@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (30000, 768), (40, 64), (768, 2752), (1000, 4096)])
+def test_gemm_nt_skinny_rows(M, N, K):
+    """fm_gemm_nt on a handful of rows (a decoding step) runs the weight-streaming kernel of csrc/gemm_skinny.hip: bf16 (+ bias), fp32
+    residual (+ bias) and SwiGLU epilogues against fp32 torch with gemm.hip's rounding points; rows / features outside the problem stay untouched."""
+    ops, L = _ops()
+    x = bf(randn(M, K, seed=11, scale=0.5))
+    w, w3 = bf(randn(N, K, seed=12, scale=0.1)), bf(randn(N, K, seed=13, scale=0.1))
+    bias = randn(N, seed=14, scale=0.3)
+    ref = x.float() @ w.float().t()
+    ldo = ops.ru(N, 8)
+    for b in (None, bias):
+        out = torch.full((M + 3, ldo), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w, out, bias=b, M=M, N=N, K=K)
+        want = ref + (bf(b).float() if b is not None else 0.0)
+        assert rel_err(out[:M, :N], want) < 4e-3, (M, N, K, b is not None)
+        assert bool((out[M:] == 7.0).all()) and bool((out[:M, N:] == 7.0).all())
+        res = randn(M + 3, ldo, seed=15)
+        o32 = torch.full((M + 3, ldo), 7.0, device=DEV)
+        ops.gemm_nt(x, w, o32, epilogue=L.EPI_RESIDUAL, res=res, bias=b, M=M, N=N, K=K)
+        assert max_err(o32[:M, :N], res[:M, :N] + bf(want).float()) < 2e-2 * float(want.abs().max()), (M, N, K)
+        assert bool((o32[M:] == 7.0).all())
+    if N % 8 == 0:
+        Hp = ops.ru(N, 64)
+        act = torch.full((M, Hp), 3.0, device=DEV, dtype=torch.bfloat16)
+        gu = torch.full((M, 2 * Hp), 3.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w, act, epilogue=L.EPI_SWIGLU, w2=w3, out2=gu, Hp=Hp, M=M, N=N, K=K)
+        g, u = bf(ref).float(), bf(x.float() @ w3.float().t()).float()
+        assert rel_err(gu[:, :N], g) < 4e-3 and rel_err(gu[:, Hp:Hp + N], u) < 4e-3
+        assert rel_err(act[:, :N], bf(torch.nn.functional.silu(g)).float() * u) < 8e-3
+        act2 = torch.full((M, Hp), 3.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w, act2, epilogue=L.EPI_SWIGLU, w2=w3, Hp=Hp, M=M, N=N, K=K)          # inference: no (g | u) copy
+        assert torch.equal(act2[:, :N], act[:, :N])
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12])
 def test_gemm_nt_tile_configs(cfg):
     """Every tile configuration of fm_gemm_nt (fm_set_gemm_nt_config) on ragged shapes and all epilogue kinds."""
