@@ -95,9 +95,12 @@ def worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_data_parallel_two_processes_one_gpu(tmp_path):
+@pytest.mark.parametrize("exchange", ["overlap", "tail"])
+def test_data_parallel_two_processes_one_gpu(tmp_path, exchange):
+    """exchange = "overlap": stage-wise under the backward (the default); "tail": one exchange after it (FOURM_DP_EXCHANGE)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = {**os.environ, "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "ml-4m_amd"), os.environ.get("PYTHONPATH", "")])}
+    env = {**os.environ, "PYTHONPATH": os.pathsep.join([ROOT, os.path.join(ROOT, "ml-4m_amd"), os.environ.get("PYTHONPATH", "")]),
+           "FOURM_DP_EXCHANGE": exchange}
     run_workers([[str(r), "2", str(port), str(tmp_path)] for r in range(2)], env)
 
     case = build_case(CASE)
