@@ -101,7 +101,26 @@ def run_pair(gemm, stream_fn, k, iters=10):
     return out
 
 
+def trace_mode():
+    """For `rocprofv3 --kernel-trace`: three 'pair' rounds per dW form with swiglu_bwd as the partner, nothing else, so that the
+    kernel start / end timestamps show whether the two streams' kernels were resident at the same time (tools/coresidency_trace.py)."""
+    main_s = torch.cuda.current_stream()
+    for cfg in (1, 3):
+        L.lib.fm_set_gemm_tn_config(cfg)
+        for _ in range(4):
+            side.wait_stream(main_s)
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    s_swiglu()
+            ops.gemm_tn_multi(enc_jobs)
+            main_s.wait_stream(side)
+            torch.cuda.synchronize()
+    L.lib.fm_set_gemm_tn_config(1)
+
+
 def main():
+    if "--trace" in sys.argv:
+        return trace_mode()
     print(f"# {torch.cuda.get_device_name(0)}; R={R}; times in us; 'pair' = both issued from a common start on two streams")
     print(f"{'dW form':28s} {'list':8s} {'partner':12s} {'k':>2s} {'gemm':>8s} {'stream':>8s} {'sum':>8s} {'pair':>8s} {'pair/sum':>8s} {'hidden':>7s}")
     partners = (("swiglu_bwd", s_swiglu, 4), ("ln_fwd_res", s_lnfwd, 8), ("ln_bwd", s_lnbwd, 6), ("sumsq", s_sumsq, 2))
