@@ -407,14 +407,14 @@ class FourMEngine:
 
     @property
     def hoist_ctx(self):
-        """The context-norm hoist applies: every decoder block's context_norm is bias-free (all 4M swiglu_nobias configurations) and
-        its cross-attention K/V projection is trainable or frozen as a whole with it."""
+        """The context-norm hoist applies: every decoder block's context_norm is bias-free and its K/V projection has no bias (all 4M
+        swiglu_nobias configurations).  Decided once per engine (it fixes the order of the flat parameter store); which of the two tensors
+        are trainable is read at every backward."""
         h = getattr(self, "_hoist_ctx", None)
         if h is None:
             m = self.model
             h = HOIST_CTX and len(m.decoder) > 0 and all(
-                not isinstance(b.context_norm.bias, nn.Parameter) and b.cross_attn.kv.bias is None
-                and b.cross_attn.kv.weight.requires_grad == b.context_norm.weight.requires_grad for b in m.decoder)
+                not isinstance(b.context_norm.bias, nn.Parameter) and b.cross_attn.kv.bias is None for b in m.decoder)
             self._hoist_ctx = h
         return h
 
@@ -992,7 +992,7 @@ class FourMEngine:
             dhc = ws.get("bwd.dhc", (Rcp, D), bf)
             ops.gemm_nt(dkv, self.wt(xa.kv.weight), dhc, M=Rc, N=D, K=2 * D)
             self._ln_bwd(blk.context_norm, dhc, ctx, sv, "nc", dctx, dctx_bf, Rc, dres=dctx)     # accumulates over layers
-        elif xa.kv.weight.requires_grad:
+        elif xa.kv.weight.requires_grad or blk.context_norm.weight.requires_grad:
             self._dw_jobs.append((dkv, hoist[1], hoist[2], 2 * D, D, Rc))                       # dL/d(W diag(gamma)) = dkv^T x_hat
         # self attention
         dh = self._self_attn_bwd(blk.self_attn, sv, g_bf, B, M, Rq, Rqp, sa_mask)
@@ -1098,7 +1098,7 @@ class FourMEngine:
             self._ln_bwd(self._unit_norm(), dxh, st["ctx"], st["sv_hat"], "ch", dctx, dctx_bf, Rc, dres=None)
             # dL/dW_l = dL/dW'_l diag(gamma_l);  dL/dgamma_l = column sums of dL/dW'_l * W_l
             jobs = [(dwp[i], b.cross_attn.kv.weight.detach(), b.context_norm.weight.detach(), self._g(b.cross_attn.kv.weight), self._g(b.context_norm.weight))
-                    for i, b in enumerate(m.decoder) if b.cross_attn.kv.weight.requires_grad]
+                    for i, b in enumerate(m.decoder) if b.cross_attn.kv.weight.requires_grad or b.context_norm.weight.requires_grad]
             if jobs:
                 ops.fold_colscale_grad(jobs)
         self._embed_bwd(dec, g, None, True)

@@ -298,6 +298,36 @@ def test_fused_adamw_step_matches_torch():
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 2.0
 
 
+def test_hoisted_context_norm_with_frozen_parts():
+    """The context-norm hoist (engine.hoist_ctx) computes dL/d(W diag(gamma)) once per decoder block and unfolds it into dW and dgamma:
+    freezing either tensor alone must leave the other one's gradient unchanged (and FOURM_HOIST_CTX=0, the per-block form, agrees)."""
+    g, case, model = setup("micro_swiglu")
+    assert model.engine.hoist_ctx
+    md = to_device(case["mod_dict"])
+
+    def grads(freeze):
+        _, _, m = setup("micro_swiglu")
+        for blk in m.decoder:
+            if freeze == "kv":
+                blk.cross_attn.kv.weight.requires_grad_(False)
+            if freeze == "norm":
+                blk.context_norm.weight.requires_grad_(False)
+        random.seed(case["order_seed"])
+        loss, _ = m(md, case["N"], case["M"])
+        loss.backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, float(loss)
+    full, l0 = grads(None)
+    for freeze, kept, gone in (("kv", "context_norm.weight", "cross_attn.kv.weight"), ("norm", "cross_attn.kv.weight", "context_norm.weight")):
+        part, l1 = grads(freeze)
+        assert l1 == l0
+        assert not any(gone in n and "decoder." in n for n in part), freeze
+        for n, gr in full.items():
+            if kept in n and "decoder." in n:
+                assert rel(part[n], gr) < 2e-5, (freeze, n, rel(part[n], gr))
+        for n in ("decoder.0.self_attn.qkv.weight", "encoder.0.attn.qkv.weight"):            # ... and nothing else moves
+            assert rel(part[n], full[n]) < 2e-5, (freeze, n)
+
+
 def test_trainer_step_trajectory_b_mod7():
     """The trainer's update - NativeScalerWithGradNormCount(loss, FusedAdamW, clip_grad=...) as run_training_4m.py:727-733 calls it - against
     torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over THREE steps of 4M-B with a changing learning rate: the weight trajectory, not
