@@ -12,32 +12,21 @@ What is frozen at capture time (documented deviations from the eager path):
   * the parameter set with gradients, loss type, token budgets, clipping mode.
 A graphed step refuses to run (loudly) if the engine's workspace or flat stores were re-allocated after capture.
 
-Data parallel: pass the ``fourm.parallel.DataParallel`` wrapper as ``wrapper`` - the forward then goes through it, and the gradient exchange
-(RCCL collectives issued by the reducer at the backward's stages, their stream hand-offs and the waits) is captured with everything else:
-torch's NCCL process group forks its communication stream from the capturing stream.  Requires the ``nccl`` (= RCCL) backend (gloo's host-side
-collectives cannot be captured).  Exercised at world size 1 with forced collectives (tests/test_parallel_gpu.py); NOT yet run at N > 1.
+Single process only: with a gradient reducer attached (data parallel) the step stays eager - RCCL launches are not captured here.
 """
 import torch
 
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, mod_dict, num_encoder_tokens: int, num_decoder_tokens: int, loss_type: str = "mod",
-                 clip_grad=None, warmup: int = 2, order_seed=None, wrapper=None):
-        """``order_seed``: seed ``random`` right before the captured forward, i.e. choose the (frozen) decoder modality order.
-        ``wrapper``: the DataParallel around ``model`` (its gradient exchange is captured too; RCCL backend only)."""
+                 clip_grad=None, warmup: int = 2, order_seed=None):
+        """``order_seed``: seed ``random`` right before the captured forward, i.e. choose the (frozen) decoder modality order."""
         from fourm.utils.optim_factory import FusedAdamW
         if not isinstance(optimizer, FusedAdamW):
             raise TypeError("GraphedTrainStep needs FusedAdamW (device-side hyper-parameters)")
         eng = model.engine
-        if wrapper is not None:
-            import torch.distributed as dist
-            if getattr(wrapper, "module", None) is not model:
-                raise ValueError("wrapper must be the DataParallel around model")
-            if not dist.is_initialized() or dist.get_backend(wrapper.process_group) != "nccl":
-                raise RuntimeError("a captured gradient exchange needs the nccl (RCCL) backend: host-side collectives cannot be captured")
-        elif eng.reducer is not None:
-            raise RuntimeError("a gradient reducer is attached (data parallel): pass the DataParallel as wrapper=, or the step stays eager")
-        self.wrapper = wrapper
+        if eng.reducer is not None:
+            raise RuntimeError("a gradient reducer is attached (data parallel): the step stays eager")
         self.model, self.opt, self.n_enc, self.n_dec, self.loss_type, self.clip = model, optimizer, num_encoder_tokens, num_decoder_tokens, loss_type, clip_grad
         dev = model.mask_token.device
         self.static = {m: {k: v.detach().clone().to(dev) for k, v in d.items() if torch.is_tensor(v)} for m, d in mod_dict.items()}
@@ -68,8 +57,7 @@ class GraphedTrainStep:
         return (eng.flat_params.data_ptr(), eng.flat_grads.data_ptr(), len(eng.ws.bufs), tuple(sorted((k, v.data_ptr()) for k, v in eng.ws.bufs.items()))[:8])
 
     def _launches(self):
-        fwd = self.wrapper if self.wrapper is not None else self.model
-        loss, mod_loss = fwd(self.static, self.n_enc, self.n_dec, loss_type=self.loss_type)
+        loss, mod_loss = self.model(self.static, self.n_enc, self.n_dec, loss_type=self.loss_type)
         loss.backward()
         norm = self.opt.fused_grad_norm(clip=self.clip)
         self.opt.step()
