@@ -315,3 +315,31 @@ for name in ("micro_swiglu", "micro_qknorm"):
     env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
     p = subprocess.run([sys.executable, "-c", f"ROOT = {ROOT!r}\n" + child], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0 and p.stdout.count("ok") == 2, (p.stdout + p.stderr)[-3000:]
+
+
+def test_context_norm_hoist_algebra():
+    """The derivation behind the engine's context-norm hoist (fourm/hip/engine.py hoist_ctx), in plain fp64 torch: with x_hat = (c - mean) rstd,
+        kv_l = LN_l(c) W_l^T = x_hat (W_l diag(gamma_l))^T                                    (bias-free norms),
+        dL/dW_l = dL/dW'_l diag(gamma_l),   dL/dgamma_l = column sums of dL/dW'_l * W_l          (W'_l = W_l diag(gamma_l)),
+        dL/dc = LayerNorm backward (no affine part) of  sum_l dkv_l W'_l  = [dkv_0 | dkv_1 | ...] [W'_0; W'_1; ...]
+    against autograd through L separate LayerNorms of the same context (what upstream's decoder blocks compute, fm_utils.py:364)."""
+    torch.manual_seed(0)
+    R, D, L = 24, 16, 3
+    c = torch.randn(R, D, dtype=torch.float64, requires_grad=True)
+    Ws = [torch.randn(2 * D, D, dtype=torch.float64, requires_grad=True) for _ in range(L)]
+    gs = [(torch.rand(D, dtype=torch.float64) + 0.5).requires_grad_(True) for _ in range(L)]
+    up = [torch.randn(R, 2 * D, dtype=torch.float64) for _ in range(L)]                          # d(loss) / d(kv_l)
+    eps = 1e-6
+    loss = sum((torch.nn.functional.layer_norm(c, (D,), g, None, eps) @ W.t() * u).sum() for W, g, u in zip(Ws, gs, up))
+    loss.backward()
+    with torch.no_grad():
+        mu, var = c.mean(-1, keepdim=True), c.var(-1, unbiased=False, keepdim=True)
+        rstd = (var + eps).rsqrt()
+        xh = (c - mu) * rstd
+        dxh = torch.cat(up, 1) @ torch.cat([W * g[None, :] for W, g in zip(Ws, gs)], 0)          # one GEMM over all layers
+        dc = rstd * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))   # LayerNorm backward, unit weight
+        assert torch.allclose(dc, c.grad, rtol=1e-9, atol=1e-11)
+        for W, g, u in zip(Ws, gs, up):
+            dWp = u.t() @ xh                                                                     # the ordinary weight-gradient GEMM, on x_hat
+            assert torch.allclose(dWp * g[None, :], W.grad, rtol=1e-9, atol=1e-11)
+            assert torch.allclose((dWp * W).sum(0), g.grad, rtol=1e-9, atol=1e-11)
