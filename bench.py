@@ -516,6 +516,19 @@ def main():
     if a.gpus != world:
         if rank == 0:
             print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    comm_check = None
+    if world > 1:
+        # self-check of the launch: a sum of ones over the process group = the ranks the collectives really span (a mis-launched
+        # N x dp1 job would print WORLD_SIZE = N and still reduce over 1), and a sum of device ordinals shows N DISTINCT GPUs under RCCL
+        ones = torch.tensor([1.0, float(local)], device=dev)
+        dist.all_reduce(ones)
+        comm_check = {"backend": dist.get_backend(), "rccl_ranks": int(ones[0].item()), "sum_local_ranks": int(ones[1].item()),
+                      "expected_sum_local_ranks": world * (world - 1) // 2 if a.dist_backend == "nccl" else None}
+        try:
+            comm_check["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001
+            comm_check["rccl_version"] = f"unavailable ({type(e).__name__})"
+        assert comm_check["rccl_ranks"] == world, f"collectives span {comm_check['rccl_ranks']} ranks, WORLD_SIZE says {world}"
 
     from fourm.data.synthetic import synthetic_batch
     from fourm.hip import ops
@@ -525,6 +538,8 @@ def main():
     torch.manual_seed(0)
     model = build_model(a.model, dev, a.mods).train()
     dp = DataParallel(model) if world > 1 else None
+    if dp is not None:
+        dp.time_exchange = True              # events around GradReducer.finish(): the exchange time the backward did not hide
     fwd = dp if dp is not None else model
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
@@ -577,7 +592,12 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
-    last_loss = float(loss)
+    last_loss = float(loss.detach())
+    exch = None
+    if dp is not None and dp._reducer is not None:
+        ms = dp._reducer.exposed_ms()[-a.steps:]
+        exch = {"exposed_ms_per_step": sum(ms) / len(ms) if ms else None, "collectives_per_step": dp._reducer.n_collectives,
+                "wire_mb_per_step": dp._reducer.bytes_on_wire / 2 ** 20}
 
     tokens_per_step = world * a.batch * (a.n_in + a.n_out)
     value = tokens_per_step * a.steps / dt
@@ -600,7 +620,9 @@ def main():
     if dp is not None:         # how the gradients travelled (fourm.parallel.DataParallel): nothing here changes the work counted in `value`
         out["config"]["data_parallel"] = {"exchange": dp._exchange_mode, "reserved_cus": dp._reserved_cus, "min_launch_mb": dp._min_launch_mb
                                           if dp._min_launch_mb != float("inf") else None, "wire_dtype": "bf16" if dp._wire is not None else "fp32",
-                                          "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS")}
+                                          "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), **(comm_check or {}), **(exch or {}),
+                                          "note": "exposed_ms_per_step = rank 0's compute stream between entering GradReducer.finish() and holding every "
+                                                  "reduced slice (collectives still running or not yet started + unpack), averaged over the timed steps"}
     if masking_ms is not None:
         out["data"] = "synthetic modalities masked on the device (Dirichlet token budgets, image masks, span masking)"
         out["masking_ms_per_batch"] = masking_ms          # the producer, outside the timed region (batches are resident when it starts)

@@ -46,8 +46,13 @@ struct AttnArgs {
     int chunk;                    // rows of the two LDS tiles of the backward (a multiple of 32; >= max(Nq, Nk) padded when one chunk does)
 };
 
+// 16-byte chunk c of row r sits at chunk c ^ sw3(r).  sw3 = the bit-REVERSED row-pair index: rows r and r + 2 (the same 128-byte half of
+// the 256-byte bank window) differ in bit 2 of the key, so the four rows a ds_read_b64_tr_b16 half-wave touches (4 rows x 64 bytes) spread
+// over all 64 banks (round 4's key (r >> 1) & 7 put rows r and r + 2 on the same 16 banks: every transpose read was a 2-way conflict, 23 %
+// of the backward's LDS cycles); the 16 rows of a ds_read_b128 lane group still see 8 distinct keys per row parity (a bijection of 3 bits).
+__device__ __forceinline__ int sw3(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 __device__ __forceinline__ const char* tile_addr(const char* tile, int row, int col) {
-    return tile + row * ROWB + ((((col >> 3) ^ ((row >> 1) & 7))) << 4) + (col & 7) * 2;
+    return tile + row * ROWB + ((((col >> 3) ^ sw3(row))) << 4) + (col & 7) * 2;
 }
 
 // copy `rows` x 64 bf16 (row stride ld elements) into a swizzled LDS tile; rows >= limit are clamped
@@ -55,7 +60,7 @@ template <int NWAVES>
 __device__ __forceinline__ void stage_rows(const bf16_t* src, int ld, int row0, int limit, int rows, char* tile, int wave, int lane) {
     for (int p = wave; p < rows / 8; p += NWAVES) {
         const int t = p * 8 + (lane >> 3);
-        const int lc = (lane & 7) ^ ((t >> 1) & 7);
+        const int lc = (lane & 7) ^ sw3(t);
         int r = row0 + t;
         r = r < limit ? r : limit - 1;
         __builtin_amdgcn_global_load_lds(GLB_PTR(src + (size_t)r * ld + lc * 8), LDS_PTR(tile + p * 8 * ROWB), 16, 0, 0);
@@ -63,7 +68,7 @@ __device__ __forceinline__ void stage_rows(const bf16_t* src, int ld, int row0, 
 }
 
 __device__ __forceinline__ bf16x8_t row_frag(const char* tile, int row, int kk, int fhi) {
-    return *(const bf16x8_t*)(tile + row * ROWB + ((((kk * 2 + fhi) ^ ((row >> 1) & 7))) << 4));
+    return *(const bf16x8_t*)(tile + row * ROWB + ((((kk * 2 + fhi) ^ sw3(row))) << 4));
 }
 
 __device__ __forceinline__ bf16x8_t pack8(const float* p) {
@@ -568,6 +573,270 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward, 128 x 128 tokens exactly (every 128-token 4M configuration: the bench shape) - round 5.
+// Same two passes and the same dS^T hand-off as attn_bwd_kernel<.., DS = true>, re-cut around what the round-4 counters showed
+// (profiles/r04_pmc_attn.txt: 1 800 VALU instructions per wave = 43 % of a SIMD's issue time with two waves on it, 23 % LDS conflict cycles):
+//   * 5 - 8 VALU per score instead of 15: the forward's (max, sum) enter as ONE addend nm = -(m + log2 l) of the exponent's FMA, the
+//     softmax scale leaves dS (dK and dQ are scaled once at their stores), a blocked score selects a per-QUERY constant pb
+//     (0, or 1 / l in a fully blocked row: exactly what exp2(NEG_FILL - m) / l evaluates to), the decoder rule is one unsigned compare of
+//     (mod_k << 8 | k) - (mod_q << 8) against cs_q, and fully blocked rows are handled OUTSIDE the loop (their Q row is zeroed in LDS, their
+//     dQ row at the store: masked_fill passes no gradient) so dS needs no select;
+//   * per-query constants as separate arrays read with one ds_read_b128 per 4 queries (16 ds_read_b96 per q-block before: 8 LDS cycles each);
+//   * the q-block loop unrolled: every LDS address is a lane constant + an immediate;
+//   * K / V fragments requested in the prologue with everything else (ONE memory round trip), and K reaches pass B from the registers that
+//     hold it (4 ds_write_b128 per lane) instead of through a third dependent global round trip.
+// ------------------------------------------------------------------------------------------------
+template <int MASK>
+__global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
+    constexpr int N = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* T0 = smem;                                     // Q, then K
+    char* T1 = smem + N * ROWB;                          // dO
+    char* dSl = smem + 2 * N * ROWB;                     // dS^T: 2 sub-tiles (64 queries each) x 128 key rows x 128 bytes
+    float* nm_l = (float*)(smem + 4 * N * ROWB);         // -(row max + log2 row sum)
+    float* dl_l = nm_l + N;                              // delta = sum_d dO O
+    float* pb_l = dl_l + N;                              // log2 of the probability of a blocked key: -inf, or -log2 l in a fully blocked row
+    int* wq_l = (int*)(pb_l + N);                        // decoder: (mod_q << 9) + cs_q - 1, cs_q = the query's visible-key bound clamped to [0, 255]
+    int* full_l = wq_l + N;                              // the row is fully blocked
+    int* uk_l = full_l + N;                              // per key - decoder: (mod_k << 9) + k, key padding: blocked
+    // decoder rule in one subtraction: (unsigned)(wq - uk) < 255  <=>  same modality and k < cs_q   (|cs - k - 1| < 256 < 512 = one modality step)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fhi = lane >> 5;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const bf16_t* Qb = a.Q + (size_t)b * N * a.ldq + h * HD;
+    const bf16_t* Kb = a.K + (size_t)b * N * a.ldk + h * HD;
+    const bf16_t* Vb = a.V + (size_t)b * N * a.ldv + h * HD;
+    const bf16_t* Ob = a.O + (size_t)b * N * a.ldo + h * HD;
+    const bf16_t* dOb = a.dO + (size_t)b * N * a.lddo + h * HD;
+
+    stage_rows<4>(Qb, a.ldq, 0, N, N, T0, wave, lane);
+    stage_rows<4>(dOb, a.lddo, 0, N, N, T1, wave, lane);
+    const int key = wave * 32 + (lane & 31);             // pass A: this lane's key
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = *(const bf16x8_t*)(Kb + (size_t)key * a.ldk + (kk * 2 + fhi) * 8);
+        vf[kk] = *(const bf16x8_t*)(Vb + (size_t)key * a.ldv + (kk * 2 + fhi) * 8);
+    }
+    {   // per-query constants: two threads per query row (4 x 16-byte loads each from O and dO)
+        const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
+        const uint4* op = (const uint4*)(Ob + (size_t)q * a.ldo + half * 32);
+        const uint4* gp = (const uint4*)(dOb + (size_t)q * a.lddo + half * 32);
+        uint4 ov[4], gv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ov[i] = op[i]; gv[i] = gp[i]; }
+        const size_t si = ((size_t)b * a.H + h) * N + q;
+        const float m = a.stat_m[si], l = a.stat_l[si];
+        int csv = 255, lov = 0;
+        if constexpr (MASK == FM_MASK_DECODER) {
+            if (a.causal) csv = q + 1;
+            else if (a.cs) csv = min(max(a.cs[(size_t)b * N + q], 0), 255);
+            if (a.modq) lov = (int)a.modq[(size_t)b * N + q] << 9;
+        }
+        if (threadIdx.x < N) {
+            const int k = threadIdx.x;
+            if constexpr (MASK == FM_MASK_DECODER) uk_l[k] = ((a.modk ? (int)a.modk[(size_t)b * N + k] : 0) << 9) + k;
+            else if constexpr (MASK == FM_MASK_KEYPAD) uk_l[k] = a.kpad[(size_t)b * N + k] != 0;
+        }
+        float dl = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t* o32 = (const uint32_t*)&ov[i];
+            const uint32_t* g32 = (const uint32_t*)&gv[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dl += bf2f((bf16_t)(o32[e] & 0xffff)) * bf2f((bf16_t)(g32[e] & 0xffff)) + bf2f((bf16_t)(o32[e] >> 16)) * bf2f((bf16_t)(g32[e] >> 16));
+        }
+        dl += __shfl_xor(dl, 1, 64);
+        if (half == 0) {
+            const bool full = MASK != FM_MASK_NONE && m < -1e38f;      // the forward kept NEG_FILL as the maximum: every key was blocked
+            nm_l[q] = full ? 0.f : -(m + __log2f(l));
+            dl_l[q] = dl;
+            pb_l[q] = full ? -__log2f(l) : -INFINITY;       // log2 of a blocked key's probability: exp2 -> 1 / l, or exactly 0
+            wq_l[q] = lov + csv - 1; full_l[q] = full;
+        }
+    }
+    __syncthreads();
+    if constexpr (MASK != FM_MASK_NONE) {
+        // fully blocked rows (empty samples, decoder rows in front of the first visible token): P = 1 / l on every key, no gradient through
+        // the scores.  Their Q row is zeroed here (no dK contribution; S is irrelevant, every score selects pb), their dQ row at the store.
+        if (__ballot(full_l[lane] | full_l[lane + 64]) != 0ull) {
+            const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
+            if (full_l[q]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(uint4*)(T0 + q * ROWB + half * 64 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+        }
+    }
+
+    // LDS addresses = lane constant + immediate from here on (offsets relative to smem; the q-block / key-block loops are unrolled)
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+    const lds_ptr L = (lds_ptr)smem;
+    constexpr uint32_t oT0 = 0, oT1 = N * ROWB, oDS = 2 * N * ROWB, oNM = 4 * N * ROWB, oDL = oNM + 4 * N, oPB = oDL + 4 * N, oWQ = oPB + 4 * N,
+                       oUK = oWQ + 8 * N;
+    const int r31 = lane & 31;
+    uint32_t rowo[4];                                    // row fragment (MFMA A operand) of row r31, k-step kk
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) rowo[kk] = r31 * ROWB + (((kk * 2 + fhi) ^ sw3(r31)) << 4);
+    uint32_t colo[2][2];                                 // transpose-read base of rows 4 fhi + 8 e + (i >> 2), columns 32 df + ...
+    {
+        const int i = lane & 15;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int df = 0; df < 2; ++df) {
+                const int rl = 4 * fhi + 8 * e + (i >> 2), c = df * 32 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+                colo[e][df] = rl * ROWB + (((c >> 3) ^ sw3(rl)) << 4) + (c & 7) * 2;
+            }
+    }
+    auto col_frag = [&](uint32_t tile, int e0df, int rows) -> bf16x8_t {   // rows rows + 4 fhi + {0..3, 8..11}, columns of block df
+        union { bf16x8_t v; s16x4_t h[2]; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(L + colo[0][e0df] + tile + rows * ROWB));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(L + colo[1][e0df] + tile + rows * ROWB));
+        return u.v;
+    };
+    const float c2 = a.scale * LOG2E;
+    // lane bit set = this lane's key is blocked for ... KEYPAD: every query (a loop constant in two SGPRs); DECODER: per score (v_cmp result)
+    unsigned long long kpmask = 0;
+    int ukey = 0;
+    if constexpr (MASK == FM_MASK_DECODER) ukey = *(const __attribute__((address_space(3))) int*)(L + oUK + 4 * key);
+    if constexpr (MASK == FM_MASK_KEYPAD) kpmask = __ballot(*(const __attribute__((address_space(3))) int*)(L + oUK + 4 * key) != 0);
+    // v_cndmask, never a branch (hipcc turns the ternary on a loop constant into control flow).  Applied to the EXPONENT, in front of
+    // v_exp_f32: hipcc's hazard recogniser does not see inside an asm statement, and a VALU reading a transcendental's result in the next
+    // issue slot gets the stale register on gfx950 (the first form of this kernel selected behind the v_exp and failed exactly so).
+    auto sel = [](float if0, float if1, unsigned long long mask) {
+        float r;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+        return r;
+    };
+    const uint32_t dswo = key * ROWB + (sw3(key) << 4) + 8 * fhi;        // dS^T store of key row `key`: chunk c at dswo ^ (c << 4)
+
+    // ---- pass A: this wave's 32 keys against every query -> dK, dV, dS^T ---------------------------
+    f32x16_t dKt[2], dVt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dKt[i][r] = dVt[i][r] = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const __attribute__((address_space(3))) bf16x8_t*)(L + rowo[kk] + oT0 + qb * 32 * ROWB), kf[kk], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const __attribute__((address_space(3))) bf16x8_t*)(L + rowo[kk] + oT1 + qb * 32 * ROWB), vf[kk], dp, 0, 0, 0);
+        }
+        float pv[16], dsv[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t qo = 4 * (qb * 32 + 8 * g) + 16 * fhi;        // accumulator rows 4 g .. 4 g + 3 = queries 32 qb + 8 g + 4 fhi + 0..3
+            const f32x4_t nm4 = *(const __attribute__((address_space(3))) f32x4_t*)(L + oNM + qo);
+            const f32x4_t dl4 = *(const __attribute__((address_space(3))) f32x4_t*)(L + oDL + qo);
+            f32x4_t pb4 = {0.f, 0.f, 0.f, 0.f};
+            typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+            i32x4_t wq4 = {0, 0, 0, 0};
+            if constexpr (MASK != FM_MASK_NONE) pb4 = *(const __attribute__((address_space(3))) f32x4_t*)(L + oPB + qo);
+            if constexpr (MASK == FM_MASK_DECODER) wq4 = *(const __attribute__((address_space(3))) i32x4_t*)(L + oWQ + qo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                float t = __builtin_fmaf(s[r], c2, nm4[j]);
+                if constexpr (MASK == FM_MASK_KEYPAD) t = sel(t, pb4[j], kpmask);
+                if constexpr (MASK == FM_MASK_DECODER) t = sel(t, pb4[j], __ballot((unsigned)(wq4[j] - ukey) >= 255u));
+                const float p = __builtin_amdgcn_exp2f(t);
+                pv[r] = p;
+                dsv[r] = p * (dp[r] - dl4[j]);
+            }
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)      // this lane's key row, 4 x 4 consecutive queries: 8-byte stores into the swizzled sub-tile
+            *(__attribute__((address_space(3))) u32x2_t*)(L + ((dswo ^ ((((qb & 1) * 4 + g4)) << 4)) + oDS + (qb >> 1) * (N * ROWB))) =
+                u32x2_t{pack2bf(dsv[4 * g4], dsv[4 * g4 + 1]), pack2bf(dsv[4 * g4 + 2], dsv[4 * g4 + 3])};
+#pragma unroll
+        for (int sblk = 0; sblk < 2; ++sblk) {
+            const bf16x8_t pb = pack8(&pv[8 * sblk]), db = pack8(&dsv[8 * sblk]);
+#pragma unroll
+            for (int df = 0; df < 2; ++df) {
+                dVt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(oT1, df, qb * 32 + sblk * 16), pb, dVt[df], 0, 0, 0);
+                dKt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(oT0, df, qb * 32 + sblk * 16), db, dKt[df], 0, 0, 0);
+            }
+        }
+    }
+    {   // lanes l and l+32 own the same key row: 16-byte stores (store_bf16_groups), one output after the other
+        const bool wide_k = (a.lddk & 7) == 0 && (((uintptr_t)a.dK) & 15) == 0;
+        const bool wide_v = (a.lddv & 7) == 0 && (((uintptr_t)a.dV) & 15) == 0;
+        bf16_t* dkrow = a.dK + ((size_t)b * N + key) * a.lddk + h * HD;
+        bf16_t* dvrow = a.dV + ((size_t)b * N + key) * a.lddv + h * HD;
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const f32x16_t& t = which ? dVt[df] : dKt[df];
+                    const float sc = which ? 1.0f : a.scale;            // dS left pass A without the softmax scale
+                    uint2 pk[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        pk[u] = make_uint2(pack2bf(t[4 * (g + u)] * sc, t[4 * (g + u) + 1] * sc), pack2bf(t[4 * (g + u) + 2] * sc, t[4 * (g + u) + 3] * sc));
+                    store_bf16_groups(which ? dvrow : dkrow, df * 32 + 8 * g, pk[0], pk[1], fhi, HD, which ? wide_v : wide_k);
+                }
+    }
+
+    // ---- K takes the place of Q in LDS, from the registers that hold it ---------------------------
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) *(__attribute__((address_space(3))) bf16x8_t*)(L + rowo[kk] + oT0 + wave * 32 * ROWB) = kf[kk];
+    __syncthreads();
+
+    // ---- pass B: dQ = dS K for this wave's 32 queries (dS^T read column-wise: queries = the MFMA's n index) ---
+    {
+        const int qb = wave;
+        const int q = qb * 32 + r31;
+        f32x16_t dQt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
+        const uint32_t sub = oDS + (qb >> 1) * (N * ROWB);
+        // the wave's 32-query half of the sub-tile: colo[.][qb & 1] without a dynamically indexed register array
+        const uint32_t dsc0 = (qb & 1) ? colo[0][1] : colo[0][0], dsc1 = (qb & 1) ? colo[1][1] : colo[1][0];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const int rows = kb * 32 + sblk * 16;
+                union { bf16x8_t v; s16x4_t h[2]; } db;
+                db.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(L + dsc0 + sub + rows * ROWB));
+                db.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(L + dsc1 + sub + rows * ROWB));
+#pragma unroll
+                for (int df = 0; df < 2; ++df) dQt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(oT0, df, rows), db.v, dQt[df], 0, 0, 0);
+            }
+        float sc = a.scale;
+        if constexpr (MASK != FM_MASK_NONE) sc = full_l[q] ? 0.f : sc;
+        const bool wide_q = (a.lddq & 7) == 0 && (((uintptr_t)a.dQ) & 15) == 0;
+        bf16_t* dqrow = a.dQ + ((size_t)b * N + q) * a.lddq + h * HD;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                uint2 pq[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    pq[u] = make_uint2(pack2bf(dQt[df][4 * (g + u)] * sc, dQt[df][4 * (g + u) + 1] * sc),
+                                       pack2bf(dQt[df][4 * (g + u) + 2] * sc, dQt[df][4 * (g + u) + 3] * sc));
+                store_bf16_groups(dqrow, df * 32 + 8 * g, pq[0], pq[1], fhi, HD, wide_q);
+            }
+    }
+}
+
 int fill(AttnArgs& a, const fm_attn_args* p, const char* who) {
     FM_CHECK_ARG(p && p->Q && p->K && p->V && p->O, "%s: null pointer", who);
     FM_CHECK_ARG(p->head_dim == HD, "%s: head_dim=%d unsupported (this build handles 64)", who, p->head_dim);
@@ -641,6 +910,27 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     FM_CHECK_ARG(a.Nq < 0x7fff && a.Nk < 0x7fff, "fm_attn_bwd: sequence too long for the packed 15-bit mask bounds");
     dim3 grid(a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
+    // 128 x 128 tokens exactly (the 128-token 4M configurations): the round-5 kernel; FOURM_ATTN_BWD_V2=0 keeps the general one
+    static const bool v2_on = [] { const char* e = getenv("FOURM_ATTN_BWD_V2"); return !e || atoi(e) != 0; }();
+    if (v2_on && tr && a.Nq == 128 && a.Nk == 128 && a.mask_kind != FM_MASK_DENSE) {
+        const size_t lds128 = (size_t)4 * 128 * ROWB + 6 * 128 * 4;
+#define BWD128(MK)                                                                                                                        \
+    {                                                                                                                                     \
+        auto k = attn_bwd128_kernel<MK>;                                                                                                  \
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);   \
+        (void)once;                                                                                                                       \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds128, (hipStream_t)stream, a);                                                           \
+    }
+        switch (a.mask_kind) {
+            case FM_MASK_NONE: BWD128(FM_MASK_NONE); break;
+            case FM_MASK_KEYPAD: BWD128(FM_MASK_KEYPAD); break;
+            case FM_MASK_DECODER: BWD128(FM_MASK_DECODER); break;
+            default: fm_set_error("fm_attn_bwd: unknown mask kind %d", a.mask_kind); return -1;
+        }
+#undef BWD128
+        FM_CHECK_LAUNCH("fm_attn_bwd");
+        return 0;
+    }
 #define BWD(TR, MK)                                                                                                   \
     if (a.chunk < NPmax) BWD2(TR, MK, true, false) else if (ds) BWD2(TR, MK, false, true) else BWD2(TR, MK, false, false)
 #define BWD2(TR, MK, CH, DSV)                                                                                         \

@@ -32,7 +32,7 @@ if lib.fm_abi_version() != ABI_VERSION:
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
-# enums (keep in sync with the header; tests/test_abi.py cross-checks them against the header text)
+# enums (keep in sync with the header; tests/test_model_cpu.py::test_ctypes_mirrors_match_the_header_layout cross-checks them, the struct layouts and the prototypes against the header)
 EPI_BF16, EPI_GELU, EPI_RESIDUAL, EPI_SWIGLU, EPI_F32, EPI_TANH, EPI_SWIGLU_BWD, EPI_GELU_BWD = 0, 1, 2, 3, 4, 5, 6, 7
 MASK_NONE, MASK_KEYPAD, MASK_DECODER, MASK_DENSE = 0, 1, 2, 3
 KIND_TOK, KIND_PATCH, KIND_SEQ, KIND_SEQ_EMB = 0, 1, 2, 3

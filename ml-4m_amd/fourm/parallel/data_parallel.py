@@ -60,6 +60,11 @@ class GradReducer:
         self._avg = backend == "nccl"          # RCCL averages in the collective; gloo has no AVG
         self._wire_bufs = {}                   # (offset, length) -> bf16 staging buffer, allocated once
         self._shards = {}
+        # measurement hooks (bench.py): events around finish() on the compute stream = the part of the exchange the backward did not hide
+        self.time_exchange = False
+        self._exch_events = []
+        self.n_collectives = 0                 # collectives launched since begin()
+        self.bytes_on_wire = 0                 # payload handed to them since begin()
 
     def _merge(self, ranges):
         out = []
@@ -80,6 +85,19 @@ class GradReducer:
 
     def begin(self):
         self._pending, self._done, self._waiting = [], set(), []
+        self.n_collectives, self.bytes_on_wire = 0, 0
+
+    def exposed_ms(self, clear: bool = True):
+        """Per finish() call: milliseconds the compute stream spent between entering finish() and having every reduced slice back
+        (waiting for collectives that were still running + launching / running the ones that had not started + the unpack kernels).
+        Synchronises.  Only recorded while ``time_exchange`` is set and the store lives on a GPU."""
+        out = []
+        for e0, e1 in self._exch_events:
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        if clear:
+            self._exch_events = []
+        return out
 
     def _exchange(self, t: torch.Tensor, op):
         """Asynchronous collectives that leave the cross-rank reduction of ``t`` in ``t``; returns the work handles."""
@@ -89,11 +107,15 @@ class GradReducer:
             shard = self._shards.get(key)
             if shard is None:
                 shard = self._shards[key] = torch.empty(head // self.world, dtype=t.dtype, device=t.device)
+            self.n_collectives += 2 + (head < t.numel())
+            self.bytes_on_wire += t.numel() * t.element_size()
             works = [dist.reduce_scatter_tensor(shard, t[:head], op=op, group=self.group, async_op=True)]
             works.append(dist.all_gather_into_tensor(t[:head], shard, group=self.group, async_op=True))
             if head < t.numel():
                 works.append(dist.all_reduce(t[head:], op=op, group=self.group, async_op=True))
             return works
+        self.n_collectives += 1
+        self.bytes_on_wire += t.numel() * t.element_size()
         return [dist.all_reduce(t, op=op, group=self.group, async_op=True)]
 
     def stage_done(self, stage: str, flush: bool = False):
@@ -122,6 +144,10 @@ class GradReducer:
 
     def finish(self):
         """Launch whatever stage has not been reported, then wait for every collective."""
+        timed = self.time_exchange and self.flat.is_cuda and (self.world > 1 or self.force)
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for s in self.stages:
             self.stage_done(s)
         if getattr(self, "_waiting", None):       # whatever is still below the launch threshold
@@ -137,6 +163,10 @@ class GradReducer:
             elif not self._avg:
                 t.div_(self.world)
         self._pending = []
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._exch_events.append((e0, e1))
 
 
 # Compute units the persistent GEMM grids leave to the collectives in "overlap" mode: 16 = two per XCD.  Measured on one MI355X
@@ -148,12 +178,22 @@ DEFAULT_RESERVED_CUS = 16
 def cap_collective_channels(n: Optional[int] = None):
     """Call BEFORE the process group's first collective (RCCL reads it when the communicator is created): at most ``n`` channels, so that a
     collective's workgroups fit the CUs DataParallel reserves.  4M-B needs ~2.5 GB over each GPU's links per ~45 ms of backward = 56 GB/s:
-    a fraction of what 16 channels move.  An explicit NCCL_MAX_NCHANNELS in the environment wins."""
+    a fraction of what 16 channels move.  An explicit NCCL_MAX_NCHANNELS in the environment wins; FOURM_DP_CAP_CHANNELS=0 switches the cap
+    off (it is process-wide: every collective of the process group, the tokenizers' codebook all-reduce included, runs on <= n channels);
+    FOURM_DP_EXCHANGE=tail never sets it.  The value is NOT validated on N > 1 hardware: it is printed when it is set, and
+    bench.py records it in ``config.data_parallel``.  Returns the cap it set, else None."""
     import os
     if n is None:
         n = int(os.environ.get("FOURM_DP_RESERVED_CUS", str(DEFAULT_RESERVED_CUS)))
+    if os.environ.get("FOURM_DP_CAP_CHANNELS", "1") == "0" or "NCCL_MAX_NCHANNELS" in os.environ:
+        return None
     if n > 0 and os.environ.get("FOURM_DP_EXCHANGE", "overlap").lower() == "overlap":
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+        os.environ["NCCL_MAX_NCHANNELS"] = str(n)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"[fourm.parallel] NCCL_MAX_NCHANNELS={n} (collectives confined to the {n} CUs the GEMM grids leave free; "
+                  f"FOURM_DP_CAP_CHANNELS=0 or FOURM_DP_EXCHANGE=tail to lift it)", flush=True)
+        return n
+    return None
 
 
 class DataParallel(nn.Module):
@@ -245,6 +285,7 @@ class DataParallel(nn.Module):
             self._reducer = GradReducer(eng.flat_grads, eng.grad_stages(), self.process_group, self._bucket_elems,
                                         algorithm=self._algorithm, wire_dtype=self._wire, force=self._force, min_launch_mb=self._min_launch_mb)
             self._reducer_for = eng.flat_grads
+            self._reducer.time_exchange = bool(getattr(self, "time_exchange", False))
             if eng.flat_grads.is_cuda and dist.get_backend(self.process_group) == "nccl":
                 from fourm.hip import _lib
                 _lib.lib.fm_set_reserved_cus(self._reserved_cus)       # RCCL's kernels run beside the persistent GEMM grids

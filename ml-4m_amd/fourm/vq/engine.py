@@ -165,6 +165,8 @@ def _assign(vq, eng, z, R, G, B, nh, nw, want_quant):
     cb = vq.quantize._codebook
     K = cb.embed.shape[0]
     if getattr(cb, "euclidean", False):
+        if not bool(cb.initted):                             # kmeans_init=True: the first batch initialises the codebook (quantize_lucid.py:271)
+            cb.init_embed_(z[:R], normalize=bool(vq.quantize.norm_latents))
         # Euclidean codebook (norm_codes=False): arg-max of <z, e> - |e|^2 / 2 over the raw codes; norm_latents normalises z first (:525-527)
         splits = max(1, min(16, K // 1024))
         wv = ws.get("vq.wv", (R, splits), torch.float32)
@@ -333,7 +335,10 @@ def vqvae_train_forward(vq, x):
     dec = _decode_rows(vq, q_rows, B, nh, nw, st["dec"])
     st.update(z=z, tokens=tokens, x_enc_final=stream, dims=(B, nh, nw), embed_at_forward=cb.embed.clone() if vq.quantize.training else cb.embed)
     if vq.quantize.training:
-        cb.ema_update_(z[:R], tokens)                      # after the code assignment, as upstream (quantize_lucid.py:409-426)
+        if getattr(cb, "euclidean", False):                # (the Euclidean codebook sees l2norm(z) when norm_latents: quantize_lucid.py:525-527)
+            cb.ema_update_(z[:R], tokens, normalize=bool(vq.quantize.norm_latents))
+        else:
+            cb.ema_update_(z[:R], tokens)                  # after the code assignment, as upstream (quantize_lucid.py:409-426)
     return dec, code_loss, st
 
 

@@ -131,22 +131,67 @@ class EuclideanCodebook(nn.Module):
         super().__init__()
         if learnable_codebook or sample_codebook_temp:
             raise NotImplementedError("learnable / sampled codebooks are not implemented")
-        if kmeans_init:
-            raise NotImplementedError("k-means initialisation is implemented for the cosine-similarity codebook only")
         self.decay, self.codebook_size, self.eps, self.kmeans_iters = decay, codebook_size, eps, kmeans_iters
         self.threshold_ema_dead_code, self.code_replacement_policy, self.use_ddp = threshold_ema_dead_code, code_replacement_policy, use_ddp
         self.epoch = 0
-        embed = torch.empty(codebook_size, dim)
-        nn.init.kaiming_uniform_(embed)                      # upstream uniform_init (:58-61)
-        self.register_buffer("initted", torch.Tensor([True]))
+        if kmeans_init:                                      # upstream: zeros until the first batch ran k-means (:196-197, :208); a checkpoint brings initted = 1
+            embed = torch.zeros(codebook_size, dim)
+        else:
+            embed = torch.empty(codebook_size, dim)
+            nn.init.kaiming_uniform_(embed)                  # upstream uniform_init (:58-61)
+        self.register_buffer("initted", torch.Tensor([not kmeans_init]))
         self.register_buffer("cluster_size", torch.zeros(codebook_size))
         self.register_buffer("embed_avg", embed.clone())
         self.register_buffer("embed", embed)
 
     euclidean = True
 
-    def init_embed_(self, z, generator=None, init_index=None):
-        return                                               # (initted from construction: no k-means path)
+    @torch.no_grad()
+    def init_embed_(self, z, generator=None, init_index=None, normalize=False):
+        """k-means initialisation from the first batch (upstream ``init_embed_`` :220-231 -> ``kmeans`` :137-167 with Euclidean distances):
+        means = K random latents, ``kmeans_iters`` rounds of  nearest mean -> per-cluster mean (empty clusters keep theirs); then
+        ``embed = embed_avg = means``, ``cluster_size = the last round's counts``.  Assignment and statistics are the training step's
+        kernels (fm_vq_assign_bias, fm_vq_code_stats[_raw]).  z: f32 (R, d) latents (normalize: ``norm_latents`` models quantize l2norm(z))."""
+        import torch.distributed as dist
+        from fourm.hip import _lib as L, ops
+        if bool(self.initted):
+            return
+        multi = self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        z = z.reshape(-1, z.shape[-1]).float().contiguous()
+        K, D = self.embed.shape
+        R = z.shape[0]
+        if normalize:
+            zn = torch.empty_like(z)
+            L.check(L.l2norm_rows(ops._p(z), z.stride(0), ops._p(zn), zn.stride(0), R, D, ops._stream()))
+            z = zn
+        if init_index is None:
+            if multi:
+                raise NotImplementedError("distributed sampling of the initial means (sample_vectors_distributed) is not implemented: pass init_index")
+            init_index = torch.randperm(R, device=z.device, generator=generator)[:K] if R >= K else torch.randint(0, R, (K,), device=z.device, generator=generator)
+        idx = init_index.to(device=z.device, dtype=torch.int64).contiguous()
+        means = torch.empty(K, D, dtype=torch.float32, device=z.device)
+        L.check(L.embed_rows_f32(ops._p(z), ops._p(idx), ops._p(means), means.stride(0), K, D, ops._stream()))
+        bins = torch.empty(K, dtype=torch.float32, device=z.device)
+        sums = torch.empty(K, D, dtype=torch.float32, device=z.device)
+        bias = torch.empty(K, dtype=torch.float32, device=z.device)
+        splits = max(1, min(16, K // 1024))
+        wv = torch.empty(R, splits, dtype=torch.float32, device=z.device)
+        wi = torch.empty(R, splits, dtype=torch.int32, device=z.device)
+        tokens = torch.empty(R, dtype=torch.int64, device=z.device)
+        for _ in range(self.kmeans_iters):
+            L.check(L.vq_code_bias(ops._p(means), K, D, ops._p(bias), ops._stream()))
+            L.check(L.vq_assign_bias(ops._p(z), z.stride(0), ops._p(means), ops._p(bias), ops._p(means), K, D, R, 1, 0, ops._p(wv), ops._p(wi), splits,
+                                     ops._p(tokens), None, ops._stream()))
+            L.check(L.vq_code_stats_raw(ops._p(z), z.stride(0), ops._p(tokens), R, D, K, ops._p(bins), ops._p(sums), ops._stream()))
+            if multi:
+                dist.all_reduce(bins)
+                dist.all_reduce(sums)
+            means = torch.where((bins == 0)[:, None], means, sums / bins.clamp(min=1)[:, None])
+        self.embed.copy_(means)
+        self.embed_avg.copy_(means)
+        self.cluster_size.copy_(bins)
+        self.initted.fill_(1.0)
+        self.epoch += 1
 
     @torch.no_grad()
     def code_bias(self):
@@ -161,9 +206,11 @@ class EuclideanCodebook(nn.Module):
         return c[1]
 
     @torch.no_grad()
-    def ema_update_(self, z, tokens, generator=None):
-        """Training branch of upstream ``forward`` (:282-297): counts and sums of the (un-normalised) latents per code, EMAs of ``cluster_size``
-        and ``embed_avg``, ``embed = embed_avg / Laplace-smoothed cluster size``, then ``expire_codes_``."""
+    def ema_update_(self, z, tokens, generator=None, normalize=False):
+        """Training branch of upstream ``forward`` (:282-297): counts and sums of the latents per code, EMAs of ``cluster_size``
+        and ``embed_avg``, ``embed = embed_avg / Laplace-smoothed cluster size``, then ``expire_codes_``.  The codebook itself never
+        normalises; ``normalize=True`` is ``VectorQuantize(norm_latents=True)``, whose forward hands the codebook l2norm(z) (:525-527):
+        the sums are then over the normalised rows (fm_vq_code_stats instead of fm_vq_code_stats_raw)."""
         import torch.distributed as dist
         from fourm.hip import _lib as L, ops
         z = z.reshape(-1, z.shape[-1])
@@ -175,7 +222,8 @@ class EuclideanCodebook(nn.Module):
         bins = torch.empty(K, dtype=torch.float32, device=z.device)
         sums = torch.empty(K, D, dtype=torch.float32, device=z.device)
         total = torch.empty(1, dtype=torch.float32, device=z.device)
-        L.check(L.vq_code_stats_raw(ops._p(z), z.stride(0), ops._p(tokens), R, D, K, ops._p(bins), ops._p(sums), ops._stream()))
+        stats = L.vq_code_stats if normalize else L.vq_code_stats_raw
+        L.check(stats(ops._p(z), z.stride(0), ops._p(tokens), R, D, K, ops._p(bins), ops._p(sums), ops._stream()))
         multi = self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if multi:
             dist.all_reduce(bins)

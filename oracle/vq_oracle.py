@@ -300,3 +300,21 @@ def kmeans_cosine(samples: Tensor, init_index: Tensor, num_iters: int = 10):
         new = F.normalize(new / bins.masked_fill(zero, 1)[:, None], p=2, dim=-1)
         means = torch.where(zero[:, None], means, new)
     return means, bins
+
+
+def kmeans_euclid(samples: Tensor, init_index: Tensor, num_iters: int = 10):
+    """Upstream ``kmeans`` (quantize_lucid.py:137-167) with use_cosine_sim=False (``EuclideanCodebook.init_embed_``, :220-231) and the
+    sampled initial means made explicit: nearest mean by -(x - m)^2 (first index on ties), per-cluster mean, empty clusters keep theirs.
+    Returns (means (K, d), bins (K) int64)."""
+    means = samples[init_index]
+    K, d = means.shape
+    bins = None
+    for _ in range(num_iters):
+        dists = -((samples[:, None, :] - means[None, :, :]) ** 2).sum(-1)
+        buckets = dists.argmax(-1)
+        bins = torch.bincount(buckets, minlength=K)
+        zero = bins == 0
+        new = torch.zeros(K, d, dtype=samples.dtype).scatter_add_(0, buckets[:, None].expand(-1, d), samples)
+        new = new / bins.masked_fill(zero, 1)[:, None]
+        means = torch.where(zero[:, None], means, new)
+    return means, bins

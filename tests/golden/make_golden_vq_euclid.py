@@ -72,6 +72,38 @@ def main():
     o_loss = torch.nn.functional.mse_loss(oq, z1[: 4 * 196])
     assert abs(float(loss) - float(o_loss)) < 1e-6 * float(o_loss)
     fx.update(vq_tokens=tok.numpy(), vq_loss=np.float32(float(loss)))
+    # norm_latents=True with the Euclidean codebook (VectorQuantize.forward hands the codebook l2norm(x), :525-527): the EMA sums are over the
+    # NORMALISED latents.  Two training forwards of the unmodified wrapper; the oracle follows with l2norm(z) in its Euclidean functions.
+    vqn = RefVQn(dim=D, codebook_size=K, decay=decay, eps=eps, use_cosine_sim=False, threshold_ema_dead_code=0, commitment_weight=1.0, norm_latents=True)
+    vqn._codebook.embed.copy_(embed0); vqn._codebook.embed_avg.copy_(embed0)
+    vqn.train()
+    avg, cluster, emb = embed0.clone(), torch.zeros(K), embed0.clone()
+    for step, z in enumerate((z1, z2)):
+        xs = z[: 4 * 196].reshape(4, 14, 14, D).permute(0, 3, 1, 2).contiguous()
+        with torch.no_grad():
+            _, loss_n, tok_n = vqn(xs)
+        zn = torch.nn.functional.normalize(z[: 4 * 196], p=2, dim=-1)
+        oi, oq, _ = V.assign_codes_euclid(zn, emb)
+        assert torch.equal(tok_n.reshape(-1), oi), "oracle (norm_latents) assignment differs from upstream"
+        assert abs(float(loss_n) - float(torch.nn.functional.mse_loss(oq, zn))) < 1e-6 * float(loss_n)
+        emb, avg, cluster = V.codebook_ema_update_euclid(avg, cluster, zn, oi, decay, eps)
+        for name, a_, b_ in (("embed", vqn._codebook.embed, emb), ("embed_avg", vqn._codebook.embed_avg, avg), ("cluster_size", vqn._codebook.cluster_size, cluster)):
+            err = float((a_ - b_).abs().max() / (b_.abs().max() + 1e-30))
+            assert err < 2e-6, ("norm_latents", step, name, err)
+        fx[f"nl_ind{step}"] = tok_n.reshape(-1).numpy()
+        fx[f"nl_embed_after{step}"], fx[f"nl_embed_avg_after{step}"], fx[f"nl_cluster_after{step}"] = (
+            vqn._codebook.embed.numpy().copy(), vqn._codebook.embed_avg.numpy().copy(), vqn._codebook.cluster_size.numpy().copy())
+    # kmeans_init=True: upstream's init_embed_ with the random sample of initial means replaced by a fixed index set
+    Kk, iters = 64, 4
+    gi = torch.Generator().manual_seed(5)
+    init_index = torch.randperm(R, generator=gi)[:Kk]
+    cbk = RefEuclid(dim=D, codebook_size=Kk, kmeans_init=True, kmeans_iters=iters, decay=decay, eps=eps, threshold_ema_dead_code=0)
+    assert not bool(cbk.initted) and float(cbk.embed.abs().max()) == 0
+    cbk.sample_fn = lambda samples, num: samples[init_index]
+    cbk.init_embed_(z1)
+    means, bins = V.kmeans_euclid(z1, init_index, iters)
+    assert float((cbk.embed - means).abs().max()) < 1e-6 and torch.equal(cbk.cluster_size, bins.float()) and bool(cbk.initted)
+    fx.update(km_K=Kk, km_iters=iters, km_init_index=init_index.numpy(), km_embed=cbk.embed.numpy().copy(), km_cluster=cbk.cluster_size.numpy().copy())
     path = os.path.join(HERE, "vq_euclid.npz")
     if a.check:
         old = np.load(path)

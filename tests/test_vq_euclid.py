@@ -41,6 +41,26 @@ def test_oracle_reproduces_upstream_fixture():
             assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max()), (step, name)
 
 
+def test_oracle_norm_latents_and_kmeans_reproduce_upstream_fixture():
+    """norm_latents=True (the codebook sees l2norm(z): EMA sums over the NORMALISED latents) and kmeans_init=True, both dumped from the
+    unmodified upstream classes."""
+    fx = fixture()
+    K, D = int(fx["K"]), int(fx["D"])
+    z1, z2 = latents(int(fx["R"]), D)
+    embed0 = torch.from_numpy(fx["embed0"])
+    emb, avg, cluster = embed0.clone(), embed0.clone(), torch.zeros(K)
+    for step, z in enumerate((z1, z2)):
+        zn = torch.nn.functional.normalize(z[: 4 * 196], p=2, dim=-1)
+        ind, _, _ = V.assign_codes_euclid(zn, emb)
+        assert np.array_equal(ind.numpy(), fx[f"nl_ind{step}"])
+        emb, avg, cluster = V.codebook_ema_update_euclid(avg, cluster, zn, ind, float(fx["decay"]), float(fx["eps"]))
+        for name, got in (("embed", emb), ("embed_avg", avg), ("cluster", cluster)):
+            want = torch.from_numpy(fx[f"nl_{name}_after{step}"])
+            assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max()), (step, name)
+    means, bins = V.kmeans_euclid(z1, torch.from_numpy(fx["km_init_index"]), int(fx["km_iters"]))
+    assert float((means - torch.from_numpy(fx["km_embed"])).abs().max()) < 1e-6 and np.array_equal(bins.float().numpy(), fx["km_cluster"])
+
+
 def test_constructor_builds_the_euclidean_codebook_with_upstream_buffers():
     from fourm.vq import VQ
     from fourm.vq.quantizers.quantize_lucid import EuclideanCodebook
@@ -50,6 +70,11 @@ def test_constructor_builds_the_euclidean_codebook_with_upstream_buffers():
     keys = {k for k in m.state_dict() if k.startswith("quantize.")}
     assert keys == {"quantize._codebook.initted", "quantize._codebook.cluster_size", "quantize._codebook.embed_avg", "quantize._codebook.embed"}
     assert torch.equal(cb.embed, cb.embed_avg) and bool(cb.initted)
+    # kmeans_init=True constructs like upstream (zeros, initted = 0: quantize_lucid.py:196-208), so a checkpoint of such a tokenizer loads
+    ck = EuclideanCodebook(dim=32, codebook_size=64, kmeans_init=True)
+    assert not bool(ck.initted) and float(ck.embed.abs().max()) == 0 and float(ck.embed_avg.abs().max()) == 0
+    ck.load_state_dict(cb.state_dict())
+    assert bool(ck.initted) and torch.equal(ck.embed, cb.embed)
 
 
 @pytest.mark.gpu
@@ -79,6 +104,32 @@ def test_hip_assignment_and_ema_match_upstream():
         for name, got in (("embed", cb.embed), ("embed_avg", cb.embed_avg), ("cluster", cb.cluster_size)):
             want = torch.from_numpy(fx[f"{name}_after{step}"]).cuda()
             assert float((got - want).abs().max()) < 5e-6 * float(want.abs().max()), (step, name)
+
+
+@pytest.mark.gpu
+def test_hip_ema_with_normalised_latents_and_kmeans_init_match_upstream():
+    """VectorQuantize(norm_latents=True) over the Euclidean codebook accumulates l2norm(z); kmeans_init=True runs upstream's
+    Euclidean k-means on the first batch.  Both against the fixture of the unmodified classes."""
+    from fourm.vq.quantizers.quantize_lucid import EuclideanCodebook
+    fx = fixture()
+    K, D, R = int(fx["K"]), int(fx["D"]), int(fx["R"])
+    z1, z2 = (t.cuda() for t in latents(R, D))
+    cb = EuclideanCodebook(dim=D, codebook_size=K, decay=float(fx["decay"]), eps=float(fx["eps"]), threshold_ema_dead_code=0).cuda()
+    cb.embed.copy_(torch.from_numpy(fx["embed0"])); cb.embed_avg.copy_(cb.embed)
+    for step, z in enumerate((z1, z2)):
+        ind = torch.from_numpy(fx[f"nl_ind{step}"]).cuda()
+        cb.ema_update_(z[: 4 * 196].contiguous(), ind, normalize=True)
+        for name, got in (("embed", cb.embed), ("embed_avg", cb.embed_avg), ("cluster", cb.cluster_size)):
+            want = torch.from_numpy(fx[f"nl_{name}_after{step}"]).cuda()
+            assert float((got - want).abs().max()) < 5e-6 * float(want.abs().max()), (step, name)
+    ck = EuclideanCodebook(dim=D, codebook_size=int(fx["km_K"]), kmeans_init=True, kmeans_iters=int(fx["km_iters"]), threshold_ema_dead_code=0).cuda()
+    ck.init_embed_(z1, init_index=torch.from_numpy(fx["km_init_index"]).cuda())
+    assert bool(ck.initted)
+    want = torch.from_numpy(fx["km_embed"]).cuda()
+    # (a near-tie of two means may move one sample between clusters under the kernel's <z, e> - |e|^2 / 2 form: means to 1e-3, counts to 2)
+    assert float((ck.embed - want).abs().max()) < 1e-3 * float(want.abs().max()), float((ck.embed - want).abs().max())
+    assert float((ck.cluster_size - torch.from_numpy(fx["km_cluster"]).cuda()).abs().max()) <= 2
+    assert torch.equal(ck.embed, ck.embed_avg)
 
 
 @pytest.mark.gpu
