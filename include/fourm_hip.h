@@ -486,7 +486,7 @@ int fm_decoder_attention_from_target(const void* target_mask, int32_t* decoder_a
  * thread.  The caller draws:  main_draws f32 (B, T, M) - the Dirichlet sample of try t;  extra_draws f32 (B, T, E, M) - the
  * sample_n(diff) draws of try t (the first diff = n - sum(floor(p * n)) rows are used, E >= M covers every case).
  *   budget = floor(p * n) + bincount(argmax(extra[:diff])), clamped to max_tokens[m]; the first try with budget >= min_tokens everywhere is
- *   taken, else the last one (tries (B), optional: the number of tries consumed).
+ *   taken, else the last one (tries (B), optional: the number of tries consumed; T + 1 = none fitted).
  * Target budgets: pass input_budget int32 (B, M) and is_img uint8 (M): the clamp becomes max(min_tokens, max_tokens - input_budget) for
  * image-like modalities (:218-219).  Input budgets: input_budget = NULL.  M <= 64. */
 int fm_token_budgets(const void* main_draws, const void* extra_draws, const int32_t* num_tokens, const int32_t* min_tokens,
@@ -504,7 +504,7 @@ int fm_token_budgets(const void* main_draws, const void* extra_draws, const int3
  *   input_budget (B);  target_budget (B) or NULL (= None; an entry < 0 = None for that sample);  r_choice (B) or NULL: the integer that
  *     replaces np.random.randint (taken modulo its argument, :425);  sentinel_ids[k] = sentinel_to_id[k].
  * Outputs, each (B, 2 * (max_tokens + 1)): tensor int32 (pad_id where empty), input_mask / target_mask uint8 (1 = masked out),
- * decoder_attention_mask int32;  tries (B) optional: draws consumed, -1 = more spans than sentinel ids (upstream raises KeyError).
+ * decoder_attention_mask int32;  tries (B) optional: draws consumed (T + 1 = they ran out: everything masked), -1 = more spans than sentinel ids (upstream raises KeyError).
  * Embedding mode (emb != NULL; sequence_emb_mask_span): emb f32 (B, emb_rows, emb_dim) with len (B); ids / unit / tensor / target_budget
  * unused; outputs are (B, max_tokens): input_mask, target_mask (all 1), decoder_attention_mask (all 0), src int32 (the source row of every
  * position, -1 = zero row) and emb_out f32 (B, max_tokens, emb_dim). */

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64) void token_budget_kernel(const float* __restric
     if (b >= B) return;
     const int n = num_tokens[b];
     int bud[BUDGET_MAX_MODS];
-    int used = T;
+    int used = T + 1;                      // no try met every minimum: the last one is kept and reported as T + 1
     for (int t = 0; t < T; ++t) {
         const float* p = main_draws + ((size_t)b * T + t) * M;
         int sum = 0;
@@ -271,14 +271,14 @@ __global__ __launch_bounds__(64) void span_mask_kernel(SpanArgs a) {
             cnt = wave_sum(cnt);
             if (cnt <= kin) break;
             kp = kp * 0.9;
-            if (++t >= a.T) { all_masked = true; t = a.T - 1; break; }   // (no draws left: everything masked, the limit kp -> 0)
+            if (++t >= a.T) { all_masked = true; break; }               // (no draws left: everything masked, the limit kp -> 0; reported as T + 1)
         }
     }
     if (lane == 0 && a.tries) a.tries[b] = t + 1;
 
     // ---- input and target sequences (simple_span_masking :73-91) ------------------------------------------------------------------------
     const float kpf = (float)kp;
-    const float* row = nz + (size_t)t * a.ld_noise;
+    const float* row = nz + (size_t)(all_masked ? 0 : t) * a.ld_noise;
     int kept_b = 0, masked_b = 0, starts_b = 0;             // counts over the tokens before the current group of 64
     for (int base = 0; base < n; base += 64) {
         const int l = base + lane;

@@ -253,7 +253,7 @@ class DeviceUnifiedMasking:
         if st is None or st.device != tries.device:
             st = self._tries_stat = torch.zeros(2, dtype=torch.int64, device=tries.device)
         st[0] += (tries < 0).sum()
-        st[1] += (tries >= limit).sum()
+        st[1] += (tries > limit).sum()                 # the kernels report limit + 1 when the draws ran out (limit = a fit on the last one)
 
     def check(self, raise_on_overflow: bool = True):
         """Synchronise once and report what the retry counters saw since the last check: raises on sentinel overflow (a batch with
@@ -265,7 +265,7 @@ class DeviceUnifiedMasking:
         overflow, exhausted = (int(v) for v in st.tolist())
         st.zero_()
         if exhausted:
-            print(f"[DeviceUnifiedMasking] {exhausted} samples exhausted their retries (upstream: 'More than max tries')")
+            print(f"[DeviceUnifiedMasking] {exhausted} samples exhausted their retries (upstream: 'More than max tries')", force=True)
         if overflow and raise_on_overflow:
             raise KeyError(f"{overflow} samples needed more sentinel ids than the tokenizer provides (upstream raises KeyError in the masking transform)")
         return (overflow, exhausted)

@@ -369,7 +369,10 @@ class FourMEngine:
             out_f, in_f = p.shape[0], p[0].numel()
             buf = torch.zeros(ru(out_f, 64) if pad_rows else out_f, ru(in_f, 64), dtype=torch.bfloat16, device=p.device)
             return Shadow(buf, (p,), [(p, buf, False)])
-        return self._get_shadow(("w", id(p)), make)
+        s = self._get_shadow(("w", id(p)), make)
+        # one image per weight: the first request fixes its row count; a padded request on an unpadded image would let the GEMM read past it
+        assert not pad_rows or s.shape[0] >= ru(p.shape[0], 64), "w(): the cached image was created without pad_rows"
+        return s
 
     def wt(self, p, pad_rows=False):
         """(in, out_p) bf16, pad columns zero: the W operand of dX = dY W.  pad_rows: ru(in, 64) rows, the extra ones zero."""
@@ -379,7 +382,9 @@ class FourMEngine:
             out_f, in_f = p.shape[0], p[0].numel()
             buf = torch.zeros(ru(in_f, 64) if pad_rows else in_f, ru(out_f, 64), dtype=torch.bfloat16, device=p.device)
             return Shadow(buf, (p,), [(p, buf, True)])
-        return self._get_shadow(("wt", id(p)), make)
+        s = self._get_shadow(("wt", id(p)), make)
+        assert not pad_rows or s.shape[0] >= ru(p[0].numel(), 64), "wt(): the cached image was created without pad_rows"
+        return s
 
     def w_fold(self, lin, norm):
         """(out, in_p) image of lin.weight * norm.weight[None, :] - the W operand of y = x_hat (W diag(gamma))^T (context-norm hoist)."""

@@ -37,7 +37,10 @@ class GradReducer:
 
     def __init__(self, flat: torch.Tensor, ranges_by_stage: Dict[str, Sequence[Tuple[int, int]]], group=None,
                  bucket_elems: int = 64 * 1024 * 1024, algorithm: str = "all_reduce", wire_dtype=None, force: bool = False,
-                 min_launch_mb: float = 0.0):
+                 min_launch_mb: float = 0.0, pack=None, unpack=None):
+        """``pack(src_f32, dst_wire)`` / ``unpack(src_wire, dst_f32, scale)``: the wire-format conversions; default = the HIP kernels
+        fm_f32_to_bf16 / fm_bf16_to_f32_scaled on the compute stream (the CPU tests of the bucketing logic inject torch copies: there is
+        no other implementation behind the default)."""
         if algorithm not in ("all_reduce", "reduce_scatter"):
             raise ValueError(f"algorithm {algorithm!r}")
         if wire_dtype not in (None, torch.float32, torch.bfloat16):
@@ -58,6 +61,7 @@ class GradReducer:
         self.min_launch_elems = (1 << 62) if min_launch_mb == float("inf") else int(min_launch_mb * 1024 * 1024 // 4)
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"          # RCCL averages in the collective; gloo has no AVG
+        self._pack, self._unpack = pack, unpack
         self._wire_bufs = {}                   # (offset, length) -> bf16 staging buffer, allocated once
         self._shards = {}
         # measurement hooks (bench.py): events around finish() on the compute stream = the part of the exchange the backward did not hide
@@ -110,6 +114,9 @@ class GradReducer:
             self.n_collectives += 2 + (head < t.numel())
             self.bytes_on_wire += t.numel() * t.element_size()
             works = [dist.reduce_scatter_tensor(shard, t[:head], op=op, group=self.group, async_op=True)]
+            if not self._avg:
+                works[0].wait()       # gloo runs asynchronous collectives on worker threads without ordering them (the world-size-4 test read an
+                                      # unwritten shard); RCCL enqueues both on one stream, in order
             works.append(dist.all_gather_into_tensor(t[:head], shard, group=self.group, async_op=True))
             if head < t.numel():
                 works.append(dist.all_reduce(t[head:], op=op, group=self.group, async_op=True))
@@ -136,7 +143,7 @@ class GradReducer:
                 w = self._wire_bufs.get((o, n))
                 if w is None:
                     w = self._wire_bufs[(o, n)] = torch.empty(n, dtype=self.wire, device=t.device)
-                ops.f32_to_bf16(t, w)                                   # pack on the compute stream, behind the gradient kernels
+                (self._pack or ops.f32_to_bf16)(t, w)                   # pack on the compute stream, behind the gradient kernels
                 self._pending.append((self._exchange(w, dist.ReduceOp.SUM), t, w))
             else:
                 op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -159,7 +166,7 @@ class GradReducer:
                 work.wait()
             if w is not None:
                 from fourm.hip import ops
-                ops.bf16_to_f32_scaled(w, t, 1.0 / self.world)          # unpack + mean into the fp32 gradient store
+                (self._unpack or ops.bf16_to_f32_scaled)(w, t, 1.0 / self.world)          # unpack + mean into the fp32 gradient store
             elif not self._avg:
                 t.div_(self.world)
         self._pending = []

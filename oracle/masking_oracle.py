@@ -45,7 +45,7 @@ def token_budget(main_draws, extra_draws, num_tokens, min_tokens, max_tokens):
         budget = np.minimum(budget, mx)
         if (budget >= mn).all():
             return budget.astype(np.int32), t + 1
-    return budget.astype(np.int32), T
+    return budget.astype(np.int32), T + 1          # no try met the minimum: the last one is kept, reported as T + 1 (success on the last try: T)
 
 
 # ---- span masking ---------------------------------------------------------------------------------------------------------------
@@ -96,7 +96,7 @@ def _masked_sequences(tokens, unit_of, input_budget, keep_prob, noise, sentinel_
             inp, tgt = span_masking(tokens, unit_of, np.full(len(noise[0]), 2.0, dtype=F), 0.0, sentinel_to_id)
             break
         inp, tgt = span_masking(tokens, unit_of, noise[t], kp, sentinel_to_id)
-    return inp, tgt, min(t + 1, len(noise))
+    return inp, tgt, t + 1                  # (T + 1 when the draws ran out, T for a fit on the last one)
 
 
 def sequence_mask(tokens, max_tokens, input_budget, target_budget, keep_prob, noise, r_choice, sentinel_to_id, pad_id,

@@ -177,7 +177,7 @@ def test_budget_oracle_matches_upstream_fixture():
         assert np.array_equal(b, g["bud/out"][c]) and tries == int(g["bud/tries"][c]), c
         if bool(g["bud/is_target"][c]):
             assert np.array_equal(MO.max_tokens_remaining(g["bud/is_img"], g["bud/max_tokens"], g["bud/min"][c], g["bud/in_budget"][c]), g["bud/max"][c])
-    assert {1, 2, 6} <= set(g["bud/tries"].tolist())
+    assert {1, 2, 7} <= set(g["bud/tries"].tolist())          # 7 = T + 1: none of the 6 recorded draws met the minimum (upstream keeps the last)
 
 
 def test_span_oracle_matches_upstream_fixture():

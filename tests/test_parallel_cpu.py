@@ -62,6 +62,48 @@ def test_grad_reducer_tail_exchange_gloo(tmp_path):
         assert torch.allclose(torch.load(tmp_path / f"r{rank}_w1.pt")[:950], (base * 1.5 + 1)[:950])
 
 
+def _worker4(rank, world, port, n, stages, bucket, out_dir, algorithm, wire):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fourm.parallel import GradReducer
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(n, generator=g)
+    torch.save(flat.clone(), os.path.join(out_dir, f"in{rank}.pt"))
+    kw = {}
+    if wire is not None:        # the wire-format kernels are HIP (fm_f32_to_bf16 / fm_bf16_to_f32_scaled); the bucketing logic under test is not
+        kw = dict(wire_dtype=wire, pack=lambda src, dst: dst.copy_(src), unpack=lambda src, dst, scale: dst.copy_(src.float() * scale))
+    red = GradReducer(flat, stages, bucket_elems=bucket, algorithm=algorithm, min_launch_mb=0.0, **kw)
+    red.begin()
+    for s in ["b", "a"]:
+        red.stage_done(s)
+    red.finish()
+    torch.save(dict(flat=flat.clone(), n_coll=red.n_collectives, wire_bytes=red.bytes_on_wire), os.path.join(out_dir, f"out{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algorithm,wire", [("reduce_scatter", None), ("reduce_scatter", torch.bfloat16), ("all_reduce", torch.bfloat16)])
+def test_grad_reducer_world_size_four(tmp_path, algorithm, wire):
+    """World size 4: reduce-scatter + all-gather of every bucket (heads that do not divide by 4 leave a tail to
+    all_reduce) and the bf16 wire format (one rounding of each rank's slice, summed in bf16 on the wire, mean in fp32)."""
+    n, world = 1003, 4
+    stages = {"a": [(0, 101), (101, 200)], "b": [(301, 498)], "c": [(800, 150)]}      # odd lengths: 301 = 75 * 4 + 1, 498 = 124 * 4 + 2, 150 = 37 * 4 + 2
+    mp.spawn(_worker4, args=(world, _free_port(), n, stages, 128, str(tmp_path), algorithm, wire), nprocs=world, join=True)
+    ins = [torch.load(tmp_path / f"in{r}.pt") for r in range(world)]
+    if wire is None:
+        want = sum(ins) / world
+    else:       # every rank's slice is rounded once, the ranks are summed (bf16 partial sums on the wire), the mean is taken in fp32
+        want = sum(t.to(torch.bfloat16).float() for t in ins) / world
+    for rank in range(world):
+        out = torch.load(tmp_path / f"out{rank}.pt")
+        got = out["flat"]
+        tol = dict(rtol=1e-6, atol=1e-6) if wire is None else dict(rtol=2e-2, atol=2e-2)     # bf16 accumulation across 4 ranks
+        for o, k in ((0, 301), (301, 498), (800, 150)):
+            assert torch.allclose(got[o:o + k], want[o:o + k], **tol), (rank, o)
+        assert torch.equal(got[950:], ins[rank][950:]) and torch.equal(got[799:800], ins[rank][799:800])      # outside every stage
+        assert out["n_coll"] >= 3 and out["wire_bytes"] == 949 * (2 if wire is not None else 4)
+    assert all(torch.equal(torch.load(tmp_path / "out0.pt")["flat"][:799], torch.load(tmp_path / f"out{r}.pt")["flat"][:799]) for r in range(1, world))
+
+
 def test_reducer_rejects_overlapping_stages():
     from fourm.parallel import GradReducer
     with pytest.raises(ValueError):
