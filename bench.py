@@ -182,7 +182,17 @@ def cpu_baseline(timeout_s=300, workload="train"):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", workload], capture_output=True, text=True,
                            timeout=timeout_s, env={**os.environ, "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)
+        rec = json.loads(line)
+        if rec.get("kind") == "port" and workload == "train":
+            # measured in the build container, where both exist (tools/cpu_port_vs_reference.py): what the port's number means in
+            # units of the unmodified reference on the same cores
+            try:
+                conv = json.load(open(os.path.join(ROOT, "profiles", "r05_cpu_port_vs_reference.json")))
+                rec["port_vs_reference"] = {"port_over_reference": conv["port_over_reference"], "measured_on": conv["cpu"], "cores": conv["cores"],
+                                            "source": "profiles/r05_cpu_port_vs_reference.txt"}
+            except Exception:      # noqa: BLE001
+                pass
+        return rec
     except Exception as e:
         return {"value": None, "unit": "images/s" if workload == "vq" else "tokens/s", "cores": os.cpu_count(), "kind": "port",
                 "reference_available": os.path.isdir(REFERENCE_TREE),
@@ -474,6 +484,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--no-extras", action="store_true", help="headline record only (default for non-default workloads): no extra.vq / extra.mod21 sub-records")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-kind", default="auto", choices=["auto", "port", "reference"], help=argparse.SUPPRESS)
     ap.add_argument("--pmc-worker", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     a.user_batch = a.batch
@@ -489,7 +500,7 @@ def main():
             print(json.dumps(cpu_baseline_vq_worker()))
         elif a.workload == "train21":
             print(json.dumps(cpu_baseline_mod21_worker()))
-        elif os.path.isdir(REFERENCE_TREE):
+        elif a.cpu_baseline_kind == "reference" or (a.cpu_baseline_kind == "auto" and os.path.isdir(REFERENCE_TREE)):
             print(json.dumps(cpu_baseline_reference_worker()))
         else:
             print(json.dumps(cpu_baseline_worker()))

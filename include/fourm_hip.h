@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 5
+#define FM_ABI_VERSION 6
 int fm_abi_version(void);
 const char* fm_last_error(void);
 
@@ -516,6 +516,43 @@ typedef struct fm_span_mask_args {
     int32_t B, ld_ids, T, ld_noise, n_sentinels, max_tokens, vocab_offset, pad_id, emb_rows, emb_dim;
 } fm_span_mask_args;
 int fm_span_mask(const fm_span_mask_args* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Diffusion detokenizer (DiVAE decoder), inference (csrc/unet.hip).  Feature maps are rows (B * H * W, C) bf16 ("NHWC"): a 1 x 1
+ * convolution is fm_gemm_nt on the rows; a 3 x 3 convolution is fm_unet_im2col + fm_gemm_nt with K = 9 C.
+ * Replaces fourm/vq/models/unet/unet.py (ResBlock :163-274, AttentionBlock :277-322, QKVAttentionLegacy :345-374, Upsample /
+ * Downsample :103-160, PatchedUNetCondCat :693-744), nn.py:23-25 / :120-140, and the element-wise half of
+ * fourm/vq/scheduling/scheduling_{ddim,ddpm}.py (step, _threshold_sample).
+ * ---------------------------------------------------------------------------------------------- */
+/* out[(b, oy, ox)][tap * (C1 + C2) + c] (bf16, row stride ldo; columns [ksize^2 (C1 + C2), kpad) zero) <- the ksize x ksize neighbourhood
+ * (padding ksize / 2, stride 1 | 2) of the channel concatenation [src1 | src2] on an (H, W) grid: src1 (B, H >> up1, W >> up1, C1) is read
+ * at (y >> up1, x >> up1) (up1 = 1: the nearest x2 up-sampling of Upsample), src2 (B, H2, W2, C2) at (y H2 / H, x W2 / W) (nearest: the skip
+ * tensor of an output block, or the conditioning under a finer grid); src2 = NULL, C2 = 0: one source.  ksize = 1: the plain concatenation.
+ * The weight operand of the GEMM behind it is conv.weight.permute(0, 2, 3, 1).reshape(Cout, ksize^2 (C1 + C2)). */
+int fm_unet_im2col(const void* src1, int ld1, int C1, const void* src2, int ld2, int C2, int H2, int W2, void* out, int ldo, int kpad,
+                   int B, int H, int W, int ksize, int stride, int up1, void* stream);
+/* y = [silu] GroupNorm_groups(x + add[b][c]) * w + b over rows (B, HW, C): fp32 statistics per (sample, group) over HW x C / groups
+ * values (two passes), fp32 arithmetic, bf16 result (GroupNorm32, nn.py:23-25; ``add`` f32 (B, >= C) with row stride ld_add, or NULL: the
+ * timestep embedding a ResBlock adds in front of out_layers, unet.py:270).  stats: f32 scratch (B * groups, 2). */
+int fm_groupnorm_nhwc(const void* x, int ldx, const void* add, int ld_add, const void* w, const void* b, void* y, int ldy, void* stats, int B, int HW,
+                      int C, int groups, float eps, int silu, void* stream);
+int fm_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows, int C, void* stream);   /* out = a + b, bf16 rows */
+int fm_silu_f32_to_bf16(const void* x, void* y, int64_t n, void* stream);                                                 /* y = bf16(x * sigmoid(x)) */
+/* out[b] = [cos(t_b f_i) | sin(t_b f_i)], f_i = exp(-ln(max_period) i / (dim / 2)); t f32 (B), out bf16 (B, ldo)   (nn.py:120-140) */
+int fm_timestep_embedding(const void* t, void* out, int ldo, int B, int dim, float max_period, void* stream);
+/* Spatial self-attention of AttentionBlock with QKVAttentionLegacy: qkv bf16 (B * T, ld) whose columns are, per head, [q | k | v] of ch
+ * channels each; weights = softmax_fp32(q k^T / sqrt(ch)); out bf16 (B * T, ldo) with a head's ch channels side by side. */
+int fm_unet_attention(const void* qkv, int ld, void* out, int ldo, int B, int T, int heads, int ch, void* stream);
+/* Scheduler step, element-wise (f32, n = B * per_sample values):
+ *   fm_diffusion_x0:    x0 = c0 * sample + c1 * model_output                     (v-prediction: c0 = sqrt(a_t), c1 = -sqrt(1 - a_t); ...)
+ *   fm_quantile_abs:    out[b] = torch.quantile(|x[b]|, q) (linear interpolation) - radix select, one workgroup per sample
+ *   fm_diffusion_step:  x0' = quantile ? clamp(x0, -s, s) / s with s = clamp(quantile[b], 1, sample_max_value)   (_threshold_sample)
+ *                           : clip_range > 0 ? clamp(x0, -clip_range, clip_range) : x0;
+ *                       out = k0 * x0' + k1 * sample + k2 * model_output + k3 * noise   (noise may be NULL);  x0_out (optional) = x0' */
+int fm_diffusion_x0(const void* sample, const void* model_output, float c0, float c1, void* x0, int64_t n, void* stream);
+int fm_quantile_abs(const void* x, int B, int64_t n, float q, void* out, void* stream);
+int fm_diffusion_step(const void* x0, const void* quantile, float sample_max_value, float clip_range, const void* sample, const void* model_output,
+                      const void* noise, float k0, float k1, float k2, float k3, void* out, void* x0_out, int B, int64_t per_sample, void* stream);
 
 #ifdef __cplusplus
 }

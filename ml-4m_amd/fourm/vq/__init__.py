@@ -1,7 +1,7 @@
 """VQ tokenizers: ViT encoder + cosine-similarity codebook search (``VQ``), plus the ViT decoder and the training path (``VQVAE``)."""
 import os
 
-from .vqvae import VQ, VQVAE
+from .vqvae import VQ, VQVAE, DiVAE
 
 
 def get_image_tokenizer(tokenizer_id: str, tokenizers_root: str = "./tokenizer_ckpts", encoder_only: bool = False, device: str = "cuda",
@@ -15,7 +15,7 @@ def get_image_tokenizer(tokenizer_id: str, tokenizers_root: str = "./tokenizer_c
       * ``encoder_only`` builds ``VQ`` from the checkpoint minus every decoder / post_quant_proj tensor, otherwise the model type is read
         off the checkpoint (controlnet keys -> VQControlNet, ``beta_schedule`` -> DiVAE, else VQVAE) and every argument of the run is
         forwarded to the constructor (``out_conv``, ``patch_size_dec``, ``image_size_enc`` ... included).
-    Diffusion-decoder checkpoints (DiVAE / VQControlNet) have no HIP decoder: they load with ``encoder_only=True`` only.
+    DiVAE checkpoints (conditional-UNet diffusion decoder) build ``fourm.vq.DiVAE``; VQControlNet loads with ``encoder_only=True`` only.
     Unlike upstream (strict=False and a printed message) unexpected MISSING keys raise: a tokenizer with random weights is never returned."""
     import torch
     path = os.path.join(tokenizers_root, f"{tokenizer_id}.pth")
@@ -47,9 +47,9 @@ def get_image_tokenizer(tokenizer_id: str, tokenizers_root: str = "./tokenizer_c
         sd = {k: v for k, v in sd.items() if "decoder" not in k and "post_quant_proj" not in k}
     else:
         a.model_type = "VQControlNet" if any("controlnet" in k for k in sd) else "DiVAE" if hasattr(a, "beta_schedule") else "VQVAE"
-        if a.model_type != "VQVAE":
-            raise NotImplementedError(f"{a.model_type}: diffusion-decoder tokenizers have no HIP decoder - load them with encoder_only=True")
-        model_type = VQVAE
+        if a.model_type == "VQControlNet":
+            raise NotImplementedError("VQControlNet (a Stable-Diffusion ControlNet from `diffusers`) has no HIP decoder - load it with encoder_only=True")
+        model_type = DiVAE if a.model_type == "DiVAE" else VQVAE
     kw = {k: v for k, v in vars(a).items() if v is not None or k in ("n_labels", "image_size_enc", "image_size_dec")}
     if not isinstance(kw.get("config"), dict):
         kw.pop("config", None)        # (a trainer's config FILE path is not a model configuration)

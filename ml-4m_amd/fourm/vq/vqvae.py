@@ -2,7 +2,9 @@
 ``fourm/vq/vqvae.py`` (``VQ`` :39-331: constructor arguments, ``encode`` / ``tokenize`` / ``tokens_to_embedding``,
 state_dict keys), and ``VQVAE`` (:396-495): the ViT decoder behind the codebook (``decode_quant`` / ``decode_tokens`` / ``autoencode``)
 and the gradient path of tokenizer training (``forward`` in training mode returns autograd-connected ``dec, code_loss``; the backward is
-hand-written, fourm/vq/engine.py).  The diffusion decoders (DiVAE, VQControlNet: UNet + schedulers from ``diffusers``) are out of scope.
+hand-written, fourm/vq/engine.py), and ``DiVAE`` (:498-764): the conditional-UNet diffusion detokenizer, inference (``decode_quant`` /
+``decode_tokens`` / ``autoencode`` / ``forward`` with given noised inputs) on fourm.vq.models.unet + fourm.vq.scheduling.  VQControlNet
+(a Stable-Diffusion ControlNet from ``diffusers``) stays upstream's.
 
 Precision = upstream's autocast arithmetic: the 12 ViT blocks with bf16 GEMM operands (fp32 accumulate, fp32 residual /
 LayerNorm / softmax); the tanh post-MLP, the 1x1 projection and the codebook search in exact fp32 (upstream disables
@@ -186,6 +188,87 @@ class VQVAE(VQ):
 
     def autoencode(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         return self.forward(x)[0]
+
+
+class DiVAE(VQ):
+    """Encoder + discrete bottleneck + diffusion decoder (upstream ``DiVAE``, vqvae.py:498-764): same constructor, state_dict keys
+    (``decoder.*`` = the conditional UNet) and methods.  Inference runs on the HIP kernels: ``decode_quant`` / ``decode_tokens`` /
+    ``autoencode`` sample with the pipeline of fourm.vq.scheduling, ``forward(input_clean, input_noised, timesteps)`` evaluates the decoder
+    once (no gradient path: the detokenizers are trained upstream).  ``uvit_*`` decoders are not built."""
+
+    def __init__(self, dec_type: str = "unet_patched", num_train_timesteps: int = 1000, cls_free_guidance_dropout: float = 0.0, masked_cfg: bool = False,
+                 masked_cfg_low: int = 0, masked_cfg_high: Optional[int] = None, scheduler: str = "ddpm", beta_schedule: str = "squaredcos_cap_v2",
+                 prediction_type: str = "v_prediction", clip_sample: bool = False, thresholding: bool = True, conditioning: str = "concat",
+                 dec_transformer_dropout: float = 0.2, zero_terminal_snr: bool = True, image_size_dec: Optional[int] = None,
+                 config: Optional[Dict[str, Any]] = None, *args, **kwargs):
+        if config is not None:
+            self.__init__(**copy.deepcopy(config))
+            return
+        ckpt_path = kwargs.get("ckpt_path", None)                 # (loaded once the decoder exists)
+        kwargs["ckpt_path"] = None
+        super().__init__(*args, **kwargs)
+        self.ckpt_path = ckpt_path
+        from .models import unet
+        from .scheduling import DDIMScheduler, DDPMScheduler, PipelineCond
+        self.dec_type, self.num_train_timesteps, self.beta_schedule, self.prediction_type = dec_type, num_train_timesteps, beta_schedule, prediction_type
+        self.clip_sample, self.thresholding, self.zero_terminal_snr = clip_sample, thresholding, zero_terminal_snr
+        self.cfg_dist = torch.distributions.Bernoulli(probs=cls_free_guidance_dropout) if cls_free_guidance_dropout > 0.0 else None
+        self.masked_cfg, self.masked_cfg_low, self.masked_cfg_high = masked_cfg, masked_cfg_low, masked_cfg_high
+        if "unet_" not in dec_type or not hasattr(unet, dec_type):
+            raise NotImplementedError(f"dec_type {dec_type} not implemented (HIP decoders: unet_patched).")
+        self.decoder = getattr(unet, dec_type)(in_channels=self.n_channels, out_channels=self.n_channels, cond_channels=self.latent_dim,
+                                               image_size=image_size_dec or self.image_size)
+        cls = DDPMScheduler if scheduler == "ddpm" else DDIMScheduler
+        self.noise_scheduler = cls(num_train_timesteps=num_train_timesteps, thresholding=thresholding, clip_sample=clip_sample, beta_schedule=beta_schedule,
+                                   prediction_type=prediction_type, zero_terminal_snr=zero_terminal_snr)
+        self.pipeline = PipelineCond(model=self.decoder, scheduler=self.noise_scheduler)
+        if self.ckpt_path is not None:
+            self.init_from_ckpt(self.ckpt_path, ignore_keys=self.ignore_keys)
+
+    def sample_mask(self, quant: torch.Tensor, low: int = 0, high: Optional[int] = None) -> torch.BoolTensor:
+        """(B, H_Q, W_Q) bool, True = conditioning masked out: a uniform number of tokens in [low, high] per sample (vqvae.py:618-638)."""
+        B, _, hq, wq = quant.shape
+        n = hq * wq
+        high = high if high is not None else n
+        zero_idxs = torch.randint(low=low, high=high + 1, size=(B,), device=quant.device)
+        order = torch.argsort(torch.rand(B, n, device=quant.device), dim=1)
+        return torch.where(order < zero_idxs.unsqueeze(1), 0, 1).reshape(B, hq, wq).bool()
+
+    def _get_pipeline(self, scheduler=None):
+        from .scheduling import PipelineCond
+        return PipelineCond(model=self.decoder, scheduler=scheduler) if scheduler is not None else self.pipeline
+
+    @torch.no_grad()
+    def decode_quant(self, quant: torch.Tensor, timesteps: Optional[int] = None, scheduler=None, generator: Optional[torch.Generator] = None,
+                     image_size=None, verbose: bool = False, scheduler_timesteps_mode: str = "trailing", orig_res=None) -> torch.Tensor:
+        """quant (B, latent_dim, h, w) -> image (B, C, H, W): ``timesteps`` denoising steps of the pipeline (vqvae.py:640-672)."""
+        return self._get_pipeline(scheduler)(quant, timesteps=timesteps, generator=generator, image_size=image_size, verbose=verbose,
+                                             scheduler_timesteps_mode=scheduler_timesteps_mode, orig_res=orig_res)
+
+    @torch.no_grad()
+    def decode_tokens(self, tokens: torch.LongTensor, **kwargs) -> torch.Tensor:
+        return self.decode_quant(self.tokens_to_embedding(tokens), **kwargs)
+
+    @torch.no_grad()
+    def autoencode(self, input_clean: torch.Tensor, timesteps: Optional[int] = None, scheduler=None, generator: Optional[torch.Generator] = None,
+                   verbose: bool = True, scheduler_timesteps_mode: str = "trailing", orig_res=None, **kwargs) -> torch.Tensor:
+        quant, _, _ = self.encode(input_clean)
+        return self._get_pipeline(scheduler)(quant, timesteps=timesteps, generator=generator, image_size=input_clean.shape[-1], verbose=verbose,
+                                             scheduler_timesteps_mode=scheduler_timesteps_mode, orig_res=orig_res)
+
+    def forward(self, input_clean: torch.Tensor, input_noised: torch.Tensor, timesteps, cond_mask: Optional[torch.Tensor] = None, orig_res=None):
+        """(dec, code_loss): encode the clean input, evaluate the diffusion decoder on the noised one (vqvae.py:716-764).  No gradient path."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.decoder.parameters()) and self.training:
+            raise NotImplementedError("DiVAE.forward has no backward here (the diffusion decoder is inference-only): call under torch.no_grad() / .eval()")
+        with torch.no_grad():
+            quant, code_loss, _ = self._encode(input_clean)
+            if cond_mask is None and self.cfg_dist is not None and self.training:
+                B, _, hq, wq = quant.shape
+                cond_mask = self.cfg_dist.sample((B,)).to(quant.device, dtype=torch.bool)[:, None, None].expand(B, hq, wq)
+                if self.masked_cfg:
+                    cond_mask = self.sample_mask(quant, low=self.masked_cfg_low, high=self.masked_cfg_high) * cond_mask
+            dec = self.decoder(input_noised, timesteps, quant, cond_mask=cond_mask, orig_res=orig_res)
+        return dec, code_loss
 
 
 # names only upstream's same-named module defines resolve lazily (see fourm/_upstream.py)

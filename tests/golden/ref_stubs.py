@@ -38,6 +38,65 @@ class _Inert(types.ModuleType):
         return cls
 
 
+def _install_diffusers_helpers():
+    """The handful of ``diffusers`` helpers upstream's DiVAE decoder calls at run time (vq/models/unet/unet.py, vq/scheduling/*.py):
+    none of them computes anything - a config namespace filled from the constructor arguments, ``nn.Module`` as the model base class,
+    attribute registration of the pipeline's parts, and ``torch.randn`` with a generator.  Restated here so that the UNMODIFIED upstream
+    classes run and the DiVAE oracle can be pinned to them."""
+    import functools
+    import inspect
+
+    import torch
+
+    class _Config(dict):
+        __getattr__ = dict.__getitem__
+
+    def register_to_config(init):
+        @functools.wraps(init)
+        def wrapped(self, *args, **kwargs):
+            sig = inspect.signature(init)
+            bound = sig.bind(self, *args, **kwargs)
+            bound.apply_defaults()
+            cfg = {k: v for k, v in bound.arguments.items() if k != "self"}
+            object.__setattr__(self, "config", _Config(cfg)) if not isinstance(self, torch.nn.Module) else self.__dict__.__setitem__("config", _Config(cfg))
+            init(self, *args, **kwargs)
+        return wrapped
+
+    class ModelMixin(torch.nn.Module):
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+        @property
+        def dtype(self):
+            return next(self.parameters()).dtype
+
+    class ConfigMixin:
+        pass
+
+    class SchedulerMixin:
+        pass
+
+    class DiffusionPipeline:
+        def __init__(self, *a, **k):
+            pass
+
+        def register_modules(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+    def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+        gen_dev = generator.device if generator is not None else (device or "cpu")
+        return torch.randn(tuple(shape), generator=generator, device=gen_dev, dtype=dtype).to(device or gen_dev)
+
+    sys.modules["diffusers.configuration_utils"].register_to_config = register_to_config
+    sys.modules["diffusers.configuration_utils"].ConfigMixin = ConfigMixin
+    sys.modules["diffusers.models.modeling_utils"].ModelMixin = ModelMixin
+    sys.modules["diffusers.schedulers.scheduling_utils"].SchedulerMixin = SchedulerMixin
+    sys.modules["diffusers"].DiffusionPipeline = DiffusionPipeline
+    sys.modules["diffusers.utils"].randn_tensor = randn_tensor
+
+
 def reference_available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "fourm"))
 
@@ -57,8 +116,8 @@ def install():
             parent, child = name.rsplit(".", 1)
             setattr(sys.modules[parent], child, m)
     sys.modules["diffusers.schedulers.scheduling_utils"].KarrasDiffusionSchedulers = []
-    sys.modules["diffusers.configuration_utils"].register_to_config = lambda f: f
     sys.modules["diffusers.utils"].BaseOutput = type("BaseOutput", (dict,), {})
+    _install_diffusers_helpers()
     sys.dont_write_bytecode = True
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
