@@ -303,7 +303,8 @@ class FourMEngine:
         accumulation window: the trainer called optimizer.zero_grad()).  ``untouched`` parameters (see
         ``_untouched_params``) keep ``grad = None`` unless an earlier micro-batch of the window reached them."""
         if zero:
-            self.flat_grads.zero_()
+            with ops._prof("fills"):
+                self.flat_grads.zero_()
             self._window_touched = set()
         skip = {id(p) for p in untouched} - getattr(self, "_window_touched", set())
         self._attached = []
@@ -505,7 +506,8 @@ class FourMEngine:
             out["seqemb_rows"] = ws.get(prefix + "seqemb_rows", (Rp, seq_ld), self.adt)
             desc.seqemb_rows, desc.seqemb_ld = out["seqemb_rows"].data_ptr(), seq_ld
         desc.rows_f32 = 1 if self.fp32 else 0
-        L.check(L.select_embed(ops.C.byref(desc), ops._stream()))
+        with ops._prof("select_embed"):
+            L.check(L.select_embed(ops.C.byref(desc), ops._stream()))
         out["_keep"] = keep
         # dense projections of pixel / embedding modalities, added onto the (zero) token rows
         for n in names:
@@ -789,7 +791,8 @@ class FourMEngine:
         sv = {} if save else None
         yp = ws.get("heads.yp", (Rp, D), self.adt)
         # decoder_norm writes straight into the segmented layout; pad rows are cleared first
-        yp.zero_()
+        with ops._prof("fills"):
+            yp.zero_()
         self._ln(m.decoder_norm, y_final, yp, R, sv, "dn", "heads", row_map=hs["r2p"])
         vocabs = [m.decoder_embeddings[h].vocab_size for h in heads]
         hs["vocabs"], hs["maxV"] = vocabs, max(vocabs)
@@ -1029,7 +1032,8 @@ class FourMEngine:
         if not is_dec and m.num_register_tokens and m.register_tokens.requires_grad:
             d.d_reg_tokens = self.grad_view(m.register_tokens).data_ptr()
         d.n_mods, d.batch, d.dim, d.Nt, d.is_decoder = len(sel["names"]), sel["B"], self.D, sel["Nt"], 1 if is_dec else 0
-        L.check(L.embed_bwd(ops.C.byref(d), ops._stream()))
+        with ops._prof("embed_bwd"):
+            L.check(L.embed_bwd(ops.C.byref(d), ops._stream()))
         if dx_extra is not None:
             # the context gradient reaches pos_emb / mod_emb only (context = proj(x) + encoder_emb, fm.py:679)
             d2 = L.EmbedBwdDesc()
@@ -1039,7 +1043,8 @@ class FourMEngine:
                 d2.mods[i].d_proj_bias = None
             d2.d_reg_tokens = None
             d2.dx, d2.lddx = dx_extra.data_ptr(), dx_extra.stride(0)
-            L.check(L.embed_bwd(ops.C.byref(d2), ops._stream()))
+            with ops._prof("embed_bwd"):
+                L.check(L.embed_bwd(ops.C.byref(d2), ops._stream()))
 
     def train_backward(self, grad_scale: torch.Tensor):
         """Backward of the last ``train_forward``.  ``grad_scale``: 1-element fp32 device tensor holding
@@ -1082,11 +1087,13 @@ class FourMEngine:
         Ld = len(m.decoder)
         ctx_hat = st.get("ctx_hat")
         if ctx_hat is None:
-            dctx.zero_()
+            with ops._prof("fills"):
+                dctx.zero_()
         else:       # context-norm hoist: the layers' d(kv) side by side, dL/d(W_l diag(gamma_l)) in a zeroed fp32 scratch
             dkv_all = ws.get("bwd.dkv_all", (Rcp, Ld * 2 * D), bf)
             dwp = ws.get("bwd.dwp", (Ld, 2 * D, D), f32)
-            dwp.zero_()
+            with ops._prof("fills"):
+                dwp.zero_()
         for i in reversed(range(Ld)):
             sv = st["dec_layers"][i]
             if "ckpt_in" in sv:       # recompute this block's activations from its saved input (one shared set of buffers)

@@ -32,6 +32,21 @@ def _prof(name, flops=0.0, nbytes=0.0, tag=""):
     return _NULL if _PROFILER is None else _PROFILER.launch(name, flops, nbytes, tag)
 
 
+def _timed(name):
+    """Decorator: the wrapped launch shows up as family ``name`` in bench.py's per-kernel breakdown (events only while a profiler is set)."""
+    def deco(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            if _PROFILER is None:
+                return fn(*a, **k)
+            with _PROFILER.launch(name, 0.0, 0.0, ""):
+                return fn(*a, **k)
+        return wrapped
+    return deco
+
+
 BK = 64          # reduction granularity of the GEMMs (zero padded)
 SEG = 256        # row-segment alignment of the grouped head GEMMs (FM_SEG_ROWS)
 
@@ -101,6 +116,7 @@ def _gemm_f32(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, b
     return out
 
 
+@_timed("heads_gemm_nt (logits, dY)")
 def gemm_nt_grouped(x, groups, tile_group, out, max_N, M=None, max_K=0):
     if x.dtype == torch.float32:
         a = L.GemmF32Args()
@@ -169,6 +185,7 @@ def gemm_tn_multi(jobs):
             L.check(L.gemm_tn_multi(arr, len(part), _stream()))
 
 
+@_timed("heads_gemm_tn (dW)")
 def gemm_tn_grouped(a_mat, b_mat, groups, seg_start, seg_count, n_groups, max_N, max_R, K, *, splits=0, force_tr=-1):
     if a_mat.dtype == torch.float32:
         g = L.GemmF32Args()
@@ -238,6 +255,7 @@ def _ln_bwd(dy, x, w, mean, rstd, dx, dres, dx_bf16, dw, db, dy_row_map, R):
     return dx
 
 
+@_timed("headnorm")
 def headnorm_fwd(x, w, b, y, stats, R, H, eps):
     """Per-head (64 features) LayerNorm of the q / k column block ``x`` -> ``y`` (both bf16 2-D views)."""
     if x.dtype == torch.float32:
@@ -245,6 +263,7 @@ def headnorm_fwd(x, w, b, y, stats, R, H, eps):
     L.check(L.headnorm_fwd(_p(x), _ld(x), _p(w), _p(b), _p(y), _ld(y), _p(stats), R, H, eps, _stream()))
 
 
+@_timed("headnorm")
 def headnorm_bwd(dy, x, w, stats, dx, dw, db, R, H):
     if x.dtype == torch.float32:
         return L.check(L.headnorm_f32_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(stats), _p(dx), _ld(dx), _p(dw), _p(db), R, H, _stream()))
@@ -300,15 +319,18 @@ def padded_rows(R: int, n_heads: int) -> int:
     return ru(R, SEG) + SEG * (n_heads - 1)
 
 
+@_timed("heads_misc")
 def segment_rows(head_of_row, n_heads, seg_start, seg_count, perm, row_to_padded, tile_group):
     L.check(L.segment_rows(_p(head_of_row), head_of_row.numel(), n_heads, _p(seg_start), _p(seg_count), _p(perm),
                            _p(row_to_padded), _p(tile_group), perm.numel(), _stream()))
 
 
+@_timed("heads_misc")
 def gather_rows(src, perm, dst, D):
     L.check(L.gather_rows(_p(src), _ld(src), _p(perm), _p(dst), _ld(dst), perm.numel(), D, _stream()))
 
 
+@_timed("cross_entropy")
 def cross_entropy(logits, perm, tile_group, target_ids, vocab, seg_start, seg_count, n_heads, max_vocab, row_loss, row_lse, head_loss,
                   total_loss, *, loss_type=L.LOSS_MOD, grad_scale=None, write_grad=False):
     """write_grad=False: forward (losses + row_lse); write_grad=True: in-place d(logits) from the saved row_lse."""
@@ -321,12 +343,14 @@ def cross_entropy(logits, perm, tile_group, target_ids, vocab, seg_start, seg_co
 # ---------------------------------------------------------------------------------------------
 # element-wise
 # ---------------------------------------------------------------------------------------------
+@_timed("swiglu_bwd")
 def swiglu_bwd(da, gu, dgu, H, Hp, R=None):
     if da.dtype == torch.float32:
         return L.check(L.swiglu_bwd_f32(_p(da), _ld(da), _p(gu), _ld(gu), _p(dgu), _ld(dgu), da.shape[0] if R is None else R, H, Hp, _stream()))
     L.check(L.swiglu_bwd(_p(da), _ld(da), _p(gu), _ld(gu), _p(dgu), _ld(dgu), da.shape[0] if R is None else R, H, Hp, _stream()))
 
 
+@_timed("gelu_bwd")
 def gelu_bwd(dh, pre, dpre, H, Hp, R=None):
     if dh.dtype == torch.float32:
         return L.check(L.gelu_bwd_f32(_p(dh), _ld(dh), _p(pre), _ld(pre), _p(dpre), _ld(dpre), dh.shape[0] if R is None else R, H, _stream()))
@@ -372,6 +396,7 @@ def shadow_jobs_table(jobs, device):
     return raw, tiles
 
 
+@_timed("fold_colscale_grad")
 def fold_colscale_grad(jobs):
     """jobs = [(dWp f32 (rows, cols) view, W f32 master, gamma f32 (cols,), gW f32 | None, ggamma f32 (cols,) | None)]:
     gW += dWp * gamma[None, :];  ggamma += sum_r dWp * W  (csrc/elementwise.hip fold_colscale_grad_kernel)."""
@@ -386,16 +411,19 @@ def fold_colscale_grad(jobs):
         L.check(L.fold_colscale_grad(arr, len(part), _stream()))
 
 
+@_timed("shadow_refresh")
 def shadow_refresh(table, n_jobs, tiles):
     L.check(L.shadow_refresh(_p(table), n_jobs, tiles, _stream()))
 
 
+@_timed("colsum")
 def colsum(dy, db, N, R=None):
     if dy.dtype == torch.float32:
         return L.check(L.colsum_f32(_p(dy), _ld(dy), _p(db), dy.shape[0] if R is None else R, N, _stream()))
     L.check(L.colsum(_p(dy), _ld(dy), _p(db), dy.shape[0] if R is None else R, N, _stream()))
 
 
+@_timed("casts")
 def f32_to_bf16(src, dst):
     if dst.dtype == torch.float32:
         return dst.copy_(src)
@@ -403,17 +431,20 @@ def f32_to_bf16(src, dst):
     return dst
 
 
+@_timed("casts")
 def bf16_to_f32_scaled(src, dst, scale=1.0):
     L.check(L.bf16_to_f32_scaled(_p(src), _p(dst), src.numel(), float(scale), _stream()))
     return dst
 
 
+@_timed("drop_path")
 def scale_rows_bf16(x, scale, rows_per_sample, R, N=None):
     """x[r] *= scale[r // rows_per_sample] (bf16, in place): DropPath on a branch output / on the gradient entering the branch."""
     L.check(L.scale_rows_bf16(_p(x), _ld(x), _p(scale), rows_per_sample, R, x.shape[1] if N is None else N, _stream()))
     return x
 
 
+@_timed("casts")
 def add_bf16_to_f32(x, delta, out, R=None):
     """out[:R] = x[:R] + delta[:R] (contiguous (rows, D) buffers of equal width)."""
     R = x.shape[0] if R is None else R
@@ -422,6 +453,7 @@ def add_bf16_to_f32(x, delta, out, R=None):
     return out
 
 
+@_timed("adamw")
 def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None):
     L.check(L.adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _p(hyper), _stream()))
 
@@ -453,14 +485,17 @@ def adamw_jobs_table(jobs, device):
     return raw, tiles
 
 
+@_timed("adamw")
 def adamw_shadow(table, n_jobs, tiles, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None):
     L.check(L.adamw_shadow(_p(table), n_jobs, tiles, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _p(hyper), _stream()))
 
 
+@_timed("grad_norm")
 def sumsq(x, out):
     L.check(L.sumsq(_p(x), x.numel(), _p(out), _stream()))
 
 
+@_timed("grad_norm")
 def clip_coef(ss, max_norm, norm_out, coef_out):
     L.check(L.clip_coef(_p(ss), float(max_norm or 0.0), _p(norm_out), _p(coef_out), _stream()))
 
