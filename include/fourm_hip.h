@@ -448,6 +448,11 @@ int fm_vq_latent_grad(const void* z, int ldz, const void* embed, const int64_t* 
                       float commitment_weight, void* dz, int ld_dz, void* commit_value, int R, int D, void* stream);
 int fm_tanh_bwd_f32(const void* dy, const void* t, void* dx, int R, int N, int ld, void* stream);
 int fm_embed_rows_f32(const void* table, const int64_t* idx, void* out, int ld_out, int R, int D, void* stream);
+/* fp32 products on the bf16 matrix cores: out (R, ldo >= 3 K) bf16 = [hi | hi | lo] of x f32 (R, K) (weight_order = 0: the activation
+ * operand) or [hi | lo | hi] (weight_order = 1: the weight operand), hi = bf16(x), lo = bf16(x - hi); apply_tanh: x <- tanh(x) first.
+ * ONE bf16 NT GEMM over the 3 K columns then accumulates hi hi + hi lo + lo hi in fp32: ~2^-16 relative (the tokenizer's fp32 tail at
+ * inference, vit_models.py:494-496). */
+int fm_split3_bf16(const void* x, int ldx, void* out, int ldo, int R, int K, int weight_order, int apply_tanh, void* stream);
 /* Input variants of the tokenizer (VQ.prepare_input, vq/vqvae.py:269-286) folded into the patch gather: fm_vq_patchify with
  *   labels != NULL: class maps int64 (B, H, W) embedded by cls_emb f32 (n_labels, C) (semantic segmentation, n_labels; img unused);
  *   scale / shift: DEVICE float[C] (or both NULL): value = scale[c] * v + shift[c] (undo_std: 2 * denormalize(x) - 1).

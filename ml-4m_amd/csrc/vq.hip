@@ -368,6 +368,48 @@ extern "C" int fm_tanh_bwd_f32(const void* dy, const void* t, void* dx, int R, i
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32 product on the bf16 matrix cores: x = hi + lo (two bf16: 16 of fp32's 24 significant bits), x w ~ hi_x hi_w + hi_x lo_w + lo_x hi_w
+// (the lo_x lo_w term is below 2^-16 relative).  Both operands are written as three column blocks - X' = [hi | hi | lo], W' = [hi | lo | hi] -
+// so that ONE bf16 NT GEMM with reduction length 3 K accumulates the three terms in fp32.  Used for the tokenizer's fp32 tail (the tanh
+// post-MLP upstream runs with autocast off, vit_models.py:494-496) at inference: ~1e-5 relative instead of bf16's 4e-3, at ~4 x the rate of
+// v_mfma_f32_32x32x2_f32.  apply_tanh: x <- tanh(x) first (the activation between fc1 and fc2, fused into the split of fc2's operand).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int ldx, bf16_t* __restrict__ out, int ldo, int R, int K, int weight_order,
+                                                     int apply_tanh) {
+    const int vec = K / 4;
+    const long long total = (long long)R * vec;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / vec;
+        const int c = (int)(i % vec) * 4;
+        const float4 v = *(const float4*)(x + (size_t)r * ldx + c);
+        float f[4] = {v.x, v.y, v.z, v.w};
+        float hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (apply_tanh) f[j] = tanhf(f[j]);
+            hi[j] = bfround(f[j]);
+            lo[j] = f[j] - hi[j];
+        }
+        const uint2 h = make_uint2(pack2bf(hi[0], hi[1]), pack2bf(hi[2], hi[3])), l = make_uint2(pack2bf(lo[0], lo[1]), pack2bf(lo[2], lo[3]));
+        bf16_t* o = out + (size_t)r * ldo + c;
+        *(uint2*)o = h;
+        *(uint2*)(o + K) = weight_order ? l : h;          // activations [hi | hi | lo], weights [hi | lo | hi]
+        *(uint2*)(o + 2 * K) = weight_order ? h : l;
+    }
+}
+}  // namespace
+
+extern "C" int fm_split3_bf16(const void* x, int ldx, void* out, int ldo, int R, int K, int weight_order, int apply_tanh, void* stream) {
+    FM_CHECK_ARG(x && out && R > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ldo >= 3 * K, "fm_split3_bf16: bad argument (K %% 4 == 0, ldo >= 3 K)");
+    size_t blocks = ((size_t)R * (K / 4) + 255) / 256;
+    if (blocks > 65535) blocks = 65535;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (bf16_t*)out, ldo, R, K, weight_order, apply_tanh);
+    FM_CHECK_LAUNCH("fm_split3_bf16");
+    return 0;
+}
+
 extern "C" int fm_embed_rows_f32(const void* table, const int64_t* idx, void* out, int ld_out, int R, int D, void* stream) {
     FM_CHECK_ARG(table && idx && out && R > 0 && D > 0 && ld_out >= D, "fm_embed_rows_f32: bad argument");
     int grid = (R + 3) / 4;

@@ -219,6 +219,7 @@ unpack_image_u8 = _sig("fm_unpack_image_u8", vp, vp, i32, i32, i32, i32, P(C.c_f
 unpack_ids_u16 = _sig("fm_unpack_ids_u16", vp, vp, i64, vp)
 unpack_mask_bits = _sig("fm_unpack_mask_bits", vp, vp, i32, i32, vp)
 decoder_attention_from_target = _sig("fm_decoder_attention_from_target", vp, vp, i32, i32, vp)
+split3_bf16 = _sig("fm_split3_bf16", vp, i32, vp, i32, i32, i32, i32, i32, vp)
 unet_im2col = _sig("fm_unet_im2col", vp, i32, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp)
 groupnorm_nhwc = _sig("fm_groupnorm_nhwc", vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, i32, vp)
 add_bf16 = _sig("fm_add_bf16", vp, i32, vp, i32, vp, i32, i64, i32, vp)
@@ -228,7 +229,7 @@ unet_attention = _sig("fm_unet_attention", vp, i32, vp, i32, i32, i32, i32, i32,
 diffusion_x0 = _sig("fm_diffusion_x0", vp, vp, f32, f32, vp, i64, vp)
 quantile_abs = _sig("fm_quantile_abs", vp, i32, i64, f32, vp, vp)
 diffusion_step = _sig("fm_diffusion_step", vp, vp, f32, f32, vp, vp, vp, f32, f32, f32, f32, vp, vp, i32, i64, vp)
-EXPORTS = ["fm_unet_im2col", "fm_groupnorm_nhwc", "fm_add_bf16", "fm_silu_f32_to_bf16", "fm_timestep_embedding", "fm_unet_attention", "fm_diffusion_x0", "fm_quantile_abs",
+EXPORTS = ["fm_split3_bf16", "fm_unet_im2col", "fm_groupnorm_nhwc", "fm_add_bf16", "fm_silu_f32_to_bf16", "fm_timestep_embedding", "fm_unet_attention", "fm_diffusion_x0", "fm_quantile_abs",
            "fm_diffusion_step", "fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_token_budgets", "fm_span_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_vq_code_bias", "fm_vq_assign_bias", "fm_vq_code_stats_raw", "fm_vq_ema_update_euclid", "fm_vq_unpatchify", "fm_vq_latent_grad", "fm_tanh_bwd_f32", "fm_embed_rows_f32", "fm_vq_patchify_ex", "fm_vq_cls_emb_bwd", "fm_vq_latent_grad_normalized", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_add_bf16_f32", "fm_scale_rows_bf16", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
            "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_fwd_res", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",

@@ -3,6 +3,7 @@ the ViT blocks on the trunk's kernels (LayerNorm with bias, qkv GEMM + bias, unm
 bias+GELU MLP with fused residual adds), the tanh "post MLP", the 1x1 projection to the latent
 dimension and the fused cosine-similarity code search.  [upstream vq/vqvae.py:302-318,
 vq/models/vit_models.py:465-501, vq/quantizers/quantize_lucid.py:388-407, :504-568]"""
+import os
 import weakref
 
 import torch
@@ -98,9 +99,27 @@ def _blocks_fwd(eng, vit, stream, B, G, st, prefix):
     return stream
 
 
+def _split3_weight(eng, p):
+    """[hi | lo | hi] bf16 image of an fp32 weight (N, K) -> (N, 3 K), cached until the parameter changes."""
+    key = ("split3", id(p))
+    hit = eng._cache.get(key)
+    stamp = (p._version, p.data_ptr())
+    if hit is None or hit[0] != stamp:
+        N, K = p.shape
+        img = torch.empty(N, 3 * K, dtype=torch.bfloat16, device=p.device)
+        L.check(L.split3_bf16(ops._p(p.detach()), K, ops._p(img), 3 * K, N, K, 1, 0, ops._stream()))
+        hit = eng._cache[key] = (stamp, img)
+    return hit[1]
+
+
+SPLIT3_TAIL = os.environ.get("FOURM_VQ_SPLIT3", "1") != "0"
+
+
 def _post_mlp_fwd(eng, vit, stream, R, st, prefix):
-    """x.float() + fc2(tanh(fc1(norm_mlp(x.float()))))  with autocast DISABLED upstream (vit_models.py:494-496): fp32 operands on the
-    fp32 matrix cores (fm_gemm_f32: v_mfma_f32_32x32x2_f32, exact fp32) - no bf16 rounding in this tail."""
+    """x.float() + fc2(tanh(fc1(norm_mlp(x.float()))))  with autocast DISABLED upstream (vit_models.py:494-496).
+    Training (st given): fp32 operands on the fp32 matrix cores (fm_gemm_f32: v_mfma_f32_32x32x2_f32, exact fp32; the backward needs t).
+    Inference: each fp32 operand as two bf16 halves, three-term products on the bf16 matrix cores (fm_split3_bf16 + one GEMM with K' = 3 K:
+    ~1e-5 relative, 4 x the rate - round 5; FOURM_VQ_SPLIT3=0 keeps the exact form)."""
     ws, f32, D, Rp = eng.ws, torch.float32, eng.D, stream.shape[0]
     n = ws.get(prefix + ".n", (Rp, D), f32)
     mu = rs = None
@@ -108,9 +127,19 @@ def _post_mlp_fwd(eng, vit, stream, R, st, prefix):
         mu, rs = ws.get(prefix + ".mu", (Rp,), f32), ws.get(prefix + ".rs", (Rp,), f32)
     ops.layernorm_fwd(stream, vit.norm_mlp.weight, vit.norm_mlp.bias, n, mu, rs, eps=vit.norm_mlp.eps, R=R)
     hid = vit.post_mlp.fc1.weight.shape[0]
+    out = ws.get(prefix + ".post", (Rp, D), f32)
+    if st is None and SPLIT3_TAIL and D % 64 == 0 and hid % 64 == 0:
+        bf = torch.bfloat16
+        n3 = ws.get(prefix + ".n3", (Rp, 3 * D), bf)
+        L.check(L.split3_bf16(ops._p(n), D, ops._p(n3), 3 * D, R, D, 0, 0, ops._stream()))
+        pre = ws.get(prefix + ".pre", (Rp, hid), f32)
+        ops.gemm_nt(n3, _split3_weight(eng, vit.post_mlp.fc1.weight), pre, epilogue=L.EPI_F32, bias=vit.post_mlp.fc1.bias, M=R, N=hid, K=3 * D)
+        t3 = ws.get(prefix + ".t3", (Rp, 3 * hid), bf)
+        L.check(L.split3_bf16(ops._p(pre), hid, ops._p(t3), 3 * hid, R, hid, 0, 1, ops._stream()))          # tanh, then the split
+        ops.gemm_nt(t3, _split3_weight(eng, vit.post_mlp.fc2.weight), out, epilogue=L.EPI_F32, res=stream, bias=vit.post_mlp.fc2.bias, M=R, N=D, K=3 * hid)      # (EPI_F32 + res: no bf16 rounding of the branch)
+        return out
     t = ws.get(prefix + ".t", (Rp, hid), f32)
     ops.gemm_nt(n, vit.post_mlp.fc1.weight.detach(), t, epilogue=L.EPI_TANH, bias=vit.post_mlp.fc1.bias, M=R, N=hid, K=D)
-    out = ws.get(prefix + ".post", (Rp, D), f32)
     ops.gemm_nt(t, vit.post_mlp.fc2.weight.detach(), out, epilogue=L.EPI_RESIDUAL, res=stream, bias=vit.post_mlp.fc2.bias, M=R, N=D, K=hid)
     if st is not None:
         st["post"] = dict(x=stream, n=n, t=t, mu=mu, rs=rs)
