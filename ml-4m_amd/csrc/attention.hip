@@ -19,6 +19,10 @@
 #include "common.h"
 #include "fourm_hip.h"
 
+#ifndef ATTN_V2_SCHED
+#define ATTN_V2_SCHED 0        // lab knob (tools/r05_attn_variants.sh builds the alternatives into separate libraries)
+#endif
+
 namespace {
 
 constexpr int HD = 64;
@@ -640,7 +644,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
         if (threadIdx.x < N) {
             const int k = threadIdx.x;
             if constexpr (MASK == FM_MASK_DECODER) uk_l[k] = ((a.modk ? (int)a.modk[(size_t)b * N + k] : 0) << 9) + k;
-            else if constexpr (MASK == FM_MASK_KEYPAD) uk_l[k] = a.kpad[(size_t)b * N + k] != 0;
+            else if constexpr (MASK == FM_MASK_KEYPAD) uk_l[k] = a.kpad ? a.kpad[(size_t)b * N + k] != 0 : 0;
         }
         float dl = 0.f;
 #pragma unroll
@@ -768,6 +772,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
                 dKt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(oT0, df, qb * 32 + sblk * 16), db, dKt[df], 0, 0, 0);
             }
         }
+#if ATTN_V2_SCHED == 1
+        __builtin_amdgcn_sched_barrier(0);      // lab variant: no instruction crosses a q-block boundary
+#endif
     }
     {   // lanes l and l+32 own the same key row: 16-byte stores (store_bf16_groups), one output after the other
         const bool wide_k = (a.lddk & 7) == 0 && (((uintptr_t)a.dK) & 15) == 0;
@@ -921,6 +928,15 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
         (void)once;                                                                                                                       \
         hipLaunchKernelGGL(k, grid, dim3(256), lds128, (hipStream_t)stream, a);                                                           \
     }
+        // The unmasked case runs on the key-padding instantiation with no padded key (kpad = NULL): hipcc schedules that body better than
+        // the mask-free one (98 vs 108 us at the bench shape, profiles/r05_attn_variants.txt); FOURM_ATTN_NONE_AS_KEYPAD=0 keeps the latter.
+        static const bool none_as_keypad = [] { const char* e = getenv("FOURM_ATTN_NONE_AS_KEYPAD"); return !e || atoi(e) != 0; }();
+        if (a.mask_kind == FM_MASK_NONE && none_as_keypad) {
+            a.kpad = nullptr;
+            BWD128(FM_MASK_KEYPAD);
+            FM_CHECK_LAUNCH("fm_attn_bwd");
+            return 0;
+        }
         switch (a.mask_kind) {
             case FM_MASK_NONE: BWD128(FM_MASK_NONE); break;
             case FM_MASK_KEYPAD: BWD128(FM_MASK_KEYPAD); break;

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 FM_MAX_MODS = 24
-_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_lib", "libfourm_hip.so")
+_LIB_PATH = os.environ.get("FOURM_HIP_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_lib", "libfourm_hip.so")
+# (FOURM_HIP_LIB: a kernel-lab build of the same ABI, e.g. tools/r05_attn_variants.sh; the product always loads the in-tree library)
 
 
 class FourmHipUnavailable(ImportError):
