@@ -12,21 +12,30 @@ What is frozen at capture time (documented deviations from the eager path):
   * the parameter set with gradients, loss type, token budgets, clipping mode.
 A graphed step refuses to run (loudly) if the engine's workspace or flat stores were re-allocated after capture.
 
-Single process only: with a gradient reducer attached (data parallel) the step stays eager - RCCL launches are not captured here.
+Data parallel: with a gradient reducer that goes through torch.distributed the step stays eager (torch's NCCL watchdog polls the
+captured collectives' events: hipErrorCapturedEvent, round 4).  With the DIRECT exchange (``DataParallel(comm="direct")``: ncclAllReduce
+through ctypes on a side stream, event fences, fourm/parallel/rccl.py) the collectives are nodes of the graph: pass the wrapper as
+``data_parallel``.  Exercised at world size 1 with forced collectives (tests/test_parallel_gpu.py); no N > 1 run exists.
 """
 import torch
 
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, mod_dict, num_encoder_tokens: int, num_decoder_tokens: int, loss_type: str = "mod",
-                 clip_grad=None, warmup: int = 2, order_seed=None):
+                 clip_grad=None, warmup: int = 2, order_seed=None, data_parallel=None):
         """``order_seed``: seed ``random`` right before the captured forward, i.e. choose the (frozen) decoder modality order."""
         from fourm.utils.optim_factory import FusedAdamW
         if not isinstance(optimizer, FusedAdamW):
             raise TypeError("GraphedTrainStep needs FusedAdamW (device-side hyper-parameters)")
         eng = model.engine
-        if eng.reducer is not None:
-            raise RuntimeError("a gradient reducer is attached (data parallel): the step stays eager")
+        self.dp = data_parallel
+        if data_parallel is not None:
+            if getattr(data_parallel, "_comm", "torch") != "direct":
+                raise RuntimeError("GraphedTrainStep(data_parallel=...) needs DataParallel(comm='direct'): collectives issued through torch.distributed "
+                                   "cannot be captured (torch's NCCL watchdog polls their events)")
+            data_parallel.time_exchange = False          # (timing events are not recorded inside a capture)
+        elif eng.reducer is not None:
+            raise RuntimeError("a gradient reducer is attached (data parallel): pass the DataParallel wrapper as data_parallel (comm='direct'), or stay eager")
         self.model, self.opt, self.n_enc, self.n_dec, self.loss_type, self.clip = model, optimizer, num_encoder_tokens, num_decoder_tokens, loss_type, clip_grad
         dev = model.mask_token.device
         self.static = {m: {k: v.detach().clone().to(dev) for k, v in d.items() if torch.is_tensor(v)} for m, d in mod_dict.items()}
@@ -57,7 +66,7 @@ class GraphedTrainStep:
         return (eng.flat_params.data_ptr(), eng.flat_grads.data_ptr(), len(eng.ws.bufs), tuple(sorted((k, v.data_ptr()) for k, v in eng.ws.bufs.items()))[:8])
 
     def _launches(self):
-        loss, mod_loss = self.model(self.static, self.n_enc, self.n_dec, loss_type=self.loss_type)
+        loss, mod_loss = (self.dp or self.model)(self.static, self.n_enc, self.n_dec, loss_type=self.loss_type)
         loss.backward()
         norm = self.opt.fused_grad_norm(clip=self.clip)
         self.opt.step()

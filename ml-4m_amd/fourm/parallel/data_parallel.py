@@ -37,7 +37,7 @@ class GradReducer:
 
     def __init__(self, flat: torch.Tensor, ranges_by_stage: Dict[str, Sequence[Tuple[int, int]]], group=None,
                  bucket_elems: int = 64 * 1024 * 1024, algorithm: str = "all_reduce", wire_dtype=None, force: bool = False,
-                 min_launch_mb: float = 0.0, pack=None, unpack=None):
+                 min_launch_mb: float = 0.0, pack=None, unpack=None, comm: str = "torch"):
         """``pack(src_f32, dst_wire)`` / ``unpack(src_wire, dst_f32, scale)``: the wire-format conversions; default = the HIP kernels
         fm_f32_to_bf16 / fm_bf16_to_f32_scaled on the compute stream (the CPU tests of the bucketing logic inject torch copies: there is
         no other implementation behind the default)."""
@@ -62,6 +62,17 @@ class GradReducer:
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"          # RCCL averages in the collective; gloo has no AVG
         self._pack, self._unpack = pack, unpack
+        # comm = "direct": RCCL called on a side stream with event fences (fourm.parallel.rccl), no torch Work objects - the form a captured
+        # train step needs (torch's NCCL watchdog polls captured events: DESIGN §6).  GPU stores only; "torch" is the default.
+        if comm not in ("torch", "direct"):
+            raise ValueError(f"comm {comm!r}: 'torch' or 'direct'")
+        self._direct = None
+        if comm == "direct" and (self.world > 1 or force):
+            if not flat.is_cuda:
+                raise ValueError("comm='direct' needs the gradient store on a GPU")
+            from .rccl import DirectComm
+            self._direct = DirectComm(group, flat.device)
+            self._avg = True
         self._wire_bufs = {}                   # (offset, length) -> bf16 staging buffer, allocated once
         self._shards = {}
         # measurement hooks (bench.py): events around finish() on the compute stream = the part of the exchange the backward did not hide
@@ -103,8 +114,33 @@ class GradReducer:
             self._exch_events = []
         return out
 
+    def _exchange_direct(self, t: torch.Tensor, op):
+        from .rccl import _DirectWork
+        d = self._direct
+        d.stream.wait_stream(torch.cuda.current_stream())               # the slice is final on the compute stream
+        avg = op == dist.ReduceOp.AVG
+        if self.algorithm == "reduce_scatter" and t.numel() >= self.world:
+            head = t.numel() // self.world * self.world
+            key = (t.data_ptr(), head)
+            shard = self._shards.get(key)
+            if shard is None:
+                shard = self._shards[key] = torch.empty(head // self.world, dtype=t.dtype, device=t.device)
+            d.reduce_scatter(shard, t[:head], avg)
+            d.all_gather(t[:head], shard)
+            self.n_collectives += 2
+            if head < t.numel():
+                d.all_reduce_(t[head:], avg)
+                self.n_collectives += 1
+        else:
+            d.all_reduce_(t, avg)
+            self.n_collectives += 1
+        self.bytes_on_wire += t.numel() * t.element_size()
+        return [_DirectWork(d)]
+
     def _exchange(self, t: torch.Tensor, op):
         """Asynchronous collectives that leave the cross-rank reduction of ``t`` in ``t``; returns the work handles."""
+        if self._direct is not None:
+            return self._exchange_direct(t, op)
         if self.algorithm == "reduce_scatter" and t.numel() >= self.world:
             head = t.numel() // self.world * self.world
             key = (t.data_ptr(), head)
@@ -212,7 +248,7 @@ class DataParallel(nn.Module):
 
     def __init__(self, module: nn.Module, device_ids=None, find_unused_parameters: bool = False, process_group=None,
                  bucket_mb: int = 256, algorithm: str = "all_reduce", wire_dtype=None, reserved_cus: Optional[int] = None,
-                 force_collectives: bool = False, min_launch_mb: Optional[float] = None, exchange: Optional[str] = None):
+                 force_collectives: bool = False, min_launch_mb: Optional[float] = None, exchange: Optional[str] = None, comm: Optional[str] = None):
         """``exchange`` (env FOURM_DP_EXCHANGE): "overlap" (default) - a stage's gradient slices are exchanged while the next stage computes;
         "tail" - nothing is exchanged under the backward, the whole gradient store goes out in bucket-sized collectives when the backward
         has finished (4M-B: 1.44 GB fp32; a ring all-reduce moves 2 (N - 1) / N of it over each GPU's links).
@@ -244,6 +280,7 @@ class DataParallel(nn.Module):
         if reserved_cus is None:
             reserved_cus = int(os.environ.get("FOURM_DP_RESERVED_CUS", str(DEFAULT_RESERVED_CUS)))
         self._reserved_cus = 0 if self._exchange_mode == "tail" else reserved_cus
+        self._comm = (comm or os.environ.get("FOURM_DP_COMM", "torch")).lower()      # "direct": fourm.parallel.rccl (ctypes RCCL on a side stream)
         self._reducer: Optional[GradReducer] = None
         self._reducer_for = None
         if dist.is_initialized() and (dist.get_world_size(process_group) > 1 or force_collectives):
@@ -290,7 +327,8 @@ class DataParallel(nn.Module):
         eng._ensure_flat()
         if self._reducer is None or self._reducer_for is not eng.flat_grads:
             self._reducer = GradReducer(eng.flat_grads, eng.grad_stages(), self.process_group, self._bucket_elems,
-                                        algorithm=self._algorithm, wire_dtype=self._wire, force=self._force, min_launch_mb=self._min_launch_mb)
+                                        algorithm=self._algorithm, wire_dtype=self._wire, force=self._force, min_launch_mb=self._min_launch_mb,
+                                        comm=self._comm if eng.flat_grads.is_cuda and dist.get_backend(self.process_group) == "nccl" else "torch")
             self._reducer_for = eng.flat_grads
             self._reducer.time_exchange = bool(getattr(self, "time_exchange", False))
             if eng.flat_grads.is_cuda and dist.get_backend(self.process_group) == "nccl":

@@ -130,7 +130,9 @@ def nccl_worker(port, out_dir):
     case = build_case(CASE)
     res = {}
     for name, kw in (("allreduce_fp32", {}), ("rs_ag_fp32", dict(algorithm="reduce_scatter")),
-                     ("allreduce_bf16", dict(wire_dtype=torch.bfloat16)), ("rs_ag_bf16", dict(algorithm="reduce_scatter", wire_dtype=torch.bfloat16))):
+                     ("allreduce_bf16", dict(wire_dtype=torch.bfloat16)), ("rs_ag_bf16", dict(algorithm="reduce_scatter", wire_dtype=torch.bfloat16)),
+                     # RCCL called directly on a side stream (fourm.parallel.rccl): no torch Work objects, capturable
+                     ("direct_allreduce_fp32", dict(comm="direct")), ("direct_rs_ag_bf16", dict(comm="direct", algorithm="reduce_scatter", wire_dtype=torch.bfloat16))):
         model = _model(case)
         want = _local_grads(model, case, 0, [0]).cpu()
         model.zero_grad(set_to_none=True)
@@ -141,8 +143,36 @@ def nccl_worker(port, out_dir):
         red = model.engine.reducer
         assert red is not None and len(red._done) >= 1 and ("wire_dtype" not in kw or len(red._wire_bufs) >= 1)      # the stages did exchange
         assert _lib.lib.fm_get_reserved_cus() == 16
+        assert (red._direct is not None) == (kw.get("comm") == "direct") and red.n_collectives >= 1
         got = model.engine.flat_grads.detach().cpu()
         res[name] = float((got - want).norm() / want.norm())
+    # the whole data-parallel step as ONE hipGraph with the direct exchange inside: three replays follow three eager steps
+    from fourm.hip.graph import GraphedTrainStep
+    from fourm.utils.optim_factory import FusedAdamW
+
+    def make():
+        m = _model(case)
+        o = FusedAdamW([{"params": [p for p in m.parameters() if p.dim() > 1], "weight_decay": 0.05}, {"params": [p for p in m.parameters() if p.dim() <= 1], "weight_decay": 0.0}],
+                       lr=1e-3, betas=(0.9, 0.95))
+        return m, o, DataParallel(m, force_collectives=True, bucket_mb=1, comm="direct")
+    batches = [_batch(case, 0, i) for i in range(3)]
+    me, oe, dpe = make()
+    eager = []
+    for b in batches:
+        random.seed(11); loss = dpe(b, case["N"], case["M"])[0]; loss.backward()
+        oe.fused_grad_norm(clip=1.0); oe.step(); oe.zero_grad(set_to_none=True)
+        eager.append(float(loss.detach()))
+    mg, og, dpg = make()
+    sd0 = {k: v.clone() for k, v in mg.state_dict().items()}
+    gs = GraphedTrainStep(mg, og, batches[0], case["N"], case["M"], clip_grad=1.0, order_seed=11, data_parallel=dpg)
+    mg.load_state_dict(sd0)
+    for st in og.state.values():
+        st["step"].zero_(); st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+    gs.resync()
+    graphed = [float(gs.step(b)[0]) for b in batches]
+    torch.cuda.synchronize()
+    res["graph_losses"] = (eager, graphed)
+    res["graph_collectives"] = mg.engine.reducer.n_collectives
     torch.save(res, os.path.join(out_dir, "nccl.pt"))
     dist.destroy_process_group()
 
@@ -156,6 +186,9 @@ def test_rccl_code_path_world_size_one(tmp_path):
     assert res["allreduce_fp32"] < 1e-6 and res["rs_ag_fp32"] < 1e-6, res          # identity (atomic order noise of the backward only)
     assert res["allreduce_bf16"] < 4e-3 and res["rs_ag_bf16"] < 4e-3, res          # one bf16 rounding of every gradient
     assert res["allreduce_bf16"] > 1e-4                                             # ... which did happen
+    assert res["direct_allreduce_fp32"] < 1e-6 and 1e-4 < res["direct_rs_ag_bf16"] < 4e-3, res      # ncclAllReduce / ReduceScatter / AllGather through ctypes
+    eager, graphed = res["graph_losses"]                                            # captured data-parallel step (direct exchange inside the graph)
+    assert all(abs(a - b) < 1e-3 * abs(a) for a, b in zip(eager, graphed)) and abs(eager[0] - eager[-1]) > 1e-3, res["graph_losses"]
 
 
 def vq_sync_worker(rank, world, port, out_dir):
