@@ -844,6 +844,253 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same backward with 51 KB of LDS and <= 168 registers: THREE workgroups per CU instead of two (the r05 counters of attn_bwd128_kernel:
+// 52 % of the wave cycles are issue stalls on dependent MFMA / VALU chains, 24 % waits - more resident waves is what covers them).
+//   * dS^T overlays the rows it was computed from: region qb (8 KB) holds Q[32 qb ..] and dO[32 qb ..] (32 rows x 128 bytes each) until
+//     every wave has multiplied q-block qb (one barrier per q-block), then the 128 keys x 32 queries of dS^T (64-byte rows);
+//   * K has its own 16 KB tile from the prologue on (pass B's operand; pass A re-reads its 32 key rows per q-block instead of holding
+//     them in 16 registers); V stays in registers.
+// ------------------------------------------------------------------------------------------------
+template <int MASK>
+__global__ __launch_bounds__(256, 3) void attn_bwd128o_kernel(AttnArgs a) {
+    constexpr int N = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+    typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+    const lds_ptr L = (lds_ptr)smem;
+    constexpr uint32_t RG = 8192, oK = 4 * RG, oNM = oK + N * ROWB, oDL = oNM + 4 * N, oPB = oDL + 4 * N, oWQ = oPB + 4 * N, oFULL = oWQ + 4 * N,
+                       oUK = oFULL + 4 * N;
+    float* nm_l = (float*)(smem + oNM); float* dl_l = (float*)(smem + oDL); float* pb_l = (float*)(smem + oPB);
+    int* wq_l = (int*)(smem + oWQ); int* full_l = (int*)(smem + oFULL); int* uk_l = (int*)(smem + oUK);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fhi = lane >> 5, r31 = lane & 31;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const bf16_t* Qb = a.Q + (size_t)b * N * a.ldq + h * HD;
+    const bf16_t* Kb = a.K + (size_t)b * N * a.ldk + h * HD;
+    const bf16_t* Vb = a.V + (size_t)b * N * a.ldv + h * HD;
+    const bf16_t* Ob = a.O + (size_t)b * N * a.ldo + h * HD;
+    const bf16_t* dOb = a.dO + (size_t)b * N * a.lddo + h * HD;
+
+    // LDS-DMA: piece p = rows 8 p .. 8 p + 7 of a tile; Q / dO pieces land in their q-block's region, K in its own tile
+    for (int p = wave; p < N / 8; p += 4) {
+        const int t = p * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ sw3(t);
+        const uint32_t dst = (p >> 2) * RG + (p & 3) * 1024;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(Qb + (size_t)t * a.ldq + lc * 8), LDS_PTR(smem + dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(dOb + (size_t)t * a.lddo + lc * 8), LDS_PTR(smem + dst + 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(Kb + (size_t)t * a.ldk + lc * 8), LDS_PTR(smem + oK + p * 1024), 16, 0, 0);
+    }
+    const int key = wave * 32 + r31;                     // pass A: this lane's key
+    bf16x8_t vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) vf[kk] = *(const bf16x8_t*)(Vb + (size_t)key * a.ldv + (kk * 2 + fhi) * 8);
+    {   // per-query constants: two threads per query row (4 x 16-byte loads each from O and dO)
+        const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
+        const uint4* op = (const uint4*)(Ob + (size_t)q * a.ldo + half * 32);
+        const uint4* gp = (const uint4*)(dOb + (size_t)q * a.lddo + half * 32);
+        uint4 ov[4], gv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ov[i] = op[i]; gv[i] = gp[i]; }
+        const size_t si = ((size_t)b * a.H + h) * N + q;
+        const float m = a.stat_m[si], l = a.stat_l[si];
+        int csv = 255, lov = 0;
+        if constexpr (MASK == FM_MASK_DECODER) {
+            if (a.causal) csv = q + 1;
+            else if (a.cs) csv = min(max(a.cs[(size_t)b * N + q], 0), 255);
+            if (a.modq) lov = (int)a.modq[(size_t)b * N + q] << 9;
+        }
+        if (threadIdx.x < N) {
+            const int k = threadIdx.x;
+            if constexpr (MASK == FM_MASK_DECODER) uk_l[k] = ((a.modk ? (int)a.modk[(size_t)b * N + k] : 0) << 9) + k;
+            else if constexpr (MASK == FM_MASK_KEYPAD) uk_l[k] = a.kpad ? a.kpad[(size_t)b * N + k] != 0 : 0;
+        }
+        float dl = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t* o32 = (const uint32_t*)&ov[i];
+            const uint32_t* g32 = (const uint32_t*)&gv[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dl += bf2f((bf16_t)(o32[e] & 0xffff)) * bf2f((bf16_t)(g32[e] & 0xffff)) + bf2f((bf16_t)(o32[e] >> 16)) * bf2f((bf16_t)(g32[e] >> 16));
+        }
+        dl += __shfl_xor(dl, 1, 64);
+        if (half == 0) {
+            const bool full = MASK != FM_MASK_NONE && m < -1e38f;
+            nm_l[q] = full ? 0.f : -(m + __log2f(l));
+            dl_l[q] = dl;
+            pb_l[q] = full ? -__log2f(l) : -INFINITY;
+            wq_l[q] = lov + csv - 1; full_l[q] = full;
+        }
+    }
+    __syncthreads();
+    if constexpr (MASK != FM_MASK_NONE) {
+        if (__ballot(full_l[lane] | full_l[lane + 64]) != 0ull) {      // fully blocked rows: zero their Q row (see attn_bwd128_kernel)
+            const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
+            if (full_l[q]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(uint4*)(smem + (q >> 5) * RG + (q & 31) * ROWB + half * 64 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+        }
+    }
+
+    uint32_t rowo[4];                                    // row fragment (MFMA A operand) of row r31 of a 32-row block, k-step kk
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) rowo[kk] = r31 * ROWB + (((kk * 2 + fhi) ^ sw3(r31)) << 4);
+    uint32_t colo[2][2], dsco[2];                        // transpose-read bases: 128-byte rows (Q, dO, K) and 64-byte rows (dS^T)
+    {
+        const int i = lane & 15;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int rl = 4 * fhi + 8 * e + (i >> 2);
+#pragma unroll
+            for (int df = 0; df < 2; ++df) {
+                const int c = df * 32 + ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+                colo[e][df] = rl * ROWB + (((c >> 3) ^ sw3(rl)) << 4) + (c & 7) * 2;
+            }
+            const int c = ((lane >> 4) & 1) * 16 + (i & 3) * 4;
+            dsco[e] = rl * 64 + (((c >> 3) ^ ((rl >> 1) & 3)) << 4) + (c & 7) * 2;
+        }
+    }
+    auto col_frag = [&](uint32_t base, int df) -> bf16x8_t {       // rows base + 4 fhi + {0..3, 8..11} of a 128-byte-row tile, columns of block df
+        union { bf16x8_t v; s16x4_t h[2]; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(L + colo[0][df] + base));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(L + colo[1][df] + base));
+        return u.v;
+    };
+    const float c2 = a.scale * LOG2E;
+    unsigned long long kpmask = 0;
+    int ukey = 0;
+    if constexpr (MASK == FM_MASK_DECODER) ukey = *(const __attribute__((address_space(3))) int*)(L + oUK + 4 * key);
+    if constexpr (MASK == FM_MASK_KEYPAD) kpmask = __ballot(*(const __attribute__((address_space(3))) int*)(L + oUK + 4 * key) != 0);
+    auto sel = [](float if0, float if1, unsigned long long mask) {      // (see attn_bwd128_kernel: never behind a v_exp)
+        float r;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+        return r;
+    };
+    const uint32_t dswo = key * 64 + (((key >> 1) & 3) << 4) + 8 * fhi;       // dS^T store of key row `key`: chunk c at dswo ^ (c << 4)
+
+    // ---- pass A ----------------------------------------------------------------------------------
+    f32x16_t dKt[2], dVt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dKt[i][r] = dVt[i][r] = 0.f;
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8_t kf = *(const __attribute__((address_space(3))) bf16x8_t*)(L + rowo[kk] + oK + wave * 32 * ROWB);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const __attribute__((address_space(3))) bf16x8_t*)(L + rowo[kk] + qb * RG), kf, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const __attribute__((address_space(3))) bf16x8_t*)(L + rowo[kk] + qb * RG + 4096), vf[kk], dp, 0, 0, 0);
+        }
+        float pv[16], dsv[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t qo = 4 * (qb * 32 + 8 * g) + 16 * fhi;
+            const f32x4_t nm4 = *(const __attribute__((address_space(3))) f32x4_t*)(L + oNM + qo);
+            const f32x4_t dl4 = *(const __attribute__((address_space(3))) f32x4_t*)(L + oDL + qo);
+            f32x4_t pb4 = {0.f, 0.f, 0.f, 0.f};
+            i32x4_t wq4 = {0, 0, 0, 0};
+            if constexpr (MASK != FM_MASK_NONE) pb4 = *(const __attribute__((address_space(3))) f32x4_t*)(L + oPB + qo);
+            if constexpr (MASK == FM_MASK_DECODER) wq4 = *(const __attribute__((address_space(3))) i32x4_t*)(L + oWQ + qo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j;
+                float t = __builtin_fmaf(s[r], c2, nm4[j]);
+                if constexpr (MASK == FM_MASK_KEYPAD) t = sel(t, pb4[j], kpmask);
+                if constexpr (MASK == FM_MASK_DECODER) t = sel(t, pb4[j], __ballot((unsigned)(wq4[j] - ukey) >= 255u));
+                const float p = __builtin_amdgcn_exp2f(t);
+                pv[r] = p;
+                dsv[r] = p * (dp[r] - dl4[j]);
+            }
+        }
+        u32x2_t dsp[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) dsp[g4] = u32x2_t{pack2bf(dsv[4 * g4], dsv[4 * g4 + 1]), pack2bf(dsv[4 * g4 + 2], dsv[4 * g4 + 3])};
+#pragma unroll
+        for (int sblk = 0; sblk < 2; ++sblk) {
+            const bf16x8_t pb = pack8(&pv[8 * sblk]);
+            union { bf16x8_t v; u32x2_t h[2]; } db;
+            db.h[0] = dsp[2 * sblk]; db.h[1] = dsp[2 * sblk + 1];
+#pragma unroll
+            for (int df = 0; df < 2; ++df) {
+                dVt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(qb * RG + 4096 + sblk * 16 * ROWB, df), pb, dVt[df], 0, 0, 0);
+                dKt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(qb * RG + sblk * 16 * ROWB, df), db.v, dKt[df], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                 // every wave has multiplied q-block qb: its region takes dS^T[:, 32 qb ..]
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) *(__attribute__((address_space(3))) u32x2_t*)(L + ((dswo ^ (g4 << 4)) + qb * RG)) = dsp[g4];
+    }
+    {
+        const bool wide_k = (a.lddk & 7) == 0 && (((uintptr_t)a.dK) & 15) == 0;
+        const bool wide_v = (a.lddv & 7) == 0 && (((uintptr_t)a.dV) & 15) == 0;
+        bf16_t* dkrow = a.dK + ((size_t)b * N + key) * a.lddk + h * HD;
+        bf16_t* dvrow = a.dV + ((size_t)b * N + key) * a.lddv + h * HD;
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int df = 0; df < 2; ++df)
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const f32x16_t& t = which ? dVt[df] : dKt[df];
+                    const float sc = which ? 1.0f : a.scale;
+                    uint2 pk[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        pk[u] = make_uint2(pack2bf(t[4 * (g + u)] * sc, t[4 * (g + u) + 1] * sc), pack2bf(t[4 * (g + u) + 2] * sc, t[4 * (g + u) + 3] * sc));
+                    store_bf16_groups(which ? dvrow : dkrow, df * 32 + 8 * g, pk[0], pk[1], fhi, HD, which ? wide_v : wide_k);
+                }
+    }
+    __syncthreads();                                     // the dS^T of the last q-block is in place
+
+    // ---- pass B: dQ = dS K for this wave's 32 queries -----------------------------------------------
+    {
+        const int qb = wave;
+        const int q = qb * 32 + r31;
+        f32x16_t dQt[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int sblk = 0; sblk < 2; ++sblk) {
+                const int rows = kb * 32 + sblk * 16;
+                union { bf16x8_t v; s16x4_t h[2]; } db;
+                db.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(L + dsco[0] + wave * RG + rows * 64));
+                db.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(L + dsco[1] + wave * RG + rows * 64));
+#pragma unroll
+                for (int df = 0; df < 2; ++df) dQt[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(col_frag(oK + rows * ROWB, df), db.v, dQt[df], 0, 0, 0);
+            }
+        float sc = a.scale;
+        if constexpr (MASK != FM_MASK_NONE) sc = full_l[q] ? 0.f : sc;
+        const bool wide_q = (a.lddq & 7) == 0 && (((uintptr_t)a.dQ) & 15) == 0;
+        bf16_t* dqrow = a.dQ + ((size_t)b * N + q) * a.lddq + h * HD;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                uint2 pq[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    pq[u] = make_uint2(pack2bf(dQt[df][4 * (g + u)] * sc, dQt[df][4 * (g + u) + 1] * sc),
+                                       pack2bf(dQt[df][4 * (g + u) + 2] * sc, dQt[df][4 * (g + u) + 3] * sc));
+                store_bf16_groups(dqrow, df * 32 + 8 * g, pq[0], pq[1], fhi, HD, wide_q);
+            }
+    }
+}
+
 int fill(AttnArgs& a, const fm_attn_args* p, const char* who) {
     FM_CHECK_ARG(p && p->Q && p->K && p->V && p->O, "%s: null pointer", who);
     FM_CHECK_ARG(p->head_dim == HD, "%s: head_dim=%d unsupported (this build handles 64)", who, p->head_dim);
@@ -921,13 +1168,25 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     static const bool v2_on = [] { const char* e = getenv("FOURM_ATTN_BWD_V2"); return !e || atoi(e) != 0; }();
     if (v2_on && tr && a.Nq == 128 && a.Nk == 128 && a.mask_kind != FM_MASK_DENSE) {
         const size_t lds128 = (size_t)4 * 128 * ROWB + 6 * 128 * 4;
-#define BWD128(MK)                                                                                                                        \
+        // Which of the two 128 x 128 kernels (profiles/r05_attn_ov.txt, B = 256, H = 12): the 3-workgroups-per-CU overlay form wins where the
+        // per-score VALU work is largest (decoder rule: 91.6 vs 106.6 us) and loses slightly elsewhere (key padding 95.4 vs 93.2, none 98.3 vs
+        // 95.9): default = overlay for the decoder mask only.  FOURM_ATTN_BWD_OV=0 / 1 forces one form for every mask.
+        static const int ov_mode = [] { const char* e = getenv("FOURM_ATTN_BWD_OV"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+        const bool ov_on = ov_mode < 0 ? a.mask_kind == FM_MASK_DECODER : ov_mode == 1;
+        if (ov_on) {      // 51 KB / <= 168 registers: three workgroups per CU
+            const size_t ldso = (size_t)4 * 8192 + 128 * ROWB + 6 * 128 * 4;
+#define BWD128O(MK)                                                                                                                       \
     {                                                                                                                                     \
-        auto k = attn_bwd128_kernel<MK>;                                                                                                  \
-        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);   \
-        (void)once;                                                                                                                       \
-        hipLaunchKernelGGL(k, grid, dim3(256), lds128, (hipStream_t)stream, a);                                                           \
+        auto k = attn_bwd128o_kernel<MK>;                                                                                                 \
+        hipLaunchKernelGGL(k, grid, dim3(256), ldso, (hipStream_t)stream, a);                                                             \
     }
+            if (a.mask_kind == FM_MASK_NONE) { a.kpad = nullptr; BWD128O(FM_MASK_KEYPAD) }
+            else if (a.mask_kind == FM_MASK_KEYPAD) BWD128O(FM_MASK_KEYPAD)
+            else BWD128O(FM_MASK_DECODER)
+#undef BWD128O
+            FM_CHECK_LAUNCH("fm_attn_bwd");
+            return 0;
+        }
         // The unmasked case runs on the key-padding instantiation with no padded key (kpad = NULL): hipcc schedules that body better than
         // the mask-free one (98 vs 108 us at the bench shape, profiles/r05_attn_variants.txt); FOURM_ATTN_NONE_AS_KEYPAD=0 keeps the latter.
         static const bool none_as_keypad = [] { const char* e = getenv("FOURM_ATTN_NONE_AS_KEYPAD"); return !e || atoi(e) != 0; }();
