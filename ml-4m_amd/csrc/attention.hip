@@ -1187,6 +1187,13 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
             FM_CHECK_LAUNCH("fm_attn_bwd");
             return 0;
         }
+#define BWD128(MK)                                                                                                                        \
+    {                                                                                                                                     \
+        auto k = attn_bwd128_kernel<MK>;                                                                                                  \
+        static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess);   \
+        (void)once;                                                                                                                       \
+        hipLaunchKernelGGL(k, grid, dim3(256), lds128, (hipStream_t)stream, a);                                                           \
+    }
         // The unmasked case runs on the key-padding instantiation with no padded key (kpad = NULL): hipcc schedules that body better than
         // the mask-free one (98 vs 108 us at the bench shape, profiles/r05_attn_variants.txt); FOURM_ATTN_NONE_AS_KEYPAD=0 keeps the latter.
         static const bool none_as_keypad = [] { const char* e = getenv("FOURM_ATTN_NONE_AS_KEYPAD"); return !e || atoi(e) != 0; }();
