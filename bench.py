@@ -124,7 +124,7 @@ class LaunchProfiler:
 
 KERNEL_REGEX = {   # profiler family -> regex on the demangled kernel name (7th template argument of gemm_nt = epilogue)
     "gemm_nt": r"(gemm_nt3_kernel<\d+, {epi}, |gemm_nt_kernel<\d+, \d+, \d+, \d+, \d+, \d+, {epi}, false)",
-    "gemm_tn": r"gemm_tn_kernel<\w+, false", "gemm_tn_multi": r"gemm_tn_multi_kernel", "attn_fwd": r"attn_fwd_kernel", "attn_bwd": r"attn_bwd_kernel",
+    "gemm_tn": r"gemm_tn_kernel<\w+, false", "gemm_tn_multi": r"gemm_tn_multi_kernel", "attn_fwd": r"attn_fwd_kernel", "attn_bwd": r"attn_bwd\w*_kernel",
     "layernorm_fwd": r"ln_fwd_kernel", "layernorm_bwd": r"ln_bwd_kernel",
 }
 
@@ -473,7 +473,7 @@ def main_vq(a):
         f32_kernel = name.startswith("gemm_f32")
         peak = F32_MATRIX_PEAK_TFLOPS if f32_kernel else BF16_PEAK_TFLOPS
         out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                           "kernel": f"{name} ({'csrc/fp32_verify.hip, fp32 MFMA: peak = the fp32 matrix rate' if f32_kernel else 'csrc/gemm.hip'})",
+                           "kernel": f"{name} ({'csrc/fp32_verify.hip, fp32 MFMA: peak = the fp32 matrix rate' if f32_kernel else 'csrc/gemm_nt3.hip: gemm_nt3_kernel<TW, EPI_BF16, SPLIT, STG, BIAS=true> (biased Linears of the ViT blocks)' if name == 'gemm_nt/epi0' else 'csrc/gemm.hip: gemm_nt_kernel (GELU / fp32-output epilogues)' if name.startswith('gemm_nt') else 'csrc'})",
                            "traffic": traffic, "traffic_detail": detail, "launches_per_step": d["n"] // 2,
                            "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms,
                            "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
@@ -682,7 +682,7 @@ def main():
                              "every dense bf16 Linear of the trunk, forward and dX",
                   "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,64,3,PP=true>  (csrc/gemm.hip)",
                   "gemm_tn_multi": "gemm_tn_multi_kernel<MASKED=false>  (csrc/gemm.hip; all dW GEMMs of a layer per launch)",
-                  "attn_fwd": "attn_fwd_kernel<true,MASK>", "attn_bwd": "attn_bwd_kernel<true,MASK>",
+                  "attn_fwd": "attn_fwd_kernel<true,MASK>", "attn_bwd": "attn_bwd128_kernel<MASK> (key padding) / attn_bwd128o_kernel<MASK> (decoder mask) at 128 x 128 tokens, attn_bwd_kernel<true,MASK,..> otherwise",
                   "layernorm_fwd": "ln_fwd_kernel<bf16,3>", "layernorm_bwd": "ln_bwd_kernel<3>"}
         name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
         fam, _, epi = name.partition("/epi")

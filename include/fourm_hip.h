@@ -538,7 +538,8 @@ int fm_unet_im2col(const void* src1, int ld1, int C1, const void* src2, int ld2,
                    int B, int H, int W, int ksize, int stride, int up1, void* stream);
 /* y = [silu] GroupNorm_groups(x + add[b][c]) * w + b over rows (B, HW, C): fp32 statistics per (sample, group) over HW x C / groups
  * values (two passes), fp32 arithmetic, bf16 result (GroupNorm32, nn.py:23-25; ``add`` f32 (B, >= C) with row stride ld_add, or NULL: the
- * timestep embedding a ResBlock adds in front of out_layers, unet.py:270).  stats: f32 scratch (B * groups, 2). */
+ * timestep embedding a ResBlock adds in front of out_layers, unet.py:270).  stats: f32 scratch of B * groups * 2 * (ceil(HW / 32) + 1) values (per-chunk partial sums,
+ * added in a fixed order: the result is bit-reproducible).  C <= 1024. */
 int fm_groupnorm_nhwc(const void* x, int ldx, const void* add, int ld_add, const void* w, const void* b, void* y, int ldy, void* stats, int B, int HW,
                       int C, int groups, float eps, int silu, void* stream);
 int fm_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows, int C, void* stream);   /* out = a + b, bf16 rows */

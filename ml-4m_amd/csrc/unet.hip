@@ -64,42 +64,74 @@ __global__ __launch_bounds__(256) void im2col_kernel(Im2colArgs a) {
 // GroupNorm(G) over (B, HW, C) rows, fp32 statistics (nn.py:23-25), optional per-(sample, channel) addend in front (ResBlock: h + emb_out,
 // unet.py:270) and SiLU behind (in_layers / out_layers: normalization, SiLU, conv).
 // ------------------------------------------------------------------------------------------------------------------------------------
+// statistics, deterministic (no atomics: two runs of the decoder must agree bit for bit - any last-bit noise in a GroupNorm is amplified to
+// the bf16 rounding level by the layers behind it).  A workgroup takes 32 consecutive rows of one sample and every channel (8-byte coalesced
+// loads: thread = (row lane, channel quad), fixed for all its rows), reduces per channel in registers, per group in LDS in a fixed order,
+// and writes (sum, sum of squares) of its rows to partial[b][chunk][g]; gn_finalize_kernel adds the chunks in order.  B * HW / 32
+// workgroups stream the map once (the first form - one workgroup per (sample, group) gathering 2-byte values at a row stride - took as
+// long as the convolution GEMMs on the 56 x 56 maps).  Sums are taken about a per-group SHIFT (the group's first value of the sample):
+// E[d^2] - E[d]^2 then does not cancel for maps with a large mean.
+constexpr int GN_ROWS = 32;
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ add, int ld_add, int HW, int C, int G,
-                                                       float eps, float* __restrict__ stats) {
-    const int b = blockIdx.x / G, g = blockIdx.x % G;
-    const int cpg = C / G;
-    const bf16_t* xb = x + (size_t)b * HW * ldx + g * cpg;
-    const float* ab = add ? add + (size_t)b * ld_add + g * cpg : nullptr;
-    const int n = HW * cpg;
-    __shared__ float red[8];
-    auto block_sum = [&](float v) {
-        v = wave_sum(v);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        __syncthreads();
-        const float t = red[0] + red[1] + red[2] + red[3];
-        __syncthreads();
-        return t;
-    };
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int p = i / cpg, c = i % cpg;
-        s += bf2f(xb[(size_t)p * ldx + c]) + (ab ? ab[c] : 0.f);
+                                                       float* __restrict__ partial) {
+    extern __shared__ float gsm[];                       // [row_lanes][C][2]
+    const int chunks = (HW + GN_ROWS - 1) / GN_ROWS;
+    const int b = blockIdx.x / chunks, chunk = blockIdx.x % chunks, r0 = chunk * GN_ROWS;
+    const int cpg = C / G, vec = C / 4;
+    const int row_lanes = 256 / vec;                     // >= 1 (C <= 1024)
+    const bf16_t* xb = x + (size_t)b * HW * ldx;
+    const float* ab = add ? add + (size_t)b * ld_add : nullptr;
+    const int nr = min(GN_ROWS, HW - r0);
+    const int rl = threadIdx.x / vec, cq = threadIdx.x % vec;
+    if (rl < row_lanes) {
+        const int c0 = cq * 4;
+        float sh[4], as[4] = {0.f, 0.f, 0.f, 0.f}, aq[4] = {0.f, 0.f, 0.f, 0.f}, av[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (c0 + j) / cpg;
+            sh[j] = bf2f(xb[g * cpg]) + (ab ? ab[g * cpg] : 0.f);              // row 0 of the sample, first channel of the group
+            if (ab) av[j] = ab[c0 + j];
+        }
+        for (int r = rl; r < nr; r += row_lanes) {
+            float f[4];
+            unpack_bf4(*(const uint2*)(xb + (size_t)(r0 + r) * ldx + c0), f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = f[j] + av[j] - sh[j];
+                as[j] += d; aq[j] += d * d;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { gsm[(rl * C + c0 + j) * 2] = as[j]; gsm[(rl * C + c0 + j) * 2 + 1] = aq[j]; }
     }
-    const float mean = block_sum(s) / (float)n;
-    float q = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {        // second pass over the (L2-resident) group: exact two-pass variance
-        const int p = i / cpg, c = i % cpg;
-        const float d = bf2f(xb[(size_t)p * ldx + c]) + (ab ? ab[c] : 0.f) - mean;
-        q += d * d;
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += 256) {
+        float s = 0.f, q = 0.f;
+        for (int l = 0; l < row_lanes; ++l)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += gsm[(l * C + c) * 2]; q += gsm[(l * C + c) * 2 + 1]; }
+        float* o = partial + (((size_t)b * chunks + chunk) * G + g) * 2;
+        o[0] = s; o[1] = q;
     }
-    const float var = block_sum(q) / (float)n;
-    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rsqrtf(var + eps); }
+}
+
+// stats[b][g] = (sum d, sum d^2) over the chunks, in chunk order
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int B, int G, int chunks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i % G;
+    float s = 0.f, q = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        const float* p = partial + (((size_t)b * chunks + c) * G + g) * 2;
+        s += p[0]; q += p[1];
+    }
+    stats[2 * i] = s; stats[2 * i + 1] = q;
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ add, int ld_add, const float* __restrict__ stats,
                                                        const float* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy,
-                                                       int B, int HW, int C, int G, int silu) {
+                                                       int B, int HW, int C, int G, int silu, float eps) {
     const int cpg = C / G, vec = C / 4;
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
     const long long total = (long long)B * HW * vec;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int v = (int)(i % vec);
@@ -112,8 +144,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = c0 + j, g = c / cpg;
-            const float m = stats[2 * (b * G + g)], r = stats[2 * (b * G + g) + 1];
-            float t = (f[j] + (add ? add[(size_t)b * ld_add + c] : 0.f) - m) * r * w[c] + bias[c];
+            const float shift = bf2f(x[(size_t)b * HW * ldx + g * cpg]) + (add ? add[(size_t)b * ld_add + g * cpg] : 0.f);
+            const float md = stats[2 * (b * G + g)] * inv_n;                             // mean - shift
+            const float var = fmaxf(stats[2 * (b * G + g) + 1] * inv_n - md * md, 0.f);
+            float t = (f[j] + (add ? add[(size_t)b * ld_add + c] : 0.f) - shift - md) * rsqrtf(var + eps) * w[c] + bias[c];
             if (silu) t = t / (1.0f + __expf(-t));
             o[j] = t;
         }
@@ -319,9 +353,14 @@ extern "C" int fm_groupnorm_nhwc(const void* x, int ldx, const void* add, int ld
                                  int C, int groups, float eps, int silu, void* stream) {
     FM_CHECK_ARG(x && w && b && y && stats && B > 0 && HW > 0 && C > 0 && groups > 0, "fm_groupnorm_nhwc: bad argument");
     FM_CHECK_ARG(C % groups == 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "fm_groupnorm_nhwc: C=%d groups=%d (C %% groups == 0, C %% 4 == 0)", C, groups);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const float*)add, ld_add, HW, C, groups, eps, (float*)stats);
+    FM_CHECK_ARG(C <= 1024 && groups <= 256, "fm_groupnorm_nhwc: C=%d groups=%d (C <= 1024)", C, groups);
+    const int chunks = (HW + GN_ROWS - 1) / GN_ROWS;
+    float* partial = (float*)stats + (size_t)B * groups * 2;                   // scratch layout: [B][G][2] sums, then [B][chunks][G][2] partials
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * chunks), dim3(256), (size_t)(256 / (C / 4)) * C * 2 * sizeof(float), (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const float*)add, ld_add, HW, C, groups, partial);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)partial, (float*)stats, B, groups, chunks);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for((long long)B * HW * (C / 4))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const float*)add, ld_add,
-                       (const float*)stats, (const float*)w, (const float*)b, (bf16_t*)y, ldy, B, HW, C, groups, silu);
+                       (const float*)stats, (const float*)w, (const float*)b, (bf16_t*)y, ldy, B, HW, C, groups, silu, eps);
     FM_CHECK_LAUNCH("fm_groupnorm_nhwc");
     return 0;
 }

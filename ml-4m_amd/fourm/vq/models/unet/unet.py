@@ -213,7 +213,7 @@ class _UNetEngine:
 
     def gn(self, tag, x, norm, B, HW, C, silu, add=None):
         y = self.buf(tag, B * HW, C)
-        st = self.buf("gn_stats", B * 32, 2, torch.float32)
+        st = self.buf("gn_stats", B * norm.num_groups * ((HW + 31) // 32 + 1), 2, torch.float32)
         L.check(L.groupnorm_nhwc(ops._p(x), x.stride(0), ops._p(add), add.stride(0) if add is not None else 0, ops._p(norm.weight.detach()), ops._p(norm.bias.detach()),
                                  ops._p(y), C, ops._p(st), B, HW, C, norm.num_groups, float(norm.eps), 1 if silu else 0, ops._stream()))
         return y
