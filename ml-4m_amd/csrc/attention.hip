@@ -292,10 +292,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
     char* T0 = smem;
     char* T1 = T0 + NP * ROWB;
     char* Ql = T0; char* dOl = T1; char* Kl = T0; char* Vl = T1;
-    float4* qs_l = (float4*)(T1 + NP * ROWB);           // per query: {row max (base 2), 1/row sum, delta, cs | mod}
-    int16_t* modk_l = (int16_t*)(qs_l + NqP);
+    // DIET (round 5; every non-chunked instantiation = sequences up to 512 tokens): the per-score arithmetic of attn_bwd128_kernel - the
+    // forward's statistics as one FMA addend, a blocked score selects a per-query exponent, the softmax scale leaves dS (dK / dQ are scaled
+    // at their stores), the decoder rule is one unsigned compare, fully blocked rows are handled outside the loops (Q row zeroed in LDS,
+    // dQ row zeroed at the store).  The chunked form (up to 32 k tokens, tiles re-staged per round) keeps the round-2 arithmetic.
+    constexpr bool DIET = !CHUNKED;
+    float4* qs_l = (float4*)(T1 + NP * ROWB);           // per query: {row max (base 2), 1/row sum, delta, cs | mod}; DIET: {nm, pb, delta, wq}
+    int32_t* modk_l = (int32_t*)(qs_l + NqP);           // per key: modality id; DIET + decoder mask: (mod_k << 11) + k
     uint8_t* kpad_l = (uint8_t*)(modk_l + NkP);
-    char* dSl = smem + (((size_t)((char*)(kpad_l + NkP) - smem) + 15) & ~(size_t)15);      // DS: sub-tile t = queries [64 t, 64 t + 64)
+    uint8_t* full_l = kpad_l + NkP;                      // DIET: the query's row is fully blocked
+    char* dSl = smem + (((size_t)((char*)(full_l + NqP) - smem) + 15) & ~(size_t)15);      // DS: sub-tile t = queries [64 t, 64 t + 64)
     static_assert(!DS || !CHUNKED, "dS^T is kept for single-chunk sequences only");
 
     const int lane = threadIdx.x & 63;
@@ -344,17 +350,51 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                     if (a.modq) modv = (uint16_t)a.modq[(size_t)b * a.Nq + q];
                 }
             }
+            if constexpr (DIET) {
+                // nm = -(m + log2 l) (the exponent's addend), pb = log2 of a blocked key's probability (-inf, or -log2 l in a fully blocked
+                // row), wq = (mod_q << 11) + cs_q - 1 with cs_q clamped to [0, 1023]; out-of-range queries: nm = pb = -inf (p = 0)
+                const float m = q < a.Nq ? a.stat_m[si] : 0.f, l = q < a.Nq ? a.stat_l[si] : 1.f;
+                const bool full = MASK != FM_MASK_NONE && q < a.Nq && m < -1e38f;
+                const float nm = q >= a.Nq ? -INFINITY : full ? 0.f : -(m + __log2f(l));
+                const float pb = full ? -__log2f(l) : -INFINITY;
+                const int wq = (int)((unsigned)(int16_t)modv << 11) + min(max(csv == 0x7fff ? 1023 : csv, 0), 1023) - 1;
+                qs_l[q] = make_float4(nm, pb, dl, __int_as_float(wq));
+                full_l[q] = full;
+            } else {
             // out-of-range queries get linv = 0: their probabilities vanish
             qs_l[q] = make_float4(q < a.Nq ? a.stat_m[si] : 0.f, q < a.Nq ? 1.0f / a.stat_l[si] : 0.f, dl,
                                   __int_as_float((csv << 16) | modv));
+            }
         }
     }
     for (int k = threadIdx.x; k < NkP; k += 256) {
         const int kc = k < a.Nk ? k : a.Nk - 1;
-        modk_l[k] = (MASK == FM_MASK_DECODER && a.modk) ? a.modk[(size_t)b * a.Nk + kc] : (int16_t)0;
+        const int mk_ = (MASK == FM_MASK_DECODER && a.modk) ? (int)a.modk[(size_t)b * a.Nk + kc] : 0;
+        modk_l[k] = DIET ? (int)((unsigned)mk_ << 11) + kc : mk_;
         kpad_l[k] = (MASK == FM_MASK_KEYPAD) ? a.kpad[(size_t)b * a.Nk + kc] : (uint8_t)0;
     }
     __syncthreads();
+    if constexpr (DIET && MASK != FM_MASK_NONE) {
+        // fully blocked rows: zero their Q row in LDS (no dK contribution; their scores all select pb); the dQ row is zeroed at the store
+        bool anyfull = false;
+        for (int q0 = 0; q0 < NqP; q0 += 64) anyfull = anyfull || __ballot(q0 + lane < NqP && full_l[q0 + lane]) != 0ull;
+        if (anyfull) {
+            for (int q = threadIdx.x >> 1; q < NqP; q += 128) {
+                if (full_l[q]) {
+                    const int half = threadIdx.x & 1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *(uint4*)(Ql + q * ROWB + half * 64 + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    auto sel = [](float if0, float if1, unsigned long long mask) {      // v_cndmask on the EXPONENT (never behind a v_exp: see attn_bwd128_kernel)
+        float r;
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(mask));
+        return r;
+    };
+    (void)sel;
 
     const int nQB = NqP / 32, nKB = NkP / 32;
     const float c2 = a.scale * LOG2E;
@@ -371,6 +411,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
         const int kc = k < a.Nk ? k : a.Nk - 1;
         const int mk = modk_l[kc];
         const bool kp = kpad_l[kc] != 0;
+        const unsigned long long kpmask = __ballot(kp), kvalid = __ballot(k < a.Nk);
+        (void)kpmask; (void)kvalid;
         bf16x8_t kf[4], vf[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {                 // rows past Nk repeat the last key (their p is forced to 0 below)
@@ -401,6 +443,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOl, lq + (lane & 31), kk, fhi), vf[kk], dp, 0, 0, 0);
             }
             float pv[16], dsv[16];
+            if constexpr (DIET) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
+                    const float4 qs = qs_l[q];                               // {nm, pb, delta, wq}: one 16-byte broadcast read
+                    float t = __builtin_fmaf(s[r], c2, qs.x);
+                    if constexpr (MASK == FM_MASK_KEYPAD) t = sel(t, qs.y, kpmask);
+                    if constexpr (MASK == FM_MASK_DECODER) t = sel(t, qs.y, __ballot((unsigned)(__float_as_int(qs.w) - mk) >= 1023u));
+                    if constexpr (MASK == FM_MASK_DENSE) t = a.dense[((size_t)b * a.Nq + (q < a.Nq ? q : a.Nq - 1)) * a.Nk + kc] != 0 ? qs.y : t;
+                    if constexpr (DS) t = sel(-INFINITY, t, kvalid);          // keys past Nk: p = 0 (their dS^T rows feed pass B)
+                    const float pr = __builtin_amdgcn_exp2f(t);
+                    pv[r] = pr;
+                    dsv[r] = pr * (dp[r] - qs.z);                            // (the softmax scale is applied at the dK / dQ stores)
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhi;
@@ -420,6 +477,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                 pv[r] = pr;
                 // masked_fill stops the gradient at blocked scores (they matter only in fully blocked rows)
                 dsv[r] = blk ? 0.f : pr * (dp[r] - qs.z) * a.scale;
+            }
             }
             if constexpr (DS) {     // this lane's key row, 4 x 4 consecutive queries: 8-byte stores into the swizzled sub-tile
                 char* sub = dSl + (qb >> 1) * (NkP * ROWB);
@@ -455,10 +513,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
                     for (int g = 0; g < 4; g += 2) {
                         const f32x16_t& t = which ? dVt[df] : dKt[df];
+                        const float ks = (DIET && !which) ? a.scale : 1.0f;      // DIET: dS left pass A without the softmax scale
                         uint2 pk[2];
 #pragma unroll
                         for (int u = 0; u < 2; ++u)
-                            pk[u] = make_uint2(pack2bf(t[4 * (g + u)], t[4 * (g + u) + 1]), pack2bf(t[4 * (g + u) + 2], t[4 * (g + u) + 3]));
+                            pk[u] = make_uint2(pack2bf(t[4 * (g + u)] * ks, t[4 * (g + u) + 1] * ks), pack2bf(t[4 * (g + u) + 2] * ks, t[4 * (g + u) + 3] * ks));
                         store_bf16_groups(which ? dvrow : dkrow, df * 32 + 8 * g, pk[0], pk[1], fhi, lim, which ? wide_v : wide_k);
                     }
         }
@@ -480,8 +539,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
         const int q = qb * 32 + (lane & 31);
         const int qc = q < a.Nq ? q : a.Nq - 1;
         const float4 qs = qs_l[q];
-        const float mq_ = qs.x, li = qs.y, dl = qs.z;
+        const float mq_ = qs.x, li = qs.y, dl = qs.z;                          // DIET: nm, pb, delta
         const int csq = __float_as_int(qs.w) >> 16, mq = __float_as_int(qs.w) & 0xffff;
+        const int wq = __float_as_int(qs.w);                                   // DIET: the packed decoder constant
         f32x16_t dQt[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -528,6 +588,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
             float dsv[16];
             unsigned long long bits = 0;
             if constexpr (MASK == FM_MASK_KEYPAD) bits = (kb * 32 < NkP ? __ballot(kpad_l[min(kb * 32 + (lane & 31), NkP - 1)] != 0) : 0ull) >> (4 * fhi);
+            if constexpr (DIET) {
+                const bool ragged = (kb + 1) * 32 > a.Nk;                    // (only the last key block can hold keys past Nk)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = (r & 3) + 8 * (r >> 2);
+                    const int k = kb * 32 + c + 4 * fhi;
+                    const int kc = k < a.Nk ? k : a.Nk - 1;
+                    float t = __builtin_fmaf(s[r], c2, mq_);
+                    if constexpr (MASK == FM_MASK_KEYPAD) t = sel(t, li, __ballot((bits >> c) & 1ull));
+                    if constexpr (MASK == FM_MASK_DECODER) t = sel(t, li, __ballot((unsigned)(wq - modk_l[kc]) >= 1023u));
+                    if constexpr (MASK == FM_MASK_DENSE) t = a.dense[((size_t)b * a.Nq + qc) * a.Nk + kc] != 0 ? li : t;
+                    if (ragged) t = k < a.Nk ? t : -INFINITY;
+                    dsv[r] = __builtin_amdgcn_exp2f(t) * (dp[r] - dl);
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = (r & 3) + 8 * (r >> 2);
@@ -546,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                 pr = k < a.Nk ? pr : 0.f;
                 dsv[r] = blk ? 0.f : pr * (dp[r] - dl) * a.scale;
             }
+            }
 #pragma unroll
             for (int sblk = 0; sblk < 2; ++sblk) {
                 const bf16x8_t db = pack8(&dsv[8 * sblk]);
@@ -559,10 +635,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
         }
         }
         }
-        (void)mq_; (void)li; (void)dl; (void)csq; (void)mq;
+        (void)mq_; (void)li; (void)dl; (void)csq; (void)mq; (void)wq;
         if (live) {
             bf16_t* dqrow = a.dQ + ((size_t)b * a.Nq + qc) * a.lddq + h * HD;
             const int lim = q < a.Nq ? HD : 0;
+            float qsc = 1.0f;                                                  // DIET: the softmax scale; 0 for a fully blocked row
+            if constexpr (DIET) qsc = (MASK != FM_MASK_NONE && full_l[q]) ? 0.f : a.scale;
 #pragma unroll
             for (int df = 0; df < 2; ++df)
 #pragma unroll
@@ -570,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                     uint2 pq[2];
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
-                        pq[u] = make_uint2(pack2bf(dQt[df][4 * (g + u)], dQt[df][4 * (g + u) + 1]), pack2bf(dQt[df][4 * (g + u) + 2], dQt[df][4 * (g + u) + 3]));
+                        pq[u] = make_uint2(pack2bf(dQt[df][4 * (g + u)] * qsc, dQt[df][4 * (g + u) + 1] * qsc), pack2bf(dQt[df][4 * (g + u) + 2] * qsc, dQt[df][4 * (g + u) + 3] * qsc));
                     store_bf16_groups(dqrow, df * 32 + 8 * g, pq[0], pq[1], fhi, lim, wide_q);
                 }
         }
@@ -1159,7 +1237,7 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     static const bool ds_on = [] { const char* e = getenv("FOURM_ATTN_BWD_DS"); return !e || atoi(e) != 0; }();
     const size_t ds_bytes = (size_t)((NqP + 63) / 64) * NkP * ROWB;
     const bool ds = ds_on && a.chunk == NPmax && ds_bytes <= 32 * 1024;
-    const size_t lds = (size_t)2 * a.chunk * ROWB + (size_t)NqP * 16 + (size_t)NkP * (2 + 1) + 64 + (ds ? ds_bytes + 16 : 0);
+    const size_t lds = (size_t)2 * a.chunk * ROWB + (size_t)NqP * (16 + 1) + (size_t)NkP * (4 + 1) + 64 + (ds ? ds_bytes + 16 : 0);
     FM_CHECK_ARG(lds <= 160 * 1024, "fm_attn_bwd: Nq=%d Nk=%d need %zu bytes of LDS for the per-row statistics", a.Nq, a.Nk, lds);
     FM_CHECK_ARG(a.Nq < 0x7fff && a.Nk < 0x7fff, "fm_attn_bwd: sequence too long for the packed 15-bit mask bounds");
     dim3 grid(a.H, a.B);
