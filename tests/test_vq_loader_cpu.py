@@ -58,15 +58,33 @@ def test_feature_map_and_sam_domains(tmp_path):
     assert a2.image_size == 16 and a2.input_size == 16 and t2.image_size == 16
 
 
-def test_missing_weights_and_diffusion_decoders_are_refused(tmp_path):
-    from fourm.vq import VQVAE, get_image_tokenizer
+def test_missing_weights_are_refused_and_diffusion_decoders_dispatch(tmp_path, monkeypatch):
+    """Holes in a checkpoint raise; a checkpoint with ``beta_schedule`` in its args is a DiVAE (upstream fourm/vq/__init__.py:62-66) and builds
+    ``fourm.vq.DiVAE`` with every diffusion argument forwarded; controlnet keys mean VQControlNet, which only loads encoder_only."""
+    from fourm.vq import VQVAE, DiVAE, get_image_tokenizer
+    import fourm.vq.models.unet as unet_pkg
+    from fourm.vq.models.unet import PatchedUNetCondCat
     m = VQVAE(image_size=32, n_channels=3, enc_type="vit_s_enc", dec_type="vit_s_dec", patch_size=8, codebook_size=64, latent_dim=8, post_mlp=True)
     sd = {k: v for k, v in m.state_dict().items() if not k.startswith("quant_proj.")}
     torch.save({"model": sd, "args": argparse.Namespace(domain="rgb", input_size=32, **BASE)}, tmp_path / "holes.pth")
     with pytest.raises(RuntimeError, match="lacks"):
         get_image_tokenizer("holes", str(tmp_path), device="cpu", verbose=False)
-    _save(tmp_path, "divae", m, domain="rgb", input_size=32, beta_schedule="linear", **BASE)
-    with pytest.raises(NotImplementedError, match="DiVAE"):
-        get_image_tokenizer("divae", str(tmp_path), device="cpu", verbose=False)
-    enc, _ = get_image_tokenizer("divae", str(tmp_path), encoder_only=True, device="cpu", verbose=False)       # the encoder half still loads
-    assert enc is not None
+    # a small UNet under the name the checkpoint asks for (the real unet_patched has 196 M parameters: too heavy for a loader test)
+    monkeypatch.setattr(unet_pkg, "unet_patched", lambda **kw: PatchedUNetCondCat(patch_size=4, model_channels=32, num_res_blocks=1, attention_resolutions=[2],
+                                                                                   channel_mult=(1, 2), **kw))
+    dargs = dict(BASE, decoder_type="unet_patched")
+    d = DiVAE(image_size=32, n_channels=3, enc_type="vit_s_enc", dec_type="unet_patched", patch_size=8, codebook_size=64, latent_dim=8, post_mlp=True,
+              scheduler="ddim", prediction_type="sample", beta_schedule="linear")
+    for p in d.decoder.parameters():
+        torch.nn.init.normal_(p, std=0.02)
+    _save(tmp_path, "divae", d, domain="rgb", input_size=32, beta_schedule="linear", prediction_type="sample", scheduler="ddim", num_train_timesteps=1000, **dargs)
+    t, a = get_image_tokenizer("divae", str(tmp_path), device="cpu", verbose=False)
+    assert isinstance(t, DiVAE) and a.model_type == "DiVAE" and t.prediction_type == "sample" and type(t.noise_scheduler).__name__ == "DDIMScheduler"
+    assert all(torch.equal(v, d.state_dict()[k]) for k, v in t.state_dict().items() if k.startswith("decoder."))
+    enc, _ = get_image_tokenizer("divae", str(tmp_path), encoder_only=True, device="cpu", verbose=False)       # the encoder half alone
+    assert enc is not None and not any(k.startswith("decoder.") for k in enc.state_dict())
+    sdc = dict(d.state_dict())
+    sdc["decoder.controlnet.x"] = torch.zeros(1)
+    torch.save({"model": sdc, "args": argparse.Namespace(domain="rgb", input_size=32, **dargs)}, tmp_path / "cn.pth")
+    with pytest.raises(NotImplementedError, match="VQControlNet"):
+        get_image_tokenizer("cn", str(tmp_path), device="cpu", verbose=False)
