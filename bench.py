@@ -603,7 +603,7 @@ def main():
     def step(i):
         loss, mod_loss = fwd(batches[i % 2], a.n_in, a.n_out, loss_type="mod")
         loss.backward()
-        norm = opt.fused_grad_norm()
+        norm = opt.fused_grad_norm(lazy=True)        # as the trainer without clipping (NativeScaler): the norm rides on the AdamW pass
         opt.step()
         opt.zero_grad(set_to_none=True)
         return loss, norm

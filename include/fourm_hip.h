@@ -322,9 +322,11 @@ int fm_scale_rows_bf16(void* x, int ld, const void* scale, int rows_per_sample, 
 /* torch.optim.AdamW update on a contiguous fp32 range (fourm/utils/optim_factory.py:239-240);
  * grad_mult: optional device scalar multiplied into the gradient (clipping).
  * hyper: optional DEVICE float[4] = {lr, weight_decay, 1 - beta1^step, sqrt(1 - beta2^step)} that overrides the scalar arguments:
- * a launch captured in a hipGraph keeps following the schedule (the host refreshes those 16 bytes before each replay). */
+ * a launch captured in a hipGraph keeps following the schedule (the host refreshes those 16 bytes before each replay).
+ * sumsq: optional device scalar that receives += sum g^2 of the RAW gradients of this range (round 5: with no clipping the gradient norm of
+ * NativeScaler / get_grad_norm_ rides on the update's own pass over the gradients instead of a separate 4 B/param read). */
 int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
-             float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* stream);
+             float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* sumsq, void* stream);
 /* AdamW on weight MATRICES with their plain bf16 shadow (the W operand of y = x W^T) rewritten in the same streaming pass: the
  * update already reads and writes every master weight, the bf16 copy costs 2 B/param on top instead of a separate 6 B/param pass.
  * One launch walks a device table of jobs in tiles of FM_ADAMW_CHUNK (8192) consecutive elements; job i owns tiles
@@ -337,7 +339,7 @@ typedef struct fm_adamw_job {
     int32_t rows, cols, ld_plain, ld_t, tile_start, pad_;
 } fm_adamw_job;
 int fm_adamw_shadow(const fm_adamw_job* jobs, int n_jobs, int total_tiles, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* stream);
+                    float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* sumsq, void* stream);
 int fm_sumsq(const void* x, int64_t n, void* out, void* stream);                         /* out[0] += sum x^2 */
 int fm_clip_coef(const void* sumsq, float max_norm, void* norm_out, void* coef_out, void* stream);
 

@@ -247,11 +247,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // grad_mult (device scalar, optional) = gradient clipping coefficient.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     size_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                    const float* __restrict__ grad_mult, const float* __restrict__ hyper) {
+                                                    const float* __restrict__ grad_mult, const float* __restrict__ hyper, float* __restrict__ sumsq) {
     if (hyper) { lr = hyper[0]; wd = hyper[1]; bc1 = hyper[2]; bc2_sqrt = hyper[3]; }      // captured launches: values live on the device
     const float gm = grad_mult ? grad_mult[0] : 1.0f;
     const float step = lr / bc1;
+    float ss = 0.f;                                   // sum of the RAW gradients' squares (sumsq != NULL: the norm rides on this pass)
     auto update = [&](float& pe, float& me, float& ve, float ge) {
+        ss += ge * ge;
         ge *= gm;
         pe *= 1.0f - lr * wd;
         me = beta1 * me + (1.0f - beta1) * ge;
@@ -280,6 +282,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             if (i2 < n) slow(i2);
         }
     }
+    if (sumsq) {
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(sumsq, ss);
+    }
 }
 
 // AdamW on weight matrices + their plain bf16 shadow in one STREAMING pass: see fm_adamw_shadow in the header.  A "tile" is a run of
@@ -290,11 +296,13 @@ constexpr int ADAMW_CHUNK = 8192;           // elements per tile: 256 threads x 
 
 __global__ __launch_bounds__(256) void adamw_shadow_kernel(const fm_adamw_job* __restrict__ jobs, int n, int total_tiles, float lr, float beta1,
                                                            float beta2, float eps, float wd, float bc1, float bc2_sqrt,
-                                                           const float* __restrict__ grad_mult, const float* __restrict__ hyper) {
+                                                           const float* __restrict__ grad_mult, const float* __restrict__ hyper, float* __restrict__ sumsq) {
     if (hyper) { lr = hyper[0]; wd = hyper[1]; bc1 = hyper[2]; bc2_sqrt = hyper[3]; }
     const float gm = grad_mult ? grad_mult[0] : 1.0f;
     const float step = lr / bc1;
+    float ss = 0.f;
     auto update = [&](float& pe, float& me, float& ve, float ge) {
+        ss += ge * ge;
         ge *= gm;
         pe *= 1.0f - lr * wd;
         me = beta1 * me + (1.0f - beta1) * ge;
@@ -345,6 +353,10 @@ __global__ __launch_bounds__(256) void adamw_shadow_kernel(const fm_adamw_job* _
                 if (dst) dst[(o / d.cols) * d.ld_plain + o % d.cols] = f2bf(P[o]);
             }
         }
+    }
+    if (sumsq) {
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(sumsq, ss);
     }
 }
 
@@ -511,24 +523,24 @@ extern "C" int fm_colsum(const void* dy, int ldy, void* db, int R, int N, void* 
 }
 
 extern "C" int fm_adamw(void* p, const void* g, void* m, void* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* stream) {
+                        float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* sumsq, void* stream) {
     FM_CHECK_ARG(p && g && m && v && n > 0 && step > 0, "fm_adamw: bad argument");
     FM_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "fm_adamw: buffers must be 16-byte aligned");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for((size_t)(n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (float*)p, (const float*)g, (float*)m,
                        (float*)v, (size_t)n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult,
-                       (const float*)hyper);
+                       (const float*)hyper, (float*)sumsq);
     FM_CHECK_LAUNCH("fm_adamw");
     return 0;
 }
 
 extern "C" int fm_adamw_shadow(const fm_adamw_job* jobs, int n_jobs, int total_tiles, float lr, float beta1, float beta2, float eps,
-                               float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* stream) {
+                               float weight_decay, int64_t step, const void* grad_mult, const void* hyper, void* sumsq, void* stream) {
     FM_CHECK_ARG(jobs && n_jobs > 0 && total_tiles > 0 && step > 0, "fm_adamw_shadow: bad argument");
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const int blocks = total_tiles < 8192 ? total_tiles : 8192;
     hipLaunchKernelGGL(adamw_shadow_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs, total_tiles, lr, beta1, beta2, eps,
-                       weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult, (const float*)hyper);
+                       weight_decay, (float)bc1, (float)sqrt(bc2), (const float*)grad_mult, (const float*)hyper, (float*)sumsq);
     FM_CHECK_LAUNCH("fm_adamw_shadow");
     return 0;
 }

@@ -173,8 +173,8 @@ add_bf16_f32 = _sig("fm_add_bf16_f32", vp, vp, vp, i64, vp)
 lib.fm_set_reserved_cus.argtypes = [C.c_int]
 lib.fm_get_reserved_cus.restype = C.c_int
 lib.fm_get_reserved_cus.argtypes = []
-adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp, vp)
-adamw_shadow = _sig("fm_adamw_shadow", vp, i32, i32, f32, f32, f32, f32, f32, i64, vp, vp, vp)
+adamw = _sig("fm_adamw", vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp, vp, vp)
+adamw_shadow = _sig("fm_adamw_shadow", vp, i32, i32, f32, f32, f32, f32, f32, i64, vp, vp, vp, vp)
 sumsq = _sig("fm_sumsq", vp, i64, vp, vp)
 clip_coef = _sig("fm_clip_coef", vp, f32, vp, vp, vp)
 sample_tokens = _sig("fm_sample_tokens", vp, i32, i32, i32, i32, f32, i32, f32, vp, vp, vp, vp)

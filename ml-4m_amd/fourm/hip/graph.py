@@ -68,7 +68,7 @@ class GraphedTrainStep:
     def _launches(self):
         loss, mod_loss = (self.dp or self.model)(self.static, self.n_enc, self.n_dec, loss_type=self.loss_type)
         loss.backward()
-        norm = self.opt.fused_grad_norm(clip=self.clip)
+        norm = self.opt.fused_grad_norm(clip=self.clip, lazy=True)
         self.opt.step()
         return loss.detach(), {k: v.detach() for k, v in mod_loss.items()}, norm
 

@@ -454,8 +454,8 @@ def add_bf16_to_f32(x, delta, out, R=None):
 
 
 @_timed("adamw")
-def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None):
-    L.check(L.adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _p(hyper), _stream()))
+def adamw(p, g, m, v, n, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None, sumsq=None):
+    L.check(L.adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _p(hyper), _p(sumsq), _stream()))
 
 
 ADAMW_CHUNK = 8192   # FM_ADAMW_CHUNK
@@ -486,8 +486,8 @@ def adamw_jobs_table(jobs, device):
 
 
 @_timed("adamw")
-def adamw_shadow(table, n_jobs, tiles, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None):
-    L.check(L.adamw_shadow(_p(table), n_jobs, tiles, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _p(hyper), _stream()))
+def adamw_shadow(table, n_jobs, tiles, lr, beta1, beta2, eps, wd, step, grad_mult=None, hyper=None, sumsq=None):
+    L.check(L.adamw_shadow(_p(table), n_jobs, tiles, lr, beta1, beta2, eps, wd, step, _p(grad_mult), _p(hyper), _p(sumsq), _stream()))
 
 
 @_timed("grad_norm")

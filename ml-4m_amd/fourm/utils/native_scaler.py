@@ -25,7 +25,7 @@ class NativeScalerWithGradNormCount:
                 if norm >= skip_grad:                                    # host decision, as upstream
                     return norm
             elif compute_grad_norm:
-                norm = optimizer.fused_grad_norm()
+                norm = optimizer.fused_grad_norm(lazy=True)              # filled by the step below (the norm rides on the AdamW pass)
             optimizer.step()
             return norm
         return self._generic_step(optimizer, parameters, clip_grad, skip_grad, compute_grad_norm)

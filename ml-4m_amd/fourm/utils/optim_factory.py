@@ -182,7 +182,7 @@ class FusedAdamW(optim.AdamW):
                     cached = self._shadow_tables[gi] = (sig, table, len(jobs), tiles)
                 _, table, n, tiles = cached
                 ops.adamw_shadow(table, n, tiles, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], max(step, 1), self._clip_coef,
-                                 hyper=self._hyper(gi))
+                                 hyper=self._hyper(gi), sumsq=getattr(self, "_ss", None))
                 for p, pl, tr, keys in its:
                     touched += keys
                     for dst in (pl, tr):
@@ -243,10 +243,21 @@ class FusedAdamW(optim.AdamW):
             o += p.numel()
 
     @torch.no_grad()
-    def fused_grad_norm(self, clip=None):
+    def fused_grad_norm(self, clip=None, lazy=False):
         """L2 norm of every gradient, computed on the device; with ``clip`` the coefficient
-        min(1, clip / (norm + 1e-6)) is folded into the next step().  Returns a device scalar."""
+        min(1, clip / (norm + 1e-6)) is folded into the next step().  Returns a device scalar.
+        ``lazy`` (no clipping only): the norm is not needed to take the step, so the sum of squares rides on the AdamW kernels' own pass over the
+        gradients (fm_adamw*'s ``sumsq``) instead of a separate 4 B/param read: the returned scalar is FILLED BY THE NEXT step() - read it
+        after that call (NativeScaler returns it to the trainer after optimizer.step(), like upstream's get_grad_norm_ value)."""
         from fourm.hip import ops
+        self._lazy_norm = None
+        if lazy and clip is None:
+            dev = next((p.grad.device for g in self.param_groups for p in g["params"] if p.grad is not None), None)
+            if dev is None:
+                return torch.tensor(0.)
+            ss, norm = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+            self._lazy_norm, self._clip_coef = (ss, norm), None
+            return norm[0]
         grads = []
         for g in self.param_groups:
             for p in g["params"]:
@@ -281,6 +292,8 @@ class FusedAdamW(optim.AdamW):
     def step(self, closure=None):
         from fourm.hip import engine, ops
         loss = closure() if closure is not None else None
+        lazy = getattr(self, "_lazy_norm", None)
+        self._ss = lazy[0] if lazy is not None else None          # device scalar the AdamW launches of this step add sum g^2 to
         done, touched, written = self._step_shadowed(self._shadowed())
         for gi, run in self._build_runs(skip=done):
             g = self.param_groups[gi]
@@ -295,10 +308,13 @@ class FusedAdamW(optim.AdamW):
                 for p in run:       # state loaded from a checkpoint (separate tensors): per-tensor launches
                     st = self.state[p]
                     ops.adamw(p, p.grad, st["exp_avg"], st["exp_avg_sq"], p.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                              g["weight_decay"], max(int(st["step"]), 1), self._clip_coef, hyper=self._hyper(gi))
+                              g["weight_decay"], max(int(st["step"]), 1), self._clip_coef, hyper=self._hyper(gi), sumsq=self._ss)
                 continue
             ops.adamw(run[0], run[0].grad, st0["exp_avg"], st0["exp_avg_sq"], n, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                      g["weight_decay"], step, self._clip_coef, hyper=self._hyper(gi))
+                      g["weight_decay"], step, self._clip_coef, hyper=self._hyper(gi), sumsq=self._ss)
+        if lazy is not None:
+            ops.clip_coef(lazy[0], 0.0, lazy[1], None)              # norm = sqrt(sum g^2): the scalar fused_grad_norm(lazy=True) returned
+            self._lazy_norm = self._ss = None
         self._clip_coef = None
         engine.bump_weight_epoch()
         for eng in {id(e): e for e, _ in touched}.values():          # the copies written above are current again

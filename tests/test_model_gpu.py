@@ -296,6 +296,18 @@ def test_fused_adamw_step_matches_torch():
         assert float((p - q).abs().max()) < 2e-6, n
     sd = opt.state_dict()
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 2.0
+    # the lazy norm (no clipping: sum g^2 rides on the AdamW launches, filled by step()) equals the eager one and leaves the same update
+    random.seed(5); loss, _ = model(md, case["N"], case["M"]); loss.backward()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        q.grad = p.grad.clone()
+    eager = float(opt.fused_grad_norm())
+    lazy = opt.fused_grad_norm(lazy=True)
+    assert float(lazy) == 0.0                                   # not computed yet ...
+    opt.step(); ropt.step()
+    want = float(torch.nn.utils.get_total_norm([q.grad for q in ref.parameters() if q.grad is not None])) if hasattr(torch.nn.utils, "get_total_norm") else eager
+    assert abs(float(lazy) - eager) < 1e-5 * eager and abs(eager - want) < 1e-5 * want, (float(lazy), eager, want)      # ... filled by the step
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        assert float((p - q).abs().max()) < 2e-6, n
 
 
 def test_hoisted_context_norm_with_frozen_parts():
@@ -345,10 +357,10 @@ def test_trainer_step_trajectory_b_mod7():
     ropt = torch.optim.AdamW(groups(list(ref.items())), lr=1e-3, betas=(0.9, 0.95))
     fused_norm = opt.fused_grad_norm
 
-    def norm_and_hand_over(clip=None):              # called by the scaler between backward and step: the same gradients go to the torch side
+    def norm_and_hand_over(clip=None, lazy=False):  # called by the scaler between backward and step: the same gradients go to the torch side
         for n, p in model.named_parameters():
             ref[n].grad = None if p.grad is None else p.grad.clone()
-        return fused_norm(clip=clip)
+        return fused_norm(clip=clip, lazy=lazy)
     opt.fused_grad_norm = norm_and_hand_over
     scaler = NativeScalerWithGradNormCount(enabled=False)
     clip = 0.5                                   # below the gradient norm of the seeded model: the clip is active on every step
