@@ -233,8 +233,9 @@ def cap_collective_channels(n: Optional[int] = None):
     if n > 0 and os.environ.get("FOURM_DP_EXCHANGE", "overlap").lower() == "overlap":
         os.environ["NCCL_MAX_NCHANNELS"] = str(n)
         if int(os.environ.get("RANK", "0")) == 0:
+            import sys
             print(f"[fourm.parallel] NCCL_MAX_NCHANNELS={n} (collectives confined to the {n} CUs the GEMM grids leave free; "
-                  f"FOURM_DP_CAP_CHANNELS=0 or FOURM_DP_EXCHANGE=tail to lift it)", flush=True)
+                  f"FOURM_DP_CAP_CHANNELS=0 or FOURM_DP_EXCHANGE=tail to lift it)", file=sys.stderr, flush=True)      # stderr: bench.py's stdout is ONE JSON line
         return n
     return None
 
