@@ -267,6 +267,172 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, 128 x 128 tokens exactly (the bench shape; same dispatch rule as attn_bwd128_kernel) - round 5.
+// The general kernel above is VALU-bound at this shape (profiles/r05_final_pmc_attn.txt: 1 400 VALU instructions per wave = 26 % of a
+// wave's cycles with THREE waves per SIMD, MFMA pipe 4.5 % busy): 12 VALU per score for the online softmax over two 64-key tiles (scale,
+// two selects, max, subtract, exp, sum, the rescale of O through AGPR moves).  With all 128 keys of a (b, h) in LDS at once there is no
+// running maximum and no rescale: 4 - 7 VALU per score
+//   * the mask is applied to the raw MFMA result (blocked -> -inf: one v_cndmask; key padding: the lane mask comes from two s_bfe of the
+//     128-bit padding bitmap through inverse_ballot - no VALU compare; decoder rule: the packed subtraction of attn_bwd128_kernel),
+//   * one v_max3 per two scores for the TRUE row maximum m, p = exp2(fma(s, c2, -m c2)) (the scale is inside the FMA), one add, one
+//     v_cvt_pk_bf16_f32 per two scores;
+//   * fully blocked rows (m = -inf) leave the loop with p = 0 and are set to p = 1, l = 128, m = NEG_FILL behind a wave-uniform branch
+//     (upstream: every score replaced by -finfo.max -> uniform attention);
+//   * ONE memory round trip (K, V by LDS-DMA, Q into registers, the mask metadata) and ONE barrier per workgroup.
+// stat_m / stat_l keep the general kernel's convention (row maximum of s * scale * log2 e, row sum of exp2).
+// ------------------------------------------------------------------------------------------------
+template <int MASK>
+__global__ __launch_bounds__(256, 3) void attn_fwd128_kernel(AttnArgs a) {
+    constexpr int N = 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Kt = smem;
+    char* Vt = smem + N * ROWB;
+    int* uk_l = (int*)(smem + 2 * N * ROWB);             // decoder: (mod_k << 9) + k per key; key padding: the 128-bit bitmap of padded keys
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fhi = lane >> 5;
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int q = wave * 32 + (lane & 31);
+    const bf16_t* Qb = a.Q + (size_t)b * N * a.ldq + h * HD;
+    const bf16_t* Kb = a.K + (size_t)b * a.kvr * a.ldk + h * HD;
+    const bf16_t* Vb = a.V + (size_t)b * a.kvr * a.ldv + h * HD;
+
+    stage_rows<4>(Kb, a.ldk, 0, N, N, Kt, wave, lane);
+    stage_rows<4>(Vb, a.ldv, 0, N, N, Vt, wave, lane);
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(Qb + (size_t)q * a.ldq + (kk * 2 + fhi) * 8);
+    int wq = 0;                                          // decoder: (mod_q << 9) + cs_q - 1: blocked <=> (unsigned)(wq - uk) >= 255
+    if constexpr (MASK == FM_MASK_DECODER) {
+        int csv = 255, lov = 0;
+        if (a.causal) csv = q + 1;
+        else if (a.cs) csv = min(max(a.cs[(size_t)b * N + q], 0), 255);
+        if (a.modq) lov = (int)a.modq[(size_t)b * N + q] << 9;
+        wq = lov + csv - 1;
+        if (threadIdx.x < N) uk_l[threadIdx.x] = (((a.modq && a.modk) ? (int)a.modk[(size_t)b * N + threadIdx.x] : 0) << 9) + (int)threadIdx.x;
+    }
+    if constexpr (MASK == FM_MASK_KEYPAD) {
+        if (wave < 2) {                                  // waves 0 / 1: keys 0..63 / 64..127
+            const unsigned long long bits = __ballot(a.kpad ? a.kpad[(size_t)b * N + threadIdx.x] != 0 : false);
+            if (lane == 0) *(unsigned long long*)(uk_l + 2 * wave) = bits;
+        }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T: key block kb, accumulator row r <-> key 32 kb + (r & 3) + 8 (r >> 2) + 4 fhi; the lane's query is the column ----
+    f32x16_t st[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb * 32 + (lane & 31), kk, fhi), qf[kk], st[kb], 0, 0, 0);
+    }
+    // ---- mask (blocked -> -inf) and the row maximum of the raw scores ------------------------------------
+    float mraw = -INFINITY;
+    unsigned bm[4] = {0u, 0u, 0u, 0u};
+    if constexpr (MASK == FM_MASK_KEYPAD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bm[i] = (unsigned)__builtin_amdgcn_readfirstlane(uk_l[i]);
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+            i32x4_t uk4 = {0, 0, 0, 0};
+            if constexpr (MASK == FM_MASK_DECODER) uk4 = *(const i32x4_t*)(uk_l + kb * 32 + 8 * g + 4 * fhi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j, cc = j + 8 * g;                  // key = 32 kb + cc + 4 fhi
+                float s = st[kb][r];
+                if constexpr (MASK == FM_MASK_KEYPAD) {
+                    const unsigned long long mk = (unsigned long long)(0u - ((bm[kb] >> cc) & 1u)) | ((unsigned long long)(0u - ((bm[kb] >> (cc + 4)) & 1u)) << 32);
+                    s = __builtin_amdgcn_inverse_ballot_w64(mk) ? -INFINITY : s;
+                }
+                if constexpr (MASK == FM_MASK_DECODER) s = (unsigned)(wq - uk4[j]) >= 255u ? -INFINITY : s;
+                st[kb][r] = s;
+                mraw = fmaxf(mraw, s);
+            }
+        }
+    mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+    const float c2 = a.scale * LOG2E;                    // > 0 (checked by the dispatch): max(s c2) = c2 max(s)
+    bool full = false;
+    if constexpr (MASK != FM_MASK_NONE) full = mraw == -INFINITY;
+    float m_run = full ? 0.f : mraw * c2;
+    const float nm = -m_run;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c2, nm));
+            st[kb][r] = p;
+            psum += p;
+        }
+    if constexpr (MASK != FM_MASK_NONE) {
+        if (__ballot(full) != 0ull) {                    // rare: empty samples, decoder rows in front of the first visible token
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[kb][r] = full ? 1.0f : st[kb][r];
+            psum = full ? 64.f : psum;
+            m_run = full ? NEG_FILL : m_run;
+        }
+    }
+    // ---- O^T = V^T P^T ----------------------------------------------------------------------------------
+    f32x16_t o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            union { bf16x8_t v; uint32_t u[4]; } pb;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pb.u[i] = pack2bf(st[kb][8 * s + 2 * i], st[kb][8 * s + 2 * i + 1]);
+            const int rA = kb * 32 + s * 16 + 4 * fhi;
+#pragma unroll
+            for (int df = 0; df < 2; ++df) {
+                const bf16x8_t vf = lds_col_frag<true>([&](int r, int c) { return tile_addr(Vt, r, c); }, rA, rA + 8, df * 32);
+                o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb.v, o[df], 0, 0, 0);
+            }
+        }
+    float l_tot = psum + __shfl_xor(psum, 32, 64);
+    float m_fin = m_run, oscale = 1.0f;
+    if (a.zero_attn) {      // softmax1 (fm_utils.py:28-30), as in attn_fwd_kernel
+        m_fin = fmaxf(m_run, 0.f);
+        oscale = __builtin_amdgcn_exp2f(m_run - m_fin);
+        l_tot = l_tot * oscale + __builtin_amdgcn_exp2f(-m_fin);
+    }
+    const float inv = oscale / l_tot;
+    {
+        bf16_t* orow = a.O + ((size_t)b * N + q) * a.ldo + h * HD;
+        const bool wide_o = (a.ldo & 7) == 0 && (((uintptr_t)a.O) & 15) == 0;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                uint2 po[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    po[u] = make_uint2(pack2bf(o[df][4 * (g + u)] * inv, o[df][4 * (g + u) + 1] * inv),
+                                       pack2bf(o[df][4 * (g + u) + 2] * inv, o[df][4 * (g + u) + 3] * inv));
+                store_bf16_groups(orow, df * 32 + 8 * g, po[0], po[1], fhi, HD, wide_o);
+            }
+    }
+    if (fhi == 0 && a.stat_m) {
+        const size_t si = ((size_t)b * a.H + h) * N + q;
+        a.stat_m[si] = m_fin;
+        a.stat_l[si] = l_tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: one workgroup per (b, h).
 //   pass A  (a wave owns 32 keys, loops over queries)   -> dK, dV      LDS: (Q, dO)
 //   pass B  (a wave owns 32 queries, loops over keys)   -> dQ          LDS: (K, V)
@@ -1207,6 +1373,20 @@ extern "C" int fm_attn_fwd(const fm_attn_args* p, void* stream) {
     FM_CHECK_ARG(lds <= 150 * 1024, "fm_attn_fwd: Nk=%d too long for the key metadata buffer", a.Nk);
     dim3 grid((a.Nq + 127) / 128, a.H, a.B);
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
+    // 128 x 128 tokens exactly: the round-5 kernel (all keys in LDS at once, 4 - 7 VALU per score); FOURM_ATTN_FWD_V2=0 keeps the general one
+    static const bool v2_on = [] { const char* e = getenv("FOURM_ATTN_FWD_V2"); return !e || atoi(e) != 0; }();
+    if (v2_on && tr && a.Nq == 128 && a.Nk == 128 && a.mask_kind != FM_MASK_DENSE && a.scale > 0.f) {
+        const size_t lds128 = (size_t)2 * 128 * ROWB + 128 * 4;
+        const dim3 grid128(a.H, a.B);
+        switch (a.mask_kind) {
+            case FM_MASK_NONE: hipLaunchKernelGGL((attn_fwd128_kernel<FM_MASK_NONE>), grid128, dim3(256), lds128, (hipStream_t)stream, a); break;
+            case FM_MASK_KEYPAD: hipLaunchKernelGGL((attn_fwd128_kernel<FM_MASK_KEYPAD>), grid128, dim3(256), lds128, (hipStream_t)stream, a); break;
+            case FM_MASK_DECODER: hipLaunchKernelGGL((attn_fwd128_kernel<FM_MASK_DECODER>), grid128, dim3(256), lds128, (hipStream_t)stream, a); break;
+            default: fm_set_error("fm_attn_fwd: unknown mask kind %d", a.mask_kind); return -1;
+        }
+        FM_CHECK_LAUNCH("fm_attn_fwd");
+        return 0;
+    }
 #define FWD(TR, MK) hipLaunchKernelGGL((attn_fwd_kernel<TR, MK>), grid, dim3(256), lds, (hipStream_t)stream, a)
 #define FWD_MASK(TR)                                                        \
     switch (a.mask_kind) {                                                  \

@@ -579,6 +579,33 @@ def test_attention(kind, Nq, Nk, tr):
         assert rel_err(got, want) < 2e-2, (kind, tr, name, rel_err(got, want))
 
 
+@pytest.mark.parametrize("kind", ["none", "keypad", "decoder"])
+@pytest.mark.parametrize("zero_attn", [False, True])
+def test_attention_fwd128_matches_the_general_kernel(kind, zero_attn):
+    """The 128 x 128 forward (all keys in LDS at once, mask on the raw scores, one exp2(fma) per score; force_tr=1) against the general
+    online-softmax kernel (force_tr=0 never takes the 128 x 128 path): the same row maxima bit for bit (fully blocked rows included:
+    -finfo(bf16).max), row sums to fp32 rounding, outputs to one bf16 rounding."""
+    ops, L = _ops()
+    B, H, N = 5, 3, 128
+    D = H * 64
+    qkv = bf(randn(B * N, 3 * D, seed=140) * 1.5)
+    mk = make_masks(kind, B, N, N, seed=141)
+    kinds = dict(none=L.MASK_NONE, keypad=L.MASK_KEYPAD, decoder=L.MASK_DECODER)
+    res = []
+    for tr in (0, 1):
+        o = torch.zeros(B * N, D, device=DEV, dtype=torch.bfloat16)
+        sm, sl = torch.zeros(B, H, N, device=DEV), torch.zeros(B, H, N, device=DEV)
+        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, N, N, 0.125, mask_kind=kinds[kind], kpad=mk["kpad"], cs=mk["cs"],
+                     modq=mk["modq"], modk=mk["modk"], stat_m=sm, stat_l=sl, force_tr=tr, zero_attn=zero_attn)
+        res.append((o.float(), sm, sl))
+    (o0, m0, l0), (o1, m1, l1) = res
+    assert torch.equal(m0, m1)
+    if kind != "none":
+        assert int((m1 < -1e38).sum()) > 0 or zero_attn          # the fixture holds fully blocked rows
+    assert float(((l0 - l1).abs() / l0).max()) < 2e-6
+    assert float((o0 - o1).abs().max()) <= 2 ** -7 * float(o0.abs().max()) and rel_err(o1, o0) < 2e-3
+
+
 @pytest.mark.parametrize("R,H,bias", [(37, 2, True), (1000, 12, False)])
 def test_headnorm(R, H, bias):
     """Per-head LayerNorm of q / k (qk_norm models) on a column block of a wider buffer, forward and backward."""
@@ -715,7 +742,8 @@ def test_adamw_matches_torch():
     assert abs(float(coef) - min(1.0, 1.0 / (float(g.norm()) + 1e-6))) < 1e-6
 
 
-@pytest.mark.parametrize("kind,Nq,Nk", [("none", 128, 128), ("keypad", 100, 100), ("decoder", 64, 64), ("keypad", 40, 130)])
+@pytest.mark.parametrize("kind,Nq,Nk", [("none", 128, 128), ("keypad", 100, 100), ("decoder", 64, 64), ("keypad", 40, 130), ("keypad", 128, 128),
+                                        ("decoder", 128, 128)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_attention_zero_attn(kind, Nq, Nk, dtype):
     """allow_zero_attn (upstream softmax1, fm_utils.py:28-30): p = softmax(pad(scores, one zero logit))[..., :-1], forward and backward,
