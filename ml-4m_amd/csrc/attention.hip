@@ -433,6 +433,177 @@ __global__ __launch_bounds__(256, 3) void attn_fwd128_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, Nq and Nk multiples of 128, Nk <= 512 (256 x 256: the 4M-L / mod21 training shapes): attn_fwd128_kernel's per-score arithmetic
+// inside an online softmax over key tiles of 128 (two LDS buffers, one barrier per tile).  A blocked score is replaced by NEGR = -2^120 on
+// the RAW score: NEGR * c2 is exact for every scale, so in a fully blocked row fma(NEGR, c2, -max) = 0 exactly and p = 1 on every key
+// without a fix-up (upstream's uniform row), while next to any real score exp2 underflows to exactly 0; a row maximum below -1e30 is
+// reported as NEG_FILL (the backward's "fully blocked" marker).  Decoder rule packed with an 11-bit key field (attn_bwd_kernel's DIET form).
+// ------------------------------------------------------------------------------------------------
+template <int MASK, bool DB>
+__global__ __launch_bounds__(256, DB ? 2 : 3) void attn_fwdt_kernel(AttnArgs a) {
+    constexpr int N = 128;
+    constexpr float NEGR = -1.329227995784916e36f;       // -2^120
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NT = a.Nk / N;
+    char* tiles = smem;                                  // [buffer][K tile 16 KB | V tile 16 KB]
+    int* uk_l = (int*)(smem + ((DB && NT > 1) ? 2 : 1) * 2 * N * ROWB);      // decoder: (mod_k << 11) + k per key; key padding: the bitmap of padded keys
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fhi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * N + wave * 32 + (lane & 31);
+    const bf16_t* Qb = a.Q + (size_t)b * a.Nq * a.ldq + h * HD;
+    const bf16_t* Kb = a.K + (size_t)b * a.kvr * a.ldk + h * HD;
+    const bf16_t* Vb = a.V + (size_t)b * a.kvr * a.ldv + h * HD;
+    auto stage = [&](int t, int buf) {
+        char* kt = tiles + buf * 2 * N * ROWB;
+        stage_rows<4>(Kb, a.ldk, t * N, a.Nk, N, kt, wave, lane);
+        stage_rows<4>(Vb, a.ldv, t * N, a.Nk, N, kt + N * ROWB, wave, lane);
+    };
+    stage(0, 0);
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(Qb + (size_t)q * a.ldq + (kk * 2 + fhi) * 8);
+    int wq = 0;                                          // decoder: (mod_q << 11) + cs_q - 1: blocked <=> (unsigned)(wq - uk) >= 1023
+    if constexpr (MASK == FM_MASK_DECODER) {
+        int csv = 1023, lov = 0;
+        if (a.causal) csv = q + 1;
+        else if (a.cs) csv = min(max(a.cs[(size_t)b * a.Nq + q], 0), 1023);
+        if (a.modq) lov = (int)a.modq[(size_t)b * a.Nq + q] << 11;
+        wq = lov + csv - 1;
+        for (int k = threadIdx.x; k < a.Nk; k += 256) uk_l[k] = (((a.modq && a.modk) ? (int)a.modk[(size_t)b * a.Nk + k] : 0) << 11) + k;
+    }
+    if constexpr (MASK == FM_MASK_KEYPAD) {
+        for (int k0 = wave * 64; k0 < a.Nk; k0 += 256) {      // wave-uniform: 64 keys per wave and round
+            const unsigned long long bits = __ballot(a.kpad ? a.kpad[(size_t)b * a.Nk + k0 + lane] != 0 : false);
+            if (lane == 0) *(unsigned long long*)(uk_l + k0 / 32) = bits;
+        }
+    }
+    __syncthreads();
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c2 = a.scale * LOG2E;                    // > 0 (checked by the dispatch): max(s c2) = c2 max(s)
+    for (int t = 0; t < NT; ++t) {
+        const int buf = DB ? (t & 1) : 0;
+        if (DB && t + 1 < NT) stage(t + 1, buf ^ 1);
+        const char* Kt = tiles + buf * 2 * N * ROWB;
+        const char* Vt = Kt + N * ROWB;
+        f32x16_t st[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, kb * 32 + (lane & 31), kk, fhi), qf[kk], st[kb], 0, 0, 0);
+        }
+        float mraw = NEGR;
+        unsigned bm[4] = {0u, 0u, 0u, 0u};
+        if constexpr (MASK == FM_MASK_KEYPAD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bm[i] = (unsigned)__builtin_amdgcn_readfirstlane(uk_l[t * 4 + i]);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+                i32x4_t uk4 = {0, 0, 0, 0};
+                if constexpr (MASK == FM_MASK_DECODER) uk4 = *(const i32x4_t*)(uk_l + t * N + kb * 32 + 8 * g + 4 * fhi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * g + j, cc = j + 8 * g;              // key = 128 t + 32 kb + cc + 4 fhi
+                    float s = st[kb][r];
+                    if constexpr (MASK == FM_MASK_KEYPAD) {
+                        const unsigned long long mk = (unsigned long long)(0u - ((bm[kb] >> cc) & 1u)) | ((unsigned long long)(0u - ((bm[kb] >> (cc + 4)) & 1u)) << 32);
+                        s = __builtin_amdgcn_inverse_ballot_w64(mk) ? NEGR : s;
+                    }
+                    if constexpr (MASK == FM_MASK_DECODER) s = (unsigned)(wq - uk4[j]) >= 1023u ? NEGR : s;
+                    st[kb][r] = s;
+                    mraw = fmaxf(mraw, s);
+                }
+            }
+        mraw = fmaxf(mraw, __shfl_xor(mraw, 32, 64));
+        const float m_new = fmaxf(m_run, mraw * c2);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // first tile: exp2(-inf) = 0
+        const float nm = -m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c2, nm));
+                st[kb][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        if (t > 0 && !__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                union { bf16x8_t v; uint32_t u[4]; } pb;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pb.u[i] = pack2bf(st[kb][8 * s + 2 * i], st[kb][8 * s + 2 * i + 1]);
+                const int rA = kb * 32 + s * 16 + 4 * fhi;
+#pragma unroll
+                for (int df = 0; df < 2; ++df) {
+                    const bf16x8_t vf = lds_col_frag<true>([&](int r, int c) { return tile_addr(Vt, r, c); }, rA, rA + 8, df * 32);
+                    o[df] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb.v, o[df], 0, 0, 0);
+                }
+            }
+        if (t + 1 < NT) {
+            __syncthreads();
+            if (!DB) {      // one buffer (34 KB, three workgroups per CU): the next tile is requested when every wave is done with this one
+                stage(t + 1, 0);
+                __syncthreads();
+            }
+        }
+    }
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (m_run < -1e30f) m_run = NEG_FILL;                // every key blocked (p = 1 on each of them): the general kernel's marker
+    float m_fin = m_run, oscale = 1.0f;
+    if (a.zero_attn) {      // softmax1 (fm_utils.py:28-30), as in attn_fwd_kernel
+        m_fin = fmaxf(m_run, 0.f);
+        oscale = __builtin_amdgcn_exp2f(m_run - m_fin);
+        l_tot = l_tot * oscale + __builtin_amdgcn_exp2f(-m_fin);
+    }
+    const float inv = oscale / l_tot;
+    {
+        bf16_t* orow = a.O + ((size_t)b * a.Nq + q) * a.ldo + h * HD;
+        const bool wide_o = (a.ldo & 7) == 0 && (((uintptr_t)a.O) & 15) == 0;
+#pragma unroll
+        for (int df = 0; df < 2; ++df)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                uint2 po[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    po[u] = make_uint2(pack2bf(o[df][4 * (g + u)] * inv, o[df][4 * (g + u) + 1] * inv),
+                                       pack2bf(o[df][4 * (g + u) + 2] * inv, o[df][4 * (g + u) + 3] * inv));
+                store_bf16_groups(orow, df * 32 + 8 * g, po[0], po[1], fhi, HD, wide_o);
+            }
+    }
+    if (fhi == 0 && a.stat_m) {
+        const size_t si = ((size_t)b * a.H + h) * a.Nq + q;
+        a.stat_m[si] = m_fin;
+        a.stat_l[si] = l_tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: one workgroup per (b, h).
 //   pass A  (a wave owns 32 keys, loops over queries)   -> dK, dV      LDS: (Q, dO)
 //   pass B  (a wave owns 32 queries, loops over keys)   -> dQ          LDS: (K, V)
@@ -1375,7 +1546,8 @@ extern "C" int fm_attn_fwd(const fm_attn_args* p, void* stream) {
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
     // 128 x 128 tokens exactly: the round-5 kernel (all keys in LDS at once, 4 - 7 VALU per score); FOURM_ATTN_FWD_V2=0 keeps the general one
     static const bool v2_on = [] { const char* e = getenv("FOURM_ATTN_FWD_V2"); return !e || atoi(e) != 0; }();
-    if (v2_on && tr && a.Nq == 128 && a.Nk == 128 && a.mask_kind != FM_MASK_DENSE && a.scale > 0.f) {
+    static const bool t_for_128 = [] { const char* e = getenv("FOURM_ATTN_FWD_T"); return e && atoi(e) == 2; }();
+    if (v2_on && !t_for_128 && tr && a.Nq == 128 && a.Nk == 128 && a.mask_kind != FM_MASK_DENSE && a.scale > 0.f) {
         const size_t lds128 = (size_t)2 * 128 * ROWB + 128 * 4;
         const dim3 grid128(a.H, a.B);
         switch (a.mask_kind) {
@@ -1384,6 +1556,26 @@ extern "C" int fm_attn_fwd(const fm_attn_args* p, void* stream) {
             case FM_MASK_DECODER: hipLaunchKernelGGL((attn_fwd128_kernel<FM_MASK_DECODER>), grid128, dim3(256), lds128, (hipStream_t)stream, a); break;
             default: fm_set_error("fm_attn_fwd: unknown mask kind %d", a.mask_kind); return -1;
         }
+        FM_CHECK_LAUNCH("fm_attn_fwd");
+        return 0;
+    }
+    // Nq, Nk multiples of 128, Nk <= 512 (256 x 256: 4M-L / mod21): the same arithmetic in an online softmax over 128-key tiles.
+    // FOURM_ATTN_FWD_T=0 keeps the general kernel; =2 also routes the 128 x 128 shape here (lab comparison with attn_fwd128_kernel).
+    static const int t_mode = [] { const char* e = getenv("FOURM_ATTN_FWD_T"); return e ? atoi(e) : 1; }();
+    if (t_mode && tr && a.Nq % 128 == 0 && a.Nk % 128 == 0 && a.Nk <= 512 && a.mask_kind != FM_MASK_DENSE && a.scale > 0.f) {
+        static const bool t_db = [] { const char* e = getenv("FOURM_ATTN_FWD_DB"); return e && atoi(e) != 0; }();      // lab: two K/V buffers, two workgroups per CU
+        const size_t ldst = (size_t)((t_db && a.Nk > 128) ? 2 : 1) * 2 * 128 * ROWB + (size_t)a.Nk * 4;
+        const dim3 gridt(a.Nq / 128, a.H, a.B);
+#define FWDT(MK)                                                                                                              \
+    if (t_db) hipLaunchKernelGGL((attn_fwdt_kernel<MK, true>), gridt, dim3(256), ldst, (hipStream_t)stream, a);                \
+    else hipLaunchKernelGGL((attn_fwdt_kernel<MK, false>), gridt, dim3(256), ldst, (hipStream_t)stream, a);
+        switch (a.mask_kind) {
+            case FM_MASK_NONE: FWDT(FM_MASK_NONE) break;
+            case FM_MASK_KEYPAD: FWDT(FM_MASK_KEYPAD) break;
+            case FM_MASK_DECODER: FWDT(FM_MASK_DECODER) break;
+            default: fm_set_error("fm_attn_fwd: unknown mask kind %d", a.mask_kind); return -1;
+        }
+#undef FWDT
         FM_CHECK_LAUNCH("fm_attn_fwd");
         return 0;
     }

@@ -581,28 +581,33 @@ def test_attention(kind, Nq, Nk, tr):
 
 @pytest.mark.parametrize("kind", ["none", "keypad", "decoder"])
 @pytest.mark.parametrize("zero_attn", [False, True])
-def test_attention_fwd128_matches_the_general_kernel(kind, zero_attn):
-    """The 128 x 128 forward (all keys in LDS at once, mask on the raw scores, one exp2(fma) per score; force_tr=1) against the general
-    online-softmax kernel (force_tr=0 never takes the 128 x 128 path): the same row maxima bit for bit (fully blocked rows included:
+@pytest.mark.parametrize("Nq,Nk", [(128, 128), (256, 256), (384, 256), (128, 512)])
+def test_attention_fwd128_matches_the_general_kernel(kind, zero_attn, Nq, Nk):
+    """The forward kernels for whole 128-token tiles - 128 x 128: all keys in LDS at once; multiples of 128 up to 512 keys: the same
+    per-score arithmetic in an online softmax over 128-key tiles (mask on the raw scores, one exp2(fma) per score; force_tr=1) - against
+    the general online-softmax kernel (force_tr=0 never takes those paths): the same row maxima bit for bit (fully blocked rows included:
     -finfo(bf16).max), row sums to fp32 rounding, outputs to one bf16 rounding."""
+    if kind == "decoder" and Nq != Nk:
+        pytest.skip("the decoder rule is a self-attention mask")
     ops, L = _ops()
-    B, H, N = 5, 3, 128
+    B, H = 5, 3
     D = H * 64
-    qkv = bf(randn(B * N, 3 * D, seed=140) * 1.5)
-    mk = make_masks(kind, B, N, N, seed=141)
+    q2 = bf(randn(B * Nq, D, seed=140) * 1.5)
+    kv = bf(randn(B * Nk, 2 * D, seed=142) * 1.5)
+    mk = make_masks(kind, B, Nq, Nk, seed=141)
     kinds = dict(none=L.MASK_NONE, keypad=L.MASK_KEYPAD, decoder=L.MASK_DECODER)
     res = []
     for tr in (0, 1):
-        o = torch.zeros(B * N, D, device=DEV, dtype=torch.bfloat16)
-        sm, sl = torch.zeros(B, H, N, device=DEV), torch.zeros(B, H, N, device=DEV)
-        ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, B, H, N, N, 0.125, mask_kind=kinds[kind], kpad=mk["kpad"], cs=mk["cs"],
+        o = torch.zeros(B * Nq, D, device=DEV, dtype=torch.bfloat16)
+        sm, sl = torch.zeros(B, H, Nq, device=DEV), torch.zeros(B, H, Nq, device=DEV)
+        ops.attn_fwd(q2, kv[:, :D], kv[:, D:], o, B, H, Nq, Nk, 0.125, mask_kind=kinds[kind], kpad=mk["kpad"], cs=mk["cs"],
                      modq=mk["modq"], modk=mk["modk"], stat_m=sm, stat_l=sl, force_tr=tr, zero_attn=zero_attn)
         res.append((o.float(), sm, sl))
     (o0, m0, l0), (o1, m1, l1) = res
     assert torch.equal(m0, m1)
-    if kind != "none":
-        assert int((m1 < -1e38).sum()) > 0 or zero_attn          # the fixture holds fully blocked rows
-    assert float(((l0 - l1).abs() / l0).max()) < 2e-6
+    if kind != "none" and not zero_attn:
+        assert int((m1 < -1e38).sum()) > 0                       # the fixture holds fully blocked rows
+    assert float(((l0 - l1).abs() / l0).max()) < 3e-6
     assert float((o0 - o1).abs().max()) <= 2 ** -7 * float(o0.abs().max()) and rel_err(o1, o0) < 2e-3
 
 
