@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void attn_fwdt_kernel(AttnArgs a) 
     int wq = 0;                                          // decoder: (mod_q << 11) + cs_q - 1: blocked <=> (unsigned)(wq - uk) >= 1023
     if constexpr (MASK == FM_MASK_DECODER) {
         int csv = 1023, lov = 0;
-        if (a.causal) csv = q + 1;
+        if (a.causal) csv = min(q + 1, 1023);                 // keys are < 512: any bound >= 512 shows them all
         else if (a.cs) csv = min(max(a.cs[(size_t)b * a.Nq + q], 0), 1023);
         if (a.modq) lov = (int)a.modq[(size_t)b * a.Nq + q] << 11;
         wq = lov + csv - 1;

@@ -579,7 +579,7 @@ def test_attention(kind, Nq, Nk, tr):
         assert rel_err(got, want) < 2e-2, (kind, tr, name, rel_err(got, want))
 
 
-@pytest.mark.parametrize("kind", ["none", "keypad", "decoder"])
+@pytest.mark.parametrize("kind", ["none", "keypad", "decoder", "causal"])
 @pytest.mark.parametrize("zero_attn", [False, True])
 @pytest.mark.parametrize("Nq,Nk", [(128, 128), (256, 256), (384, 256), (128, 512)])
 def test_attention_fwd128_matches_the_general_kernel(kind, zero_attn, Nq, Nk):
@@ -587,25 +587,31 @@ def test_attention_fwd128_matches_the_general_kernel(kind, zero_attn, Nq, Nk):
     per-score arithmetic in an online softmax over 128-key tiles (mask on the raw scores, one exp2(fma) per score; force_tr=1) - against
     the general online-softmax kernel (force_tr=0 never takes those paths): the same row maxima bit for bit (fully blocked rows included:
     -finfo(bf16).max), row sums to fp32 rounding, outputs to one bf16 rounding."""
-    if kind == "decoder" and Nq != Nk:
+    if kind in ("decoder", "causal") and Nq != Nk:
         pytest.skip("the decoder rule is a self-attention mask")
     ops, L = _ops()
     B, H = 5, 3
     D = H * 64
     q2 = bf(randn(B * Nq, D, seed=140) * 1.5)
     kv = bf(randn(B * Nk, 2 * D, seed=142) * 1.5)
-    mk = make_masks(kind, B, Nq, Nk, seed=141)
-    kinds = dict(none=L.MASK_NONE, keypad=L.MASK_KEYPAD, decoder=L.MASK_DECODER)
+    mk = make_masks("none" if kind == "causal" else kind, B, Nq, Nk, seed=141)
+    kinds = dict(none=L.MASK_NONE, keypad=L.MASK_KEYPAD, decoder=L.MASK_DECODER, causal=L.MASK_DECODER)
     res = []
     for tr in (0, 1):
         o = torch.zeros(B * Nq, D, device=DEV, dtype=torch.bfloat16)
         sm, sl = torch.zeros(B, H, Nq, device=DEV), torch.zeros(B, H, Nq, device=DEV)
         ops.attn_fwd(q2, kv[:, :D], kv[:, D:], o, B, H, Nq, Nk, 0.125, mask_kind=kinds[kind], kpad=mk["kpad"], cs=mk["cs"],
-                     modq=mk["modq"], modk=mk["modk"], stat_m=sm, stat_l=sl, force_tr=tr, zero_attn=zero_attn)
+                     modq=mk["modq"], modk=mk["modk"], stat_m=sm, stat_l=sl, force_tr=tr, zero_attn=zero_attn, causal=kind == "causal")
         res.append((o.float(), sm, sl))
     (o0, m0, l0), (o1, m1, l1) = res
     assert torch.equal(m0, m1)
-    if kind != "none" and not zero_attn:
+    if kind == "causal":                                         # (decoder_causal_mask, fm.py:466-468) against the definition itself
+        qh, kh, vh = (t.reshape(B, -1, H, 64).transpose(1, 2).float() for t in (q2, kv[:, :D], kv[:, D:]))
+        blocked = torch.ones(Nq, Nk, dtype=torch.bool, device=DEV).triu(1)[None, None]
+        if not zero_attn:
+            ref, _ = ref_attention(qh, kh, vh, blocked, 0.125)
+            assert rel_err(o1.reshape(B, Nq, H, 64).transpose(1, 2), ref) < 8e-3
+    if kind in ("keypad", "decoder") and not zero_attn:
         assert int((m1 < -1e38).sum()) > 0                       # the fixture holds fully blocked rows
     assert float(((l0 - l1).abs() / l0).max()) < 3e-6
     assert float((o0 - o1).abs().max()) <= 2 ** -7 * float(o0.abs().max()) and rel_err(o1, o0) < 2e-3
