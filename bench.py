@@ -124,7 +124,7 @@ class LaunchProfiler:
 
 KERNEL_REGEX = {   # profiler family -> regex on the demangled kernel name (7th template argument of gemm_nt = epilogue)
     "gemm_nt": r"(gemm_nt3_kernel<\d+, {epi}, |gemm_nt_kernel<\d+, \d+, \d+, \d+, \d+, \d+, {epi}, false)",
-    "gemm_tn": r"gemm_tn_kernel<\w+, false", "gemm_tn_multi": r"gemm_tn_multi_kernel", "attn_fwd": r"attn_fwd_kernel", "attn_bwd": r"attn_bwd\w*_kernel",
+    "gemm_tn": r"gemm_tn_kernel<\w+, false", "gemm_tn_multi": r"gemm_tn_multi_kernel", "attn_fwd": r"attn_fwd\w*_kernel", "attn_bwd": r"attn_bwd\w*_kernel",
     "layernorm_fwd": r"ln_fwd_kernel", "layernorm_bwd": r"ln_bwd_kernel",
 }
 
@@ -682,7 +682,7 @@ def main():
                              "every dense bf16 Linear of the trunk, forward and dX",
                   "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,64,3,PP=true>  (csrc/gemm.hip)",
                   "gemm_tn_multi": "gemm_tn_multi_kernel<MASKED=false>  (csrc/gemm.hip; all dW GEMMs of a layer per launch)",
-                  "attn_fwd": "attn_fwd_kernel<true,MASK>", "attn_bwd": "attn_bwd128_kernel<MASK> (key padding) / attn_bwd128o_kernel<MASK> (decoder mask) at 128 x 128 tokens, attn_bwd_kernel<true,MASK,..> otherwise",
+                  "attn_fwd": "attn_fwd128_kernel<MASK> at 128 x 128 tokens, attn_fwdt_kernel<MASK> at multiples of 128 up to 512 keys, attn_fwd_kernel<true,MASK> otherwise", "attn_bwd": "attn_bwd128_kernel<MASK> (key padding) / attn_bwd128o_kernel<MASK> (decoder mask) at 128 x 128 tokens, attn_bwd_kernel<true,MASK,..> otherwise",
                   "layernorm_fwd": "ln_fwd_kernel<bf16,3>", "layernorm_bwd": "ln_bwd_kernel<3>"}
         name, d = max(agg.items(), key=lambda kv: kv[1]["ms"])
         fam, _, epi = name.partition("/epi")

@@ -3,25 +3,26 @@
 # rocprofv3 kernel stats of the bench command, lab tables of the GEMM kernels.  Everything lands under gpurun_out/ (copy what is to be
 # judged into profiles/).
 cd "$(dirname "$0")/.."
+TAG=${TAG:-r05_final}
 mkdir -p gpurun_out; rm -f gpurun_out/parity.jsonl
 export TMPDIR=/tmp
 ROOT=$(pwd)
 export LD_LIBRARY_PATH=$ROOT/ml-4m_amd/fourm/_lib:$LD_LIBRARY_PATH
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 if [ -z "$SKIP_TESTS" ]; then
-  timeout 1500 python -m pytest tests -v -m gpu -x --tb=short --durations=15 > gpurun_out/r05_final_pytest_full.txt 2>&1     # (-v into a file: a cut-off run still shows how far it got)
-  grep -v Warning gpurun_out/r05_final_pytest_full.txt | tail -30 | cut -c1-300 > gpurun_out/r05_final_pytest.txt
-  tail -3 gpurun_out/r05_final_pytest.txt
+  timeout 1500 python -m pytest tests -v -m gpu -x --tb=short --durations=15 > gpurun_out/${TAG}_pytest_full.txt 2>&1     # (-v into a file: a cut-off run still shows how far it got)
+  grep -v Warning gpurun_out/${TAG}_pytest_full.txt | tail -30 | cut -c1-300 > gpurun_out/${TAG}_pytest.txt
+  tail -3 gpurun_out/${TAG}_pytest.txt
   cp gpurun_out/parity.jsonl profiles/r05_parity.jsonl      # bench.py's `parity` record reads the newest profiles/rNN_parity.jsonl
 fi
-BENCH_SHAPE_TABLE=gpurun_out/r05_final_shape_table.txt timeout 900 python bench.py 2> gpurun_out/r05_final_bench.err | tail -1 > gpurun_out/r05_final_bench.json
-cut -c1-400 gpurun_out/r05_final_bench.json
+BENCH_SHAPE_TABLE=gpurun_out/${TAG}_shape_table.txt timeout 900 python bench.py 2> gpurun_out/${TAG}_bench.err | tail -1 > gpurun_out/${TAG}_bench.json
+cut -c1-400 gpurun_out/${TAG}_bench.json
 rm -rf gpurun_out/prof_final
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_final -o trace -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-traffic --no-extras > $ROOT/gpurun_out/r05_final_bench_under_rocprof.json 2> $ROOT/gpurun_out/prof_final.err)
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_final -o trace -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-traffic --no-extras > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2> $ROOT/gpurun_out/prof_final.err)
 f=$(find gpurun_out/prof_final -name "*kernel_stats.csv" | head -1)
-cp "$f" gpurun_out/r05_final_kernel_stats.csv
+cp "$f" gpurun_out/${TAG}_kernel_stats.csv
 rm -rf gpurun_out/prof_final
-head -12 gpurun_out/r05_final_kernel_stats.csv | cut -c1-160
+head -12 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-160
 { echo "# tools/gemm_lab nt 265,268,1001,1002,1003: round-2 automatic choice (265), round-2 256x256 ping-pong (268), gemm_nt3 256-wide / 192-wide / by shape (the default)";
   timeout 200 tools/bin/gemm_lab nt 265,268,1001,1002,1003;
   echo "# the same with experiment flags on gemm_nt3 (by shape): 10243 legacy epilogue (32-byte-per-row stores), 1013 no wait for the DMA, 1023 no main-loop DMA, 1043 no stores, 1063 no DMA + no stores";
@@ -29,7 +30,7 @@ head -12 gpurun_out/r05_final_kernel_stats.csv | cut -c1-160
   echo "# T(K) at fixed M, N (operands with leading dimension 6144)";
   timeout 200 tools/bin/gemm_lab ksweep 266,1001,1002;
   echo "# all dW GEMMs of a layer: one fm_gemm_tn launch each vs ONE fm_gemm_tn_multi launch";
-  timeout 100 tools/bin/gemm_lab tnmulti 32768 1; } > gpurun_out/r05_final_lab_nt3.txt 2>&1
-tail -4 gpurun_out/r05_final_lab_nt3.txt
-timeout 300 bash tools/pmc_attn_run.sh > gpurun_out/r05_final_pmc_attn.txt 2>&1; tail -2 gpurun_out/r05_final_pmc_attn.txt | cut -c1-300
-timeout 300 python tools/divae_bench.py 8 25 > gpurun_out/r05_final_divae_bench.txt 2>&1; tail -2 gpurun_out/r05_final_divae_bench.txt
+  timeout 100 tools/bin/gemm_lab tnmulti 32768 1; } > gpurun_out/${TAG}_lab_nt3.txt 2>&1
+tail -4 gpurun_out/${TAG}_lab_nt3.txt
+timeout 300 bash tools/pmc_attn_run.sh > gpurun_out/${TAG}_pmc_attn.txt 2>&1; tail -2 gpurun_out/${TAG}_pmc_attn.txt | cut -c1-300
+timeout 300 python tools/divae_bench.py 8 25 > gpurun_out/${TAG}_divae_bench.txt 2>&1; tail -2 gpurun_out/${TAG}_divae_bench.txt
