@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 6
+#define FM_ABI_VERSION 7
 int fm_abi_version(void);
 const char* fm_last_error(void);
 
@@ -60,6 +60,12 @@ typedef struct fm_gemm_nt_args {
     void* out; void* out2; const void* res; const void* bias; const void* bias2;
     int32_t M, N, K, ldw, ldx, ldo, ldo2, ldr, Hp, epilogue;
     const fm_gemm_group* groups; const int32_t* tile_group; int32_t max_N, pad_;
+    /* Row range in DEVICE memory (ABI 7; both or neither, NULL = rows [0, M)): the launch covers rows [*row0_dev, *row0_dev +
+     * roundup(*m_dev, FM_SEG_ROWS)) of X / out - one modality head's segment as fm_segment_rows laid it out (seg_start[h], seg_count[h];
+     * pad rows zero) - with M an upper bound.  One dense launch per head then replaces the grouped launch without a host read of the
+     * row counts (FourM.forward_logits, fm.py:521-545).  FM_EPI_BF16 without bias, ldo % 64 == 0, out 128-byte aligned, N % 8 == 0,
+     * K % 64 == 0; other arguments are rejected. */
+    const int32_t* m_dev; const int32_t* row0_dev;
 } fm_gemm_nt_args;
 int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
 /* tile configuration of fm_gemm_nt, for A/B measurements (table in csrc/gemm.hip): low byte 0-8 = fixed

@@ -1194,7 +1194,8 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     a.n_tiles_x = (a.M + TX - 1) / TX;
     int grid = a.n_tiles_w * a.n_tiles_x;
     if (GROUPED) {
-        a.group_w = a.n_tiles_w < 16 ? a.n_tiles_w : 16;
+        const int gw_max = TW > 128 ? 8 : 16;            // one L2 working set of W tiles (<= 3.1 MB at K = 768)
+        a.group_w = a.n_tiles_w < gw_max ? a.n_tiles_w : gw_max;
         const int chunks = ((a.n_tiles_w + a.group_w - 1) / a.group_w) * ((a.n_tiles_x + 3) / 4);
         grid = (chunks + 7) / 8 * 8 * a.group_w * 4;
     }
@@ -1233,6 +1234,11 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
         // rows are segmented in FM_SEG_ROWS (= 256 = the X tile) per group; a.K = upper bound of the groups' K
         static_assert(FM_SEG_ROWS == 256, "the grouped configurations use a 256-row X tile");
         if (a.K >= 1536) return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, true, true>(a, max_n, s);
+        if constexpr (EPI == EPI_BF16) {      // lab (tools/heads_bench.py): 256 x 256 ping-pong tiles for the logits GEMM
+            static const int heads_cfg = [] { const char* e = getenv("FOURM_HEADS_NT_CFG"); return e ? atoi(e) : 0; }();
+            if (heads_cfg == 1) return launch_nt_cfg<256, 256, 2, 4, 32, 3, EPI, true, true>(a, max_n, s);
+            if (heads_cfg == 2) return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, true, true>(a, max_n, s);
+        }
         return launch_nt_cfg<128, 256, 2, 4, 32, 3, EPI, true>(a, max_n, s);
     }
     if (a.M <= 128) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI, GROUPED>(a, max_n, s);
@@ -1285,6 +1291,16 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     a.prio = g_nt_prio;
     a.dephase_groups = g_lab[0]; a.dephase_step = g_lab[1]; a.lab = g_lab[3];
     hipStream_t s = (hipStream_t)stream;
+    a.m_dev = p->m_dev; a.row0_dev = p->row0_dev;
+    if (p->m_dev || p->row0_dev) {            // row range in device memory (one dense launch per modality head): gemm_nt3 only
+        FM_CHECK_ARG(p->m_dev && p->row0_dev && !grouped, "fm_gemm_nt: m_dev and row0_dev go together (dense launches only)");
+        const int r = fm_launch_nt3(a, p->epilogue, g_lab[2] ? g_lab[2] : 3, s);
+        if (r < 0) { fm_set_error("fm_gemm_nt (nt3, device-side rows): launch failed"); return -2; }
+        if (r > 0) return 0;
+        fm_set_error("fm_gemm_nt: a device-side row range needs FM_EPI_BF16 without bias, N %% 8 == 0, K %% 64 == 0, ldo %% 64 == 0 and a 128-byte aligned out "
+                     "(N=%d K=%d ldo=%d epilogue=%d)", p->N, p->K, p->ldo, p->epilogue);
+        return -1;
+    }
     const int max_n = grouped ? p->max_N : p->N;
     if (!grouped && p->M <= 32) {             // a handful of rows (a decoding step): the weight-streaming kernel of gemm_skinny.hip
         const int r = fm_launch_nt_skinny(a, p->epilogue, s);

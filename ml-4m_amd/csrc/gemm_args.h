@@ -13,6 +13,7 @@ struct NTArgs {
     void* out; void* out2; const float* res; const float* bias; const float* bias2;
     int M, N, K, ldw, ldx, ldo, ldo2, ldr, Hp;
     const fm_gemm_group* groups; const int* tile_group;   // grouped mode (may be null)
+    const int* m_dev; const int* row0_dev;                // gemm_nt3 DEVM: row count / first row of this launch in device memory (may be null)
     int n_tiles_w, n_tiles_x;
     int group_w;                                          // grouped: W-tiles per column block
     int prio;                                             // raise the wave priority around the MFMA clusters

@@ -41,9 +41,22 @@ constexpr uint32_t OOB = 0x80000000u;       // an offset with bit 31 set is outs
 // 128-byte lines: the same store instructions, half the write requests (64 bytes each), bit-identical outputs.
 // BIAS (staged dense epilogues only): out = bf16(acc + bf16(bias[n])); EPI_GELU: pre = that value (out2, optional), out = bf16(gelu(pre)) -
 // the biased Linears of the tokenizers' ViTs and of the *_gelu 4M variants (gemm.hip's epilogue arithmetic, bit for bit).
-template <int TW, int EPI, bool SPLIT = false, bool STG = false, bool BIAS = false>
+// DEVM (the per-modality logits GEMMs, round 5): the row range of the launch is read from device memory - rows [row0_dev[0], + m_dev[0] rounded
+// up to whole 256-row tiles) of X / out (a head's FM_SEG_ROWS-aligned segment; the caller's pad rows are zero) - so that one dense launch per
+// head replaces the grouped kernel of gemm.hip without the host knowing the row counts (hipGraph capture).  The grid is every CU in use;
+// workgroups without a tile leave at once.
+template <int TW, int EPI, bool SPLIT = false, bool STG = false, bool BIAS = false, bool DEVM = false>
 __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (DEVM) {
+        static_assert(EPI == EPI_BF16, "device-side row ranges: bf16 outputs only");
+        const int m = (a.m_dev[0] + 255) & ~255;
+        const size_t r0 = (size_t)a.row0_dev[0];
+        a.M = m; a.n_tiles_x = m >> 8;
+        a.X += r0 * a.ldx;
+        a.out = (char*)a.out + r0 * a.ldo * 2;
+        if (a.n_tiles_w * a.n_tiles_x <= (int)blockIdx.x) return;
+    }
     constexpr int TX = 256, KB = 64, WW = 2, WX = 4, NWAVES = 8, KS = 4;
     constexpr int RB = 128, CPR = 8, RPP = 8;
     constexpr int FW = TW / WW / 32, FX = TX / WX / 32;             // 4 (3) x 2 fragments of 32 x 32 per wave
@@ -560,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
 #endif
 }
 
-template <int TW, int EPI, bool SPLIT = false, bool STG = false, bool BIAS = false>
+template <int TW, int EPI, bool SPLIT = false, bool STG = false, bool BIAS = false, bool DEVM = false>
 int launch_nt3(NTArgs a, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (a.N + NPT - 1) / NPT;
@@ -573,14 +586,14 @@ int launch_nt3(NTArgs a, hipStream_t s) {
     if (a.group_w == 15) a.group_w = 0;
     int grid = a.n_tiles_w * a.n_tiles_x;
     const int cus = fm_grid_cus();
-    if (grid > cus) grid = cus;
+    if (grid > cus || DEVM) grid = cus;                  // (DEVM: a.M is the caller's upper bound; the kernel reads the row count)
     // Tiles are walked from the LAST row block to the first: the rows the producer kernel wrote last are the ones still in the Infinity
     // Cache (a forward walk over freshly written data larger than the cache meets the oldest, evicted rows first), and this launch's own
     // outputs are then written last-rows-first for the ascending streaming kernel behind it.  62.0 -> 61.85 ms per 4M-B step, same box
     // (profiles/r04_ab_reverse_walk.txt); FOURM_NT3_LAB bit 2048: forward walk.
     a.reverse = (a.lab & 2048) ? 0 : 1;
     const size_t lds = (size_t)2 * (TW + 256) * 128 + (STG ? (TW == 256 ? 32768 : 49152) : 0);
-    auto k = gemm_nt3_kernel<TW, EPI, SPLIT, STG, BIAS>;
+    auto k = gemm_nt3_kernel<TW, EPI, SPLIT, STG, BIAS, DEVM>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);
@@ -595,6 +608,13 @@ int launch_nt3(NTArgs a, hipStream_t s) {
 int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     using namespace fmk;
     if (!mode || a.groups || a.bias2) return 0;
+    if (a.m_dev) {      // row range in device memory: the staged bf16 form only; tile width by N alone (the row count is not known here)
+        if (!a.row0_dev || epilogue != FM_EPI_BF16 || a.bias || a.K % 64 != 0 || a.K < 128 || a.N % 8 != 0 || a.ldo % 64 != 0 ||
+            (((uintptr_t)a.out) & 127) != 0 || (a.lab & (16 | 1024)))
+            return 0;
+        if ((size_t)256 * (size_t)a.ldo * 4 >= 0x7fffffffull || (size_t)256 * (size_t)a.ldx * 2 >= 0x7fffffffull || (size_t)256 * (size_t)a.ldw * 2 >= 0x7fffffffull) return 0;
+        return (a.N % 192 == 0 && a.N % 256 != 0) ? launch_nt3<192, EPI_BF16, true, true, false, true>(a, s) : launch_nt3<256, EPI_BF16, true, true, false, true>(a, s);
+    }
     if (a.bias && !(epilogue == FM_EPI_BF16 || epilogue == FM_EPI_GELU)) return 0;
     if (a.bias && ((((uintptr_t)a.bias) & 15) != 0 || (a.lab & (16 | 1024)))) return 0;       // (biased launches exist in the staged form only)
     if (a.M < 2048 || a.K % 64 != 0 || a.K < 128 || a.N % 8 != 0) return 0;

@@ -27,7 +27,7 @@ def _load():
 lib = _load()
 lib.fm_last_error.restype = C.c_char_p
 lib.fm_abi_version.restype = C.c_int
-ABI_VERSION = 6
+ABI_VERSION = 7
 if lib.fm_abi_version() != ABI_VERSION:
     raise FourmHipUnavailable(f"libfourm_hip.so ABI {lib.fm_abi_version()} != expected {ABI_VERSION}; rebuild")
 
@@ -47,7 +47,8 @@ class GemmGroup(C.Structure):
 class GemmNTArgs(C.Structure):
     _fields_ = [("W", vp), ("W2", vp), ("X", vp), ("out", vp), ("out2", vp), ("res", vp), ("bias", vp), ("bias2", vp),
                 ("M", i32), ("N", i32), ("K", i32), ("ldw", i32), ("ldx", i32), ("ldo", i32), ("ldo2", i32), ("ldr", i32),
-                ("Hp", i32), ("epilogue", i32), ("groups", vp), ("tile_group", vp), ("max_N", i32), ("pad_", i32)]
+                ("Hp", i32), ("epilogue", i32), ("groups", vp), ("tile_group", vp), ("max_N", i32), ("pad_", i32),
+                ("m_dev", vp), ("row0_dev", vp)]
 
 
 class GemmTNArgs(C.Structure):

@@ -29,6 +29,11 @@ from . import ops
 _WEIGHT_EPOCH = 0
 # run the activation backward inside the fc2 dX GEMM epilogue (bit-identical; measured slightly slower, see _mlp_bwd)
 FUSE_ACT_BWD = os.environ.get("FOURM_FUSE_ACT_BWD", "0") == "1"
+# Logits of the per-modality heads: one dense gemm_nt3 launch per head (row range from device memory) instead of the grouped kernel of
+# gemm.hip, for up to HEADS_DENSE_MAX heads (each launch has a fixed cost: 7 heads of 4M-B mod7 -0.4 ms per step, the 21 heads of mod21 no gain
+# in situ - profiles/r05_heads_dense.txt; FOURM_HEADS_DENSE=0: grouped always).
+HEADS_DENSE = os.environ.get("FOURM_HEADS_DENSE", "1") == "1"
+HEADS_DENSE_MAX = int(os.environ.get("FOURM_HEADS_DENSE_MAX", "8"))
 # The residual add behind attn.proj / cross_attn.proj / mlp.fc2 runs in the LayerNorm that follows (fm_layernorm_fwd_res) instead of the
 # GEMM epilogue: the GEMM becomes a plain bf16 launch (the lock-step kernel), the fp32 read-modify-write of the stream moves from an
 # epilogue all workgroups enter together (~2.8 TB/s) into a streaming kernel (5.5 TB/s).  Bit-identical.  FOURM_DEFER_RESIDUAL=0: fused.
@@ -812,7 +817,11 @@ class FourMEngine:
             self._head_groups = cache = (key, fwd, bwd, vt)
         hs["g_fwd"], hs["g_bwd"], hs["vocab_t"] = cache[1], cache[2], cache[3]
         logits = ws.get("heads.logits", (Rp, ldl), self.adt)
-        ops.gemm_nt_grouped(yp, hs["g_fwd"], hs["tile_group"], logits, hs["maxV"], max_K=D)
+        if HEADS_DENSE and not self.fp32 and nH <= HEADS_DENSE_MAX and ops.heads_dense_ok(w_fwd, vocabs, logits):
+            # one dense launch per head on gemm_nt3, row ranges read from seg_start / seg_count on the device (round 5: 1.03 -> ~0.8 ms at 4M-B)
+            ops.gemm_nt_heads(yp, w_fwd, vocabs, hs["seg_start"], hs["seg_count"], logits, D)
+        else:
+            ops.gemm_nt_grouped(yp, hs["g_fwd"], hs["tile_group"], logits, hs["maxV"], max_K=D)
         hs.update(yp=yp, logits=logits, sv=sv)
         hs["row_loss"] = ws.get("heads.row_loss", (Rp,), torch.float32)
         hs["row_lse"] = ws.get("heads.row_lse", (Rp,), torch.float32)

@@ -136,6 +136,29 @@ def gemm_nt_grouped(x, groups, tile_group, out, max_N, M=None, max_K=0):
     return out
 
 
+def heads_dense_ok(ws, vocabs, out):
+    """One dense fm_gemm_nt launch per head (row range read from device memory) can replace the grouped logits GEMM: bf16, every
+    vocabulary a multiple of 8, whole-line output rows (the staged epilogue of gemm_nt3)."""
+    return (out.dtype == torch.bfloat16 and all(v % 8 == 0 for v in vocabs) and all(w.dtype == torch.bfloat16 and w.shape[1] % 64 == 0 for w in ws)
+            and _ld(out) % 64 == 0 and out.data_ptr() % 128 == 0)
+
+
+@_timed("heads_gemm_nt (logits, dY)")
+def gemm_nt_heads(x, ws, vocabs, seg_start, seg_count, out, K):
+    """The logits of every modality head as ONE DENSE launch per head on the lock-step kernel (csrc/gemm_nt3.hip, DEVM): head h covers rows
+    [seg_start[h], seg_start[h] + roundup(seg_count[h], SEG)) of x / out - read by the kernel from device memory, so the step stays
+    capturable - against its own (V_h, K) weight.  Same outputs as gemm_nt_grouped on the rows of the segments (pad rows of x are zero)."""
+    for h, (w, v) in enumerate(zip(ws, vocabs)):
+        a = L.GemmNTArgs()
+        a.W, a.X, a.out = _p(w), _p(x), _p(out)
+        a.M, a.N, a.K = x.shape[0], v, K
+        a.ldw, a.ldx, a.ldo = _ld(w), _ld(x), _ld(out)
+        a.epilogue = L.EPI_BF16
+        a.m_dev, a.row0_dev = seg_count.data_ptr() + 4 * h, seg_start.data_ptr() + 4 * h
+        L.check(L.gemm_nt(C.byref(a), _stream()))
+    return out
+
+
 def gemm_tn(a_mat, b_mat, out, *, N=None, K=None, R=None, splits=0, force_tr=-1, a_cols=0, b_cols=0):
     """out[n][k] += sum_r a[r][n] b[r][k]; out fp32 (N, >=K)."""
     if a_mat.dtype == torch.float32:        # verification kernel: X := a^T, W := b^T through strides, accumulate

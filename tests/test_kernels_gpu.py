@@ -334,6 +334,52 @@ def test_gemm_tn_identity_layout():
         assert torch.equal(out, b.float()), f"tr={tr}"
 
 
+@pytest.mark.parametrize("vocabs,counts", [([512, 192, 1000, 64], [700, 0, 300, 5]), ([16384, 8192, 4096], [2000, 1500, 90])])
+def test_gemm_nt_heads_dense_matches_grouped(vocabs, counts):
+    """One dense gemm_nt3 launch per head with the row range read from device memory (fm_gemm_nt m_dev / row0_dev, ABI 7) against the
+    grouped launch on the same segmented rows: the logits of every head's segment (pad rows included: zero), nothing outside it; an
+    empty head (no rows) launches workgroups that leave at once."""
+    ops, L = _ops()
+    D = 192
+    n_heads, R = len(vocabs), sum(counts) + 40
+    head = torch.full((R,), -1, dtype=torch.int32)
+    idx = torch.randperm(R, generator=torch.Generator().manual_seed(5))
+    o = 0
+    for h, c in enumerate(counts):
+        head[idx[o:o + c]] = h
+        o += c
+    head = head.to(DEV)
+    Rp = ops.padded_rows(R, n_heads)
+    seg_start = torch.zeros(n_heads, dtype=torch.int32, device=DEV)
+    seg_count = torch.zeros_like(seg_start)
+    perm = torch.zeros(Rp, dtype=torch.int32, device=DEV)
+    r2p = torch.zeros(R, dtype=torch.int32, device=DEV)
+    tile_group = torch.zeros(Rp // ops.SEG, dtype=torch.int32, device=DEV)
+    ops.segment_rows(head, n_heads, seg_start, seg_count, perm, r2p, tile_group)
+    y = bf(randn(R, D, seed=112))
+    yp = torch.zeros(Rp, D, device=DEV, dtype=torch.bfloat16)
+    ops.gather_rows(y, perm, yp, D)
+    yp[perm < 0] = 0
+    ws = [bf(randn(v, D, seed=120 + i) * 0.3) for i, v in enumerate(vocabs)]
+    ldl = ops.ru(max(vocabs), 64)
+    want = torch.zeros(Rp, ldl, device=DEV, dtype=torch.bfloat16)
+    groups = ops.make_groups([dict(W=w, N=v, K=D, ldw=D) for w, v in zip(ws, vocabs)], DEV)
+    ops.gemm_nt_grouped(yp, groups, tile_group, want, max(vocabs), max_K=D)
+    got = torch.full((Rp, ldl), 7.0, device=DEV, dtype=torch.bfloat16)
+    assert ops.heads_dense_ok(ws, vocabs, got)
+    ops.gemm_nt_heads(yp, ws, vocabs, seg_start, seg_count, got, D)
+    covered = torch.zeros(Rp, ldl, dtype=torch.bool, device=DEV)
+    for h, (v, c) in enumerate(zip(vocabs, counts)):
+        s, n = int(seg_start[h]), ops.ru(c, ops.SEG)
+        covered[s:s + n, :v] = True
+        if c:
+            ref = y[torch.nonzero(head == h).flatten()].float() @ ws[h].float().t()
+            assert rel_err(got[s:s + c, :v], ref) < 4e-3
+            assert float((got[s:s + n, :v].float() - want[s:s + n, :v].float()).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+            assert float(got[s + c:s + n, :v].float().abs().max() if n > c else 0.0) == 0.0      # pad rows: zero inputs
+    assert bool((got[~covered] == 7.0).all())                                    # nothing written outside the heads' segments
+
+
 def test_gemm_grouped():
     ops, L = _ops()
     D = 128

@@ -54,7 +54,13 @@ def rep(name, t, fl=flops):
 rep("grouped NT logits (fwd)", timeit(lambda: ops.gemm_nt_grouped(yp, g_fwd, tile_group, logits, max(vocabs), max_K=D)))
 rep("grouped NT dY (bwd)", timeit(lambda: ops.gemm_nt_grouped(logits, g_bwd, tile_group, dyp, D, max_K=ldl)))
 rep("grouped TN dW heads", timeit(lambda: ops.gemm_tn_grouped(logits, yp, g_tn, seg_start, seg_count, nH, max(vocabs), Rp, D)))
+rep("dense per head, device-side rows (fwd)", timeit(lambda: ops.gemm_nt_heads(yp, ws, vocabs, seg_start, seg_count, logits, D)))
 # the same work as 7 dense launches (upper bound on what the grouped kernel could do)
+def dense_default():
+    for h in range(nH):
+        c = counts[h]
+        ops.gemm_nt(yp[:ops.ru(c, 256)], ws[h], logits[:ops.ru(c, 256)], N=vocabs[h], K=D, M=c)
+rep("7 dense NT launches, default dispatch (fwd)", timeit(dense_default))
 for cfg in (2, 6):
     L.lib.fm_set_gemm_nt_config(cfg)
     def dense():
