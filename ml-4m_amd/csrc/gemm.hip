@@ -1233,6 +1233,11 @@ int launch_nt(const NTArgs& a, int max_n, hipStream_t s) {
     if constexpr (GROUPED) {
         // rows are segmented in FM_SEG_ROWS (= 256 = the X tile) per group; a.K = upper bound of the groups' K
         static_assert(FM_SEG_ROWS == 256, "the grouped configurations use a 256-row X tile");
+        if constexpr (EPI == EPI_BF16) {      // lab (tools/heads_bench.py): 256 x 256 tiles for the dY GEMM of the heads
+            static const int heads_cfg_k = [] { const char* e = getenv("FOURM_HEADS_NT_CFG"); return e ? atoi(e) : 0; }();
+            if (a.K >= 1536 && heads_cfg_k == 3) return launch_nt_cfg<256, 256, 2, 4, 32, 3, EPI, true, true>(a, max_n, s);
+            if (a.K >= 1536 && heads_cfg_k == 4) return launch_nt_cfg<256, 256, 2, 4, 64, 2, EPI, true>(a, max_n, s);
+        }
         if (a.K >= 1536) return launch_nt_cfg<128, 256, 2, 4, 64, 3, EPI, true, true>(a, max_n, s);
         if constexpr (EPI == EPI_BF16) {      // lab (tools/heads_bench.py): 256 x 256 ping-pong tiles for the logits GEMM
             static const int heads_cfg = [] { const char* e = getenv("FOURM_HEADS_NT_CFG"); return e ? atoi(e) : 0; }();
