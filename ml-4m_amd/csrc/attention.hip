@@ -22,6 +22,15 @@
 #ifndef ATTN_V2_SCHED
 #define ATTN_V2_SCHED 0        // lab knob (tools/r05_attn_variants.sh builds the alternatives into separate libraries)
 #endif
+#ifndef ATTN_DOT2
+#define ATTN_DOT2 1            // lab knob: 0 = delta without v_dot2c_f32_bf16
+#endif
+#ifndef ATTN_KV_DMA
+#define ATTN_KV_DMA 1          // lab knob: 0 = K / V fragments of attn_bwd128_kernel loaded straight from global memory (32-byte requests)
+#endif
+#ifndef ATTN_STAGED_STORES
+#define ATTN_STAGED_STORES 1   // lab knob: 0 = dQ / dK / dV of attn_bwd128_kernel through store_bf16_groups (32-byte write requests)
+#endif
 
 namespace {
 
@@ -47,6 +56,7 @@ struct AttnArgs {
     int lddo, lddq, lddk, lddv;
     int kvr;                      // forward: rows between two samples in K / V (>= Nk: a K/V cache filled up to Nk)
     int zero_attn;                // softmax1: one extra zero logit in the denominator (allow_zero_attn)
+    int o16;                      // forward (attn_fwd128_kernel): the rows of O are 16-byte aligned - whole-line stores staged through LDS
     int chunk;                    // rows of the two LDS tiles of the backward (a multiple of 32; >= max(Nq, Nk) padded when one chunk does)
 };
 
@@ -96,6 +106,37 @@ __device__ __forceinline__ bool blocked_at(const AttnArgs& a, int b, int q, int 
     else return false;
 }
 constexpr float LOG2E = 1.4426950408889634f;
+// A wave's 32 rows x 64 bf16 (two 32 x 32 accumulators: register 4 g + j of t[df] = feature 32 df + 8 g + 4 fhi + j of row lane & 31) leave
+// as WHOLE 128-byte lines: through a wave-private 4 KB LDS area (16-byte chunks XOR-swizzled by the row) and back row-contiguous, 8 lanes
+// per row.  store_bf16_groups hands the L2 four 32-byte write requests per line; this form one - the request count, not the bytes, is what the
+// 150 MB of dQ / dK / dV of an attention backward cost (4.7 M of its 6.7 M L2 requests per launch at the bench shape).
+// row_scale multiplies the lane's row.  The rows must be 16-byte aligned (checked by the dispatch).
+__device__ __forceinline__ void store_rows_staged(const f32x16_t (&t)[2], float row_scale, char* stage, bf16_t* g_row0, int ld, int lane) {
+    const int r = lane & 31, fhi = lane >> 5;
+#pragma unroll
+    for (int df = 0; df < 2; ++df)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(uint2*)(stage + r * 128 + ((((df * 4 + g) ^ (r & 7))) << 4) + fhi * 8) =
+                make_uint2(pack2bf(t[df][4 * g] * row_scale, t[df][4 * g + 1] * row_scale), pack2bf(t[df][4 * g + 2] * row_scale, t[df][4 * g + 3] * row_scale));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + (lane >> 3), c = lane & 7;
+        const uint4 v = *(const uint4*)(stage + row * 128 + ((c ^ (row & 7)) << 4));
+        *(uint4*)((char*)(g_row0 + (size_t)row * ld) + c * 16) = v;
+    }
+}
+
+// acc + a.lo * b.lo + a.hi * b.hi on two packed bf16 pairs: ONE v_dot2c_f32_bf16 (products of bf16 are exact in fp32) instead of four unpacks
+// and two FMAs - delta = rowsum(dO o O) in the prologue of the backward kernels (~80 of a wave's ~960 VALU instructions before round 5's end)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16pair_t;
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+#if ATTN_DOT2
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair_t, a), __builtin_bit_cast(bf16pair_t, b), acc, false);
+#else       // lab (tools/r05_attn_variants.sh): the unpack + FMA form
+    return acc + (bf2f((bf16_t)(a & 0xffff)) * bf2f((bf16_t)(b & 0xffff)) + bf2f((bf16_t)(a >> 16)) * bf2f((bf16_t)(b >> 16)));
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward: grid (ceil(Nq/128), H, B), 4 waves x 32 queries, keys in tiles of 64 with online softmax
@@ -410,6 +451,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd128_kernel(AttnArgs a) {
         l_tot = l_tot * oscale + __builtin_amdgcn_exp2f(-m_fin);
     }
     const float inv = oscale / l_tot;
+#if ATTN_STAGED_STORES
+    if (a.o16) {        // (set by the dispatch: O rows 16-byte aligned) whole-line stores through the K tile: every wave is done with it behind the barrier
+        __syncthreads();
+        store_rows_staged(o, inv, Kt + wave * 4096, a.O + ((size_t)b * N + wave * 32) * a.ldo + h * HD, a.ldo, lane);
+    } else
+#endif
     {
         bf16_t* orow = a.O + ((size_t)b * N + q) * a.ldo + h * HD;
         const bool wide_o = (a.ldo & 7) == 0 && (((uintptr_t)a.O) & 15) == 0;
@@ -581,6 +628,12 @@ __global__ __launch_bounds__(256, DB ? 2 : 3) void attn_fwdt_kernel(AttnArgs a) 
         l_tot = l_tot * oscale + __builtin_amdgcn_exp2f(-m_fin);
     }
     const float inv = oscale / l_tot;
+#if ATTN_STAGED_STORES
+    if (a.o16) {        // whole-line stores through the (dead) K / V buffer, as in attn_fwd128_kernel
+        __syncthreads();
+        store_rows_staged(o, inv, tiles + wave * 4096, a.O + ((size_t)b * a.Nq + blockIdx.x * N + wave * 32) * a.ldo + h * HD, a.ldo, lane);
+    } else
+#endif
     {
         bf16_t* orow = a.O + ((size_t)b * a.Nq + q) * a.ldo + h * HD;
         const bool wide_o = (a.ldo & 7) == 0 && (((uintptr_t)a.O) & 15) == 0;
@@ -673,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnArgs a) {
                 const uint32_t* g32 = (const uint32_t*)&gv[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    dl += bf2f((bf16_t)(o32[e] & 0xffff)) * bf2f((bf16_t)(g32[e] & 0xffff)) + bf2f((bf16_t)(o32[e] >> 16)) * bf2f((bf16_t)(g32[e] >> 16));
+                    dl = dot2_bf16(o32[e], g32[e], dl);
             }
         }
         dl += __shfl_xor(dl, 1, 64);
@@ -1036,11 +1089,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
     stage_rows<4>(dOb, a.lddo, 0, N, N, T1, wave, lane);
     const int key = wave * 32 + (lane & 31);             // pass A: this lane's key
     bf16x8_t kf[4], vf[4];
+#if ATTN_KV_DMA
+    // K and V reach their registers through the (still unused) dS^T area: whole 128-byte lines by LDS-DMA instead of 32-byte pieces per row and
+    // instruction (the fragment loads were 1 024 of a workgroup's ~1 900 L2 requests)
+    stage_rows<4>(Kb, a.ldk, 0, N, N, dSl, wave, lane);
+    stage_rows<4>(Vb, a.ldv, 0, N, N, dSl + N * ROWB, wave, lane);
+#else
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         kf[kk] = *(const bf16x8_t*)(Kb + (size_t)key * a.ldk + (kk * 2 + fhi) * 8);
         vf[kk] = *(const bf16x8_t*)(Vb + (size_t)key * a.ldv + (kk * 2 + fhi) * 8);
     }
+#endif
     {   // per-query constants: two threads per query row (4 x 16-byte loads each from O and dO)
         const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
         const uint4* op = (const uint4*)(Ob + (size_t)q * a.ldo + half * 32);
@@ -1068,7 +1128,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
             const uint32_t* g32 = (const uint32_t*)&gv[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                dl += bf2f((bf16_t)(o32[e] & 0xffff)) * bf2f((bf16_t)(g32[e] & 0xffff)) + bf2f((bf16_t)(o32[e] >> 16)) * bf2f((bf16_t)(g32[e] >> 16));
+                dl = dot2_bf16(o32[e], g32[e], dl);
         }
         dl += __shfl_xor(dl, 1, 64);
         if (half == 0) {
@@ -1080,6 +1140,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
         }
     }
     __syncthreads();
+#if ATTN_KV_DMA
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = row_frag(dSl, key, kk, fhi);
+        vf[kk] = row_frag(dSl + N * ROWB, key, kk, fhi);
+    }
+    __syncthreads();                                     // every wave holds its K / V fragments: the area may take dS^T
+#endif
     if constexpr (MASK != FM_MASK_NONE) {
         // fully blocked rows (empty samples, decoder rows in front of the first visible token): P = 1 / l on every key, no gradient through
         // the scores.  Their Q row is zeroed here (no dK contribution; S is irrelevant, every score selects pb), their dQ row at the store.
@@ -1191,6 +1259,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);      // lab variant: no instruction crosses a q-block boundary
 #endif
     }
+#if !ATTN_STAGED_STORES
     {   // lanes l and l+32 own the same key row: 16-byte stores (store_bf16_groups), one output after the other
         const bool wide_k = (a.lddk & 7) == 0 && (((uintptr_t)a.dK) & 15) == 0;
         const bool wide_v = (a.lddv & 7) == 0 && (((uintptr_t)a.dV) & 15) == 0;
@@ -1212,10 +1281,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
                 }
     }
 
+#endif
     // ---- K takes the place of Q in LDS, from the registers that hold it ---------------------------
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) *(__attribute__((address_space(3))) bf16x8_t*)(L + rowo[kk] + oT0 + wave * 32 * ROWB) = kf[kk];
+#if ATTN_STAGED_STORES
+    // dK, dV: behind the barrier every wave is done with the dO tile - 4 KB of it per wave stage the outputs into whole-line stores
+    store_rows_staged(dKt, a.scale, T1 + wave * 4096, a.dK + ((size_t)b * N + wave * 32) * a.lddk + h * HD, a.lddk, lane);      // (dS left pass A without the softmax scale)
+    store_rows_staged(dVt, 1.0f, T1 + wave * 4096, a.dV + ((size_t)b * N + wave * 32) * a.lddv + h * HD, a.lddv, lane);
+#endif
     __syncthreads();
 
     // ---- pass B: dQ = dS K for this wave's 32 queries (dS^T read column-wise: queries = the MFMA's n index) ---
@@ -1243,6 +1318,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
             }
         float sc = a.scale;
         if constexpr (MASK != FM_MASK_NONE) sc = full_l[q] ? 0.f : sc;
+#if ATTN_STAGED_STORES
+        store_rows_staged(dQt, sc, T1 + wave * 4096, a.dQ + ((size_t)b * N + qb * 32) * a.lddq + h * HD, a.lddq, lane);
+        return;
+#endif
         const bool wide_q = (a.lddq & 7) == 0 && (((uintptr_t)a.dQ) & 15) == 0;
         bf16_t* dqrow = a.dQ + ((size_t)b * N + q) * a.lddq + h * HD;
 #pragma unroll
@@ -1331,7 +1410,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd128o_kernel(AttnArgs a) {
             const uint32_t* g32 = (const uint32_t*)&gv[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                dl += bf2f((bf16_t)(o32[e] & 0xffff)) * bf2f((bf16_t)(g32[e] & 0xffff)) + bf2f((bf16_t)(o32[e] >> 16)) * bf2f((bf16_t)(g32[e] >> 16));
+                dl = dot2_bf16(o32[e], g32[e], dl);
         }
         dl += __shfl_xor(dl, 1, 64);
         if (half == 0) {
@@ -1446,6 +1525,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd128o_kernel(AttnArgs a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) *(__attribute__((address_space(3))) u32x2_t*)(L + ((dswo ^ (g4 << 4)) + qb * RG)) = dsp[g4];
     }
+#if !ATTN_STAGED_STORES
     {
         const bool wide_k = (a.lddk & 7) == 0 && (((uintptr_t)a.dK) & 15) == 0;
         const bool wide_v = (a.lddv & 7) == 0 && (((uintptr_t)a.dV) & 15) == 0;
@@ -1466,6 +1546,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd128o_kernel(AttnArgs a) {
                     store_bf16_groups(which ? dvrow : dkrow, df * 32 + 8 * g, pk[0], pk[1], fhi, HD, which ? wide_v : wide_k);
                 }
     }
+#endif
     __syncthreads();                                     // the dS^T of the last q-block is in place
 
     // ---- pass B: dQ = dS K for this wave's 32 queries -----------------------------------------------
@@ -1490,6 +1571,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd128o_kernel(AttnArgs a) {
             }
         float sc = a.scale;
         if constexpr (MASK != FM_MASK_NONE) sc = full_l[q] ? 0.f : sc;
+#if ATTN_STAGED_STORES
+        // dK and dV stayed in registers through pass B (<= 168 registers still: three workgroups per CU): behind this barrier every wave is done
+        // with dS^T and K, and 4 KB of the K tile per wave stage all three outputs into whole-line stores
+        __syncthreads();
+        char* stg = smem + oK + wave * 4096;
+        store_rows_staged(dKt, a.scale, stg, a.dK + ((size_t)b * N + wave * 32) * a.lddk + h * HD, a.lddk, lane);
+        store_rows_staged(dVt, 1.0f, stg, a.dV + ((size_t)b * N + wave * 32) * a.lddv + h * HD, a.lddv, lane);
+        store_rows_staged(dQt, sc, stg, a.dQ + ((size_t)b * N + qb * 32) * a.lddq + h * HD, a.lddq, lane);
+        return;
+#endif
         const bool wide_q = (a.lddq & 7) == 0 && (((uintptr_t)a.dQ) & 15) == 0;
         bf16_t* dqrow = a.dQ + ((size_t)b * N + q) * a.lddq + h * HD;
 #pragma unroll
@@ -1550,6 +1641,7 @@ extern "C" int fm_attn_fwd(const fm_attn_args* p, void* stream) {
     if (v2_on && !t_for_128 && tr && a.Nq == 128 && a.Nk == 128 && a.mask_kind != FM_MASK_DENSE && a.scale > 0.f) {
         const size_t lds128 = (size_t)2 * 128 * ROWB + 128 * 4;
         const dim3 grid128(a.H, a.B);
+        a.o16 = ((a.ldo & 7) == 0 && (((uintptr_t)a.O) & 15) == 0) ? 1 : 0;
         switch (a.mask_kind) {
             case FM_MASK_NONE: hipLaunchKernelGGL((attn_fwd128_kernel<FM_MASK_NONE>), grid128, dim3(256), lds128, (hipStream_t)stream, a); break;
             case FM_MASK_KEYPAD: hipLaunchKernelGGL((attn_fwd128_kernel<FM_MASK_KEYPAD>), grid128, dim3(256), lds128, (hipStream_t)stream, a); break;
@@ -1566,6 +1658,7 @@ extern "C" int fm_attn_fwd(const fm_attn_args* p, void* stream) {
         static const bool t_db = [] { const char* e = getenv("FOURM_ATTN_FWD_DB"); return e && atoi(e) != 0; }();      // lab: two K/V buffers, two workgroups per CU
         const size_t ldst = (size_t)((t_db && a.Nk > 128) ? 2 : 1) * 2 * 128 * ROWB + (size_t)a.Nk * 4;
         const dim3 gridt(a.Nq / 128, a.H, a.B);
+        a.o16 = ((a.ldo & 7) == 0 && (((uintptr_t)a.O) & 15) == 0) ? 1 : 0;
 #define FWDT(MK)                                                                                                              \
     if (t_db) hipLaunchKernelGGL((attn_fwdt_kernel<MK, true>), gridt, dim3(256), ldst, (hipStream_t)stream, a);                \
     else hipLaunchKernelGGL((attn_fwdt_kernel<MK, false>), gridt, dim3(256), ldst, (hipStream_t)stream, a);
@@ -1616,7 +1709,8 @@ extern "C" int fm_attn_bwd(const fm_attn_args* p, void* stream) {
     const int tr = p->force_tr >= 0 ? p->force_tr : g_attn_tr;
     // 128 x 128 tokens exactly (the 128-token 4M configurations): the round-5 kernel; FOURM_ATTN_BWD_V2=0 keeps the general one
     static const bool v2_on = [] { const char* e = getenv("FOURM_ATTN_BWD_V2"); return !e || atoi(e) != 0; }();
-    if (v2_on && tr && a.Nq == 128 && a.Nk == 128 && a.mask_kind != FM_MASK_DENSE) {
+    const bool rows16 = ((a.lddq | a.lddk | a.lddv) & 7) == 0 && ((((uintptr_t)a.dQ) | ((uintptr_t)a.dK) | ((uintptr_t)a.dV)) & 15) == 0;      // whole-line staged stores
+    if (v2_on && tr && rows16 && a.Nq == 128 && a.Nk == 128 && a.mask_kind != FM_MASK_DENSE) {
         const size_t lds128 = (size_t)4 * 128 * ROWB + 6 * 128 * 4;
         // Which of the two 128 x 128 kernels (profiles/r05_attn_ov.txt, B = 256, H = 12): the 3-workgroups-per-CU overlay form wins where the
         // per-score VALU work is largest (decoder rule: 91.6 vs 106.6 us) and loses slightly elsewhere (key padding 95.4 vs 93.2, none 98.3 vs
