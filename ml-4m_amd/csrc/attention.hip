@@ -28,6 +28,9 @@
 #ifndef ATTN_KV_DMA
 #define ATTN_KV_DMA 1          // lab knob: 0 = K / V fragments of attn_bwd128_kernel loaded straight from global memory (32-byte requests)
 #endif
+#ifndef ATTN_DELTA_LDS
+#define ATTN_DELTA_LDS 1       // lab knob: 0 = delta of attn_bwd128_kernel from two-threads-per-row global loads of O and dO (16-byte requests)
+#endif
 #ifndef ATTN_STAGED_STORES
 #define ATTN_STAGED_STORES 1   // lab knob: 0 = dQ / dK / dV of attn_bwd128_kernel through store_bf16_groups (32-byte write requests)
 #endif
@@ -1101,13 +1104,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
         vf[kk] = *(const bf16x8_t*)(Vb + (size_t)key * a.ldv + (kk * 2 + fhi) * 8);
     }
 #endif
+#if ATTN_DELTA_LDS && ATTN_KV_DMA
+    // delta = rowsum(dO o O): O as whole lines (8 lanes per row, rows 32 i + (t >> 3)), dO from its LDS tile behind the barrier.  The two-threads-
+    // per-row form below asked the L2 for 16 bytes per lane and instruction, 64 bytes apart: 2 048 sixteen-byte requests per workgroup, more than
+    // everything else of the kernel together.
+    uint4 ovl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ovl[i] = *(const uint4*)(Ob + (size_t)(32 * i + (threadIdx.x >> 3)) * a.ldo + (threadIdx.x & 7) * 8);
+#endif
     {   // per-query constants: two threads per query row (4 x 16-byte loads each from O and dO)
         const int q = threadIdx.x >> 1, half = threadIdx.x & 1;
+#if !(ATTN_DELTA_LDS && ATTN_KV_DMA)
         const uint4* op = (const uint4*)(Ob + (size_t)q * a.ldo + half * 32);
         const uint4* gp = (const uint4*)(dOb + (size_t)q * a.lddo + half * 32);
         uint4 ov[4], gv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ov[i] = op[i]; gv[i] = gp[i]; }
+#endif
         const size_t si = ((size_t)b * a.H + h) * N + q;
         const float m = a.stat_m[si], l = a.stat_l[si];
         int csv = 255, lov = 0;
@@ -1121,6 +1134,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
             if constexpr (MASK == FM_MASK_DECODER) uk_l[k] = ((a.modk ? (int)a.modk[(size_t)b * N + k] : 0) << 9) + k;
             else if constexpr (MASK == FM_MASK_KEYPAD) uk_l[k] = a.kpad ? a.kpad[(size_t)b * N + k] != 0 : 0;
         }
+#if !(ATTN_DELTA_LDS && ATTN_KV_DMA)
         float dl = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1131,10 +1145,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
                 dl = dot2_bf16(o32[e], g32[e], dl);
         }
         dl += __shfl_xor(dl, 1, 64);
+#endif
         if (half == 0) {
             const bool full = MASK != FM_MASK_NONE && m < -1e38f;      // the forward kept NEG_FILL as the maximum: every key was blocked
             nm_l[q] = full ? 0.f : -(m + __log2f(l));
+#if !(ATTN_DELTA_LDS && ATTN_KV_DMA)
             dl_l[q] = dl;
+#endif
             pb_l[q] = full ? -__log2f(l) : -INFINITY;       // log2 of a blocked key's probability: exp2 -> 1 / l, or exactly 0
             wq_l[q] = lov + csv - 1; full_l[q] = full;
         }
@@ -1146,6 +1163,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
         kf[kk] = row_frag(dSl, key, kk, fhi);
         vf[kk] = row_frag(dSl + N * ROWB, key, kk, fhi);
     }
+#if ATTN_DELTA_LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 32 * i + (threadIdx.x >> 3), c = threadIdx.x & 7;
+        const uint4 gv = *(const uint4*)(T1 + row * ROWB + ((c ^ sw3(row)) << 4));
+        float d = dot2_bf16(ovl[i].x, gv.x, 0.f);
+        d = dot2_bf16(ovl[i].y, gv.y, d); d = dot2_bf16(ovl[i].z, gv.z, d); d = dot2_bf16(ovl[i].w, gv.w, d);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if (c == 0) dl_l[row] = d;
+    }
+#endif
     __syncthreads();                                     // every wave holds its K / V fragments: the area may take dS^T
 #endif
     if constexpr (MASK != FM_MASK_NONE) {
