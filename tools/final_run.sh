@@ -23,6 +23,8 @@ f=$(find gpurun_out/prof_final -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/${TAG}_kernel_stats.csv
 rm -rf gpurun_out/prof_final
 head -12 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-160
+# the lab binary is rebuilt against the current header (fm_gemm_nt_args grows with the ABI; a stale binary would pass a short struct)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -I include tools/gemm_lab.cpp -L ml-4m_amd/fourm/_lib -lfourm_hip -o tools/bin/gemm_lab 2>/dev/null
 { echo "# tools/gemm_lab nt 265,268,1001,1002,1003: round-2 automatic choice (265), round-2 256x256 ping-pong (268), gemm_nt3 256-wide / 192-wide / by shape (the default)";
   timeout 200 tools/bin/gemm_lab nt 265,268,1001,1002,1003;
   echo "# the same with experiment flags on gemm_nt3 (by shape): 10243 legacy epilogue (32-byte-per-row stores), 1013 no wait for the DMA, 1023 no main-loop DMA, 1043 no stores, 1063 no DMA + no stores";
