@@ -343,3 +343,18 @@ def test_context_norm_hoist_algebra():
             dWp = u.t() @ xh                                                                     # the ordinary weight-gradient GEMM, on x_hat
             assert torch.allclose(dWp * g[None, :], W.grad, rtol=1e-9, atol=1e-11)
             assert torch.allclose((dWp * W).sum(0), g.grad, rtol=1e-9, atol=1e-11)
+
+
+def test_every_environment_switch_is_documented():
+    """INTEGRATION.md section D lists every FOURM_* variable the package or bench.py reads (a switch that exists only in the source is a
+    behaviour nobody can look up)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    files = [f for f in glob.glob(os.path.join(root, "ml-4m_amd", "**", "*"), recursive=True) if f.endswith((".py", ".hip", ".cpp", ".h"))]
+    for f in files + [os.path.join(root, "bench.py")]:
+        with open(f, errors="ignore") as fh:
+            names |= set(re.findall(r'(?:getenv\(|environ\.get\(|environ\[)\s*"(FOURM_[A-Z0-9_]+)"', fh.read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert len(names) > 20 and not missing, missing
