@@ -265,7 +265,9 @@ class DeviceUnifiedMasking:
         overflow, exhausted = (int(v) for v in st.tolist())
         st.zero_()
         if exhausted:
-            print(f"[DeviceUnifiedMasking] {exhausted} samples exhausted their retries (upstream: 'More than max tries')", force=True)
+            # `force` is a keyword of the rank-aware print that fourm.utils.dist.setup_for_distributed installs; the stock print rejects it
+            kw = {"force": True} if hasattr(print, "_fourm_builtin") else {}
+            print(f"[DeviceUnifiedMasking] {exhausted} samples exhausted their retries (upstream: 'More than max tries')", **kw)
         if overflow and raise_on_overflow:
             raise KeyError(f"{overflow} samples needed more sentinel ids than the tokenizer provides (upstream raises KeyError in the masking transform)")
         return (overflow, exhausted)

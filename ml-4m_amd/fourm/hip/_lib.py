@@ -199,6 +199,8 @@ lib.fm_set_gemm_tn_config.argtypes = [C.c_int]
 lib.fm_set_attn_transpose_read.argtypes = [C.c_int]
 
 lib.fm_set_gemm_nt_config.argtypes = [C.c_int]
+lib.fm_lab_set.argtypes = [C.c_int, C.c_int]      # lab knobs (header, "lab" section)
+lib.fm_lab_set.restype = None
 vq_code_stats = _sig("fm_vq_code_stats", vp, i32, vp, i32, i32, i32, vp, vp, vp)
 vq_ema_update = _sig("fm_vq_ema_update", vp, vp, vp, vp, i32, i32, f32, vp)
 vq_code_bias = _sig("fm_vq_code_bias", vp, i32, i32, vp, vp)
@@ -239,7 +241,7 @@ EXPORTS = ["fm_split3_bf16", "fm_unet_im2col", "fm_groupnorm_nhwc", "fm_add_bf16
            "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_fold_colscale_grad", "fm_colsum", "fm_f32_to_bf16", "fm_adamw", "fm_adamw_shadow",
            "fm_sumsq", "fm_clip_coef", "fm_vq_patchify", "fm_l2norm_rows", "fm_vq_assign",
            "fm_sample_tokens", "fm_maskgit_commit", "fm_gemm_f32", "fm_attn_f32_fwd", "fm_attn_f32_bwd", "fm_layernorm_bwd_f32", "fm_headnorm_f32_fwd", "fm_headnorm_f32_bwd",
-           "fm_swiglu_bwd_f32", "fm_gelu_bwd_f32", "fm_colsum_f32", "fm_cross_entropy_f32"]
+           "fm_swiglu_bwd_f32", "fm_gelu_bwd_f32", "fm_colsum_f32", "fm_cross_entropy_f32", "fm_lab_set"]
 
 
 def check(rc: int):

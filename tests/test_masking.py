@@ -352,6 +352,29 @@ def test_device_unified_masking_contract():
     assert all(torch.equal(out2[k][f], out3[k][f]) for k in out2 for f in ("input_mask", "target_mask", "decoder_attention_mask"))
 
 
+def test_device_masking_check_reports_exhausted_retries_with_the_stock_print(capsys):
+    """check(): the 'exhausted retries' warning must print under the stock print() (no ``force`` keyword: that only exists once
+    fourm.utils.dist.setup_for_distributed has installed the rank-aware print) and under the rank-aware one on a silent rank."""
+    import builtins
+    from fourm.data.masking import DeviceUnifiedMasking
+    from fourm.utils import dist as fdist
+    um = DeviceUnifiedMasking.__new__(DeviceUnifiedMasking)
+    assert um.check() == (0, 0)
+    um._tries_stat = torch.tensor([0, 3], dtype=torch.int64)
+    assert um.check() == (0, 3) and "3 samples exhausted" in capsys.readouterr().out
+    assert um._tries_stat.tolist() == [0, 0]
+    stock = builtins.print
+    try:
+        fdist.setup_for_distributed(False)                    # a non-master rank: print is silent unless forced
+        um._tries_stat = torch.tensor([0, 2], dtype=torch.int64)
+        assert um.check() == (0, 2) and "2 samples exhausted" in capsys.readouterr().out
+    finally:
+        builtins.print = stock
+    um._tries_stat = torch.tensor([1, 0], dtype=torch.int64)
+    with pytest.raises(KeyError):
+        um.check()
+
+
 @pytest.mark.gpu
 def test_device_masking_feeds_the_model():
     """The loader contract end to end: DeviceUnifiedMasking's batched output is what FourM.forward consumes - loss and
