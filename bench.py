@@ -123,7 +123,7 @@ class LaunchProfiler:
 
 
 KERNEL_REGEX = {   # profiler family -> regex on the demangled kernel name (7th template argument of gemm_nt = epilogue)
-    "gemm_nt": r"(gemm_nt3_kernel<\d+, {epi}, |gemm_nt_kernel<\d+, \d+, \d+, \d+, \d+, \d+, {epi}, false)",
+    "gemm_nt": r"(gemm_nt3_kernel<\d+, {epi}, |gemm_nt_kernel<\d+, \d+, \d+, \d+, \d+, \d+, {epi}, false|gemm_nt4_kernel<\d+, \d+, \d+, \d+, (true|false)>{nt4})",
     "gemm_tn": r"gemm_tn_kernel<\w+, false", "gemm_tn_multi": r"gemm_tn_multi_kernel", "attn_fwd": r"attn_fwd\w*_kernel", "attn_bwd": r"attn_bwd\w*_kernel",
     "layernorm_fwd": r"ln_fwd_kernel", "layernorm_bwd": r"ln_bwd_kernel",
 }
@@ -467,7 +467,7 @@ def main_vq(a):
         fam, _, epi = name.partition("/epi")
         traffic, detail = (None, None)
         if world == 1 and not a.no_traffic and fam in KERNEL_REGEX:
-            traffic, detail = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0"), worker_args=["--workload", "vq", "--batch", str(batch)])
+            traffic, detail = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0", nt4="" if (epi or "0") == "0" else "NEVER"), worker_args=["--workload", "vq", "--batch", str(batch)])
         # the fp32 tail (tanh post-MLP, upstream disables autocast there) runs on v_mfma_f32_32x32x2_f32: exact fp32 at 1/16 of the bf16
         # rate - its launches are priced against the fp32 matrix peak of MI355X_MICROARCH.md, every other kernel against the bf16 peak
         f32_kernel = name.startswith("gemm_f32")
@@ -677,8 +677,9 @@ def main():
     if rank == 0 and not a.no_kernel_profile:
         agg = prof.summary()
         tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
-        symbol = {"gemm_nt": "FAMILY of two template instantiations, gemm_nt3_kernel<TW=192|256, EPI={epi}, SPLIT=true, STG=true>  (csrc/gemm_nt3.hip: lock-step "
-                             "256 x 256 / 192 x 256 tiles, tile width by rounds x width on the CUs in use, outputs staged through LDS into whole-line stores) - "
+        symbol = {"gemm_nt": "FAMILY of template instantiations: gemm_nt4_kernel<TW=384, TX=256, 2, 2, STG=true> (csrc/gemm_nt4.hip, round 6: 4 waves x 512 registers, "
+                             "256 x 384 tiles, accumulators in hand-named AGPRs) where N % 384 == 0 (N = 768, 1536, 2304), gemm_nt3_kernel<TW=192|256, EPI={epi}, SPLIT=true, "
+                             "STG=true> (csrc/gemm_nt3.hip: 8 waves, lock-step 256 x 256 / 192 x 256 tiles) elsewhere; outputs staged through LDS into whole-line stores - "
                              "every dense bf16 Linear of the trunk, forward and dX",
                   "gemm_tn": "gemm_tn_kernel<true,false,128,256,2,4,64,3,PP=true>  (csrc/gemm.hip)",
                   "gemm_tn_multi": "gemm_tn_multi_kernel<MASKED=false>  (csrc/gemm.hip; all dW GEMMs of a layer per launch)",
@@ -691,7 +692,7 @@ def main():
                   "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
         if world == 1 and not a.no_traffic and fam in KERNEL_REGEX:
             same_job = ["--mods", a.mods, "--model", a.model, "--batch", str(a.batch), "--n-in", str(a.n_in), "--n-out", str(a.n_out)]
-            common["traffic"], common["traffic_detail"] = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0"), worker_args=same_job)
+            common["traffic"], common["traffic_detail"] = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0", nt4="" if (epi or "0") == "0" else "NEVER"), worker_args=same_job)
         if d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS, **common}

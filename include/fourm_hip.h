@@ -569,7 +569,7 @@ int fm_diffusion_step(const void* x0, const void* quantile, float sample_max_val
                       const void* noise, float k0, float k1, float k2, float k3, void* out, void* x0_out, int B, int64_t per_sample, void* stream);
 
 /* ---- lab (not part of the drop-in surface) ------------------------------------------------------------------------------------------
- * Experiment knobs of the GEMM kernels, used by tools/gemm_lab.cpp, tools/*.py and the FOURM_NT3_LAB environment switch only: key 0 / 1
+ * Experiment knobs of the GEMM kernels, used by tools/gemm_lab.cpp, the Python tools and the FOURM_NT3_LAB environment switch only: key 0 / 1
  * staggered workgroup start (groups, step), 2 gemm_nt3 mode override, 3 gemm_nt3 ablation flags (gemm_args.h NTArgs::lab), others reserved.
  * Process-global, not thread-safe, no effect on results except where an ablation flag says so.  Keys outside [0, 16) are ignored. */
 void fm_lab_set(int key, int value);

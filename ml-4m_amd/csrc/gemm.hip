@@ -1165,7 +1165,8 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
 int g_nt_config = 9, g_nt_prio = 1;
 // experiment knobs (tools/gemm_lab via fm_lab_set): [0] de-phase groups, [1] de-phase step (x 2048 cycles), [2] gemm_nt3 mode (0 off,
 // 1 = 256-wide tiles, 2 = 192-wide, 3 = by shape: the default; FOURM_NT3=0 turns it off), [3] gemm_nt3 experiment flags
-int g_lab[16] = {0, 0, [] { const char* e = getenv("FOURM_NT3"); return e ? atoi(e) : 3; }(), [] { const char* e = getenv("FOURM_NT3_LAB"); return e ? atoi(e) : 0; }()};
+int g_lab[16] = {0, 0, [] { const char* e = getenv("FOURM_NT3"); return e ? atoi(e) : 3; }(), [] { const char* e = getenv("FOURM_NT3_LAB"); return e ? atoi(e) : 0; }(),
+                 [] { const char* e = getenv("FOURM_NT4"); return e ? atoi(e) : 1; }()};      // [4] gemm_nt4 mode (gemm_nt4.hip; FOURM_NT4=0 turns it off)
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
@@ -1310,6 +1311,11 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
     if (!grouped && p->M <= 32) {             // a handful of rows (a decoding step): the weight-streaming kernel of gemm_skinny.hip
         const int r = fm_launch_nt_skinny(a, p->epilogue, s);
         if (r < 0) { fm_set_error("fm_gemm_nt (skinny): launch failed"); return -2; }
+        if (r > 0) return 0;
+    }
+    if (!grouped && g_lab[4]) {               // the 4-wave 256 x 384-tile kernel (gemm_nt4.hip) takes the plain bf16 launches it tiles exactly
+        const int r = fm_launch_nt4(a, p->epilogue, g_lab[4], s);
+        if (r < 0) { fm_set_error("fm_gemm_nt (nt4): launch failed"); return -2; }
         if (r > 0) return 0;
     }
     if (!grouped && g_lab[2]) {               // the lock-step large-tile kernel (gemm_nt3.hip) takes the dense launches it handles

@@ -33,6 +33,8 @@ __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_r
 int fm_launch_nt_flat(const fmk::NTArgs& a, int epilogue, hipStream_t s);
 // gemm_nt3.hip: the lock-step large-tile kernel (same return convention; mode 1 = 256-wide tiles, 2 = 192-wide, 3 = by shape)
 int fm_launch_nt3(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s);
+// gemm_nt4.hip: the 4-wave / 512-register kernel on 256 x 384 tiles (same return convention; mode bits: see the file)
+int fm_launch_nt4(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s);
 // gemm_skinny.hip: M <= 32 rows (decoding steps): one workgroup per 32 output features, the 4 waves split K (same return convention)
 int fm_launch_nt_skinny(const fmk::NTArgs& a, int epilogue, hipStream_t s);
 // compute units the persistent GEMM grids may occupy (all of them minus fm_set_reserved_cus, a multiple of 8)

@@ -154,6 +154,36 @@ def test_gemm_nt_flat_swiglu_bit_identical(M, H, K, save):
         L.lib.fm_set_gemm_nt_config(NT_TILED)
 
 
+@pytest.mark.parametrize("M,N,K", [(32768, 768, 768), (4096, 2304, 768), (2048, 1536, 1024), (8192, 768, 4096), (2304, 384, 192), (6144, 768, 2048)])
+@pytest.mark.parametrize("mode", [1, 5])
+def test_gemm_nt4_bit_identical(M, N, K, mode):
+    """The 4-wave 256 x 384-tile kernel (gemm_nt4.hip: 16 accumulator fragments in hand-named AGPRs, staged whole-line epilogue through the stage
+    buffer a tile's last barrier freed; mode 5 = unstaged stores) accumulates in gemm_nt3's order: bit-identical outputs, run after run, and right
+    against fp32.  One / several tiles per workgroup, K from 3 K-tiles up."""
+    ops, L = _ops()
+    x = bf(randn(M, K, seed=31) * 0.7 + torch.arange(K, device=DEV)[None] * 0.001)
+    w = bf(randn(N, K, seed=32) * 0.05 + torch.arange(N, device=DEV)[:, None] * 0.0001)
+    try:
+        L.lib.fm_lab_set(4, 0)
+        ref = torch.full((M, N), 5.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(x, w, ref)
+        rows = torch.randperm(M, device=DEV)[:512]
+        assert rel_err(ref[rows], x[rows].float() @ w.float().t()) < 4e-3
+        L.lib.fm_lab_set(4, mode)
+        for rep in range(6):
+            out = torch.full((M, N), -3.0, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_nt(x, w, out)
+            assert torch.equal(out, ref), (rep, int((out != ref).sum()))
+        # a column view of a wider buffer (ldo > N) and row-strided operands (ldx, ldw > K): what the engine passes for q / k / v slices
+        xs = torch.zeros(M, K + 64, device=DEV, dtype=torch.bfloat16); xs[:, :K] = x
+        ws = torch.zeros(N, K + 128, device=DEV, dtype=torch.bfloat16); ws[:, :K] = w
+        big = torch.full((M, N + 256), 9.0, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_nt(xs[:, :K], ws[:, :K], big[:, 128:128 + N], K=K)
+        assert torch.equal(big[:, 128:128 + N], ref) and bool((big[:, :128] == 9.0).all()) and bool((big[:, 128 + N:] == 9.0).all())
+    finally:
+        L.lib.fm_lab_set(4, 1)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 260, 192), (1024, 768, 768), (70, 2304, 768)])
 def test_gemm_nt_plain(M, N, K):
     ops, L = _ops()

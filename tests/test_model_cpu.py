@@ -134,6 +134,21 @@ def test_c_abi_exports_every_declared_symbol():
     assert ctypes.sizeof(_lib.GemmGroup) == 32 and ctypes.sizeof(_lib.ModDesc) % 8 == 0
 
 
+def test_gemm_nt4_keeps_the_agpr_file_to_itself(tmp_path):
+    """gemm_nt4.hip names 256 accumulator registers (the AGPR file) in asm text the compiler cannot see into.  Sound only while the compiler
+    itself never uses an AGPR in those kernels (it would, as spill space, once the VGPR file fills): tools/check_nt4_asm.py compiles the file to
+    assembly and checks every gemm_nt4 kernel - no AGPR reference outside the asm statements, nothing in scratch."""
+    import shutil
+    import sys
+    if not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_nt4_asm
+    kernels, problems = check_nt4_asm.check(check_nt4_asm.compile_to_asm(str(tmp_path)))
+    assert not problems, problems[:5]
+    assert len(kernels) >= 2 and all(k["mfma"] > 100 and k["asm_agpr"] > 100 for k in kernels.values()), kernels
+
+
 def test_ctypes_mirrors_match_the_header_layout(tmp_path):
     """Every struct of include/fourm_hip.h: sizeof and the offset of every field, as gcc lays them out, against the
     ctypes mirrors the Python side passes to libfourm_hip.so (a silent mismatch would corrupt arguments)."""

@@ -34,8 +34,9 @@ template <typename F> static double time_us(F fn, int iters = 20, int warm = 3) 
 }
 
 struct NTCase { const char* name; int N, K, epi; };
+// configurations >= 2000: gemm_nt4.hip in mode (cfg - 2000) % 10 where it applies (nt3 by shape elsewhere), lab flags (cfg - 2000) / 10
 // configurations >= 1000: the lock-step large-tile kernel (gemm_nt3.hip) in mode cfg - 1000 over the default choice
-static void set_cfg(int cfg) { if (cfg >= 1000) { fm_lab_set(2, (cfg - 1000) % 10); fm_lab_set(3, (cfg - 1000) / 10); fm_set_gemm_nt_config(9); } else { fm_lab_set(2, 0); fm_set_gemm_nt_config(cfg); } }
+static void set_cfg(int cfg) { fm_lab_set(4, 0); if (cfg >= 2000) { fm_lab_set(4, (cfg - 2000) % 10); fm_lab_set(2, 3); fm_lab_set(3, (cfg - 2000) / 10); fm_set_gemm_nt_config(9); } else if (cfg >= 1000) { fm_lab_set(2, (cfg - 1000) % 10); fm_lab_set(3, (cfg - 1000) / 10); fm_set_gemm_nt_config(9); } else { fm_lab_set(2, 0); fm_set_gemm_nt_config(cfg); } }
 
 // the clocks of an idle box ramp up over hundreds of milliseconds: spin a GEMM before the first timing
 static void warm_gpu(int ms_target) {
