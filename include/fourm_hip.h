@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FM_ABI_VERSION 7
+#define FM_ABI_VERSION 8
 int fm_abi_version(void);
 const char* fm_last_error(void);
 
@@ -132,6 +132,13 @@ int fm_layernorm_fwd_res(const void* x, int ldx, const void* delta, int ldd, voi
 int fm_layernorm_bwd(const void* dy, int lddy, const int32_t* dy_row_map, const void* x, int ldx, const void* w,
                      const void* mean, const void* rstd, const void* dres, void* dx, int lddx, void* dx_bf16,
                      int lddxbf, void* dw, void* db, int R, int D, void* stream);
+/* The same for a bias-free norm whose bf16 output h = bf16(xhat * w) (R, D; what fm_layernorm_fwd wrote, kept for the weight-gradient
+ * GEMM of the Linear it feeds) is still in memory: xhat = h / w is rebuilt from the 2-byte h instead of the 4-byte x (14 instead of
+ * 16 bytes per element; xhat carries h's bf16 rounding, relative 2^-9).  x is read only for 4-column chunks holding a weight of
+ * magnitude < 1e-20.  No row map, no bias gradient. */
+int fm_layernorm_bwd_h(const void* dy, int lddy, const void* h, int ldh, const void* x, int ldx, const void* w,
+                       const void* mean, const void* rstd, const void* dres, void* dx, int lddx, void* dx_bf16,
+                       int lddxbf, void* dw, int R, int D, void* stream);
 
 /* Per-head LayerNorm of q / k for qk_norm models (NormAttention / NormCrossAttention q_norm, k_norm:
  * fourm/models/fm_utils.py:235-236,244-245,279-280,290-291).  x, y: bf16 rows of H heads x 64 contiguous features

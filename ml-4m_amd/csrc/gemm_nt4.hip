@@ -135,6 +135,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt4_kernel(NTArgs a) {
         // out of the K loop and keeps them in registers the main loop needs (the 256 x 384 tile leaves 128 VGPRs for everything else)
         int lane = lane_k, frow = lane & 31, fhi = lane >> 5;
         asm volatile("" : "+v"(lane), "+v"(frow), "+v"(fhi));
+        const uint32_t oob = (a.lab & 8) ? 0x80000000u : 0u;             // lab: every store dropped by the bounds check (its instruction is still issued)
         const __amdgpu_buffer_rsrc_t rs_out = rsrc_of((const char*)a.out + (size_t)m0 * a.ldo * 2);
         if constexpr (STG) {
             // a wave's 32 rows x (TW / WW) features go through a wave-private 4 KB of the free W region (8-byte swizzled writes in the
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt4_kernel(NTArgs a) {
                     for (int q = 0; q < 4; ++q) {
                         const int rl = wx * (TX / WX) + j * 32 + q * 8 + (lane >> 3);
                         const int c = n0 + ww * (TW / WW) + rnd * 64 + (lane & 7) * 8;
-                        __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out, (uint32_t)(rl * a.ldo) * 2u + (uint32_t)c * 2u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out, oob | ((uint32_t)(rl * a.ldo) * 2u + (uint32_t)c * 2u), 0, 0);
                     }
                 });
             });
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt4_kernel(NTArgs a) {
                     const auto y = __builtin_amdgcn_permlane32_swap(p0.y, p1.y, false, false);
                     const u32x4_t v = {x[0], y[0], x[1], y[1]};
                     const int c = c0 + i * 32 + 16 * gp;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, rowoff + (uint32_t)c * 2u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, oob | (rowoff + (uint32_t)c * 2u), 0, 0);
                 });
             });
         }

@@ -117,8 +117,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ;  dw += sum_r dy * xhat ;  db += sum_r dy
 constexpr int BWD_ROWS = 32;   // rows per workgroup (4 waves x 8)
 
-template <int MAXC>
+// FROM_H (bias-free norms whose bf16 output h = bf16(xhat * w) was saved for the weight-gradient GEMM anyway): xhat = h / w is rebuilt
+// from the 2-byte h instead of the 4-byte x (16 -> 14 bytes per element of this HBM-bound kernel; relative error of xhat 2^-9, the
+// rounding h already carries into the GEMMs).  Chunks holding a weight of magnitude < 1e-20 (h = 0 there: xhat is not recoverable)
+// read x as before.
+template <int MAXC, bool FROM_H = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const int* __restrict__ dy_row_map,
+                                                     const bf16_t* __restrict__ h, int ldh,
                                                      const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* dres, float* dx, int lddx, bf16_t* __restrict__ dx_bf, int lddxbf,
@@ -127,19 +132,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     float* red = (float*)smem;   // [2][4 waves][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
-    float4 aw[MAXC], ab[MAXC], wv[MAXC];
+    float4 aw[MAXC], ab[MAXC], wv[MAXC], iw[FROM_H ? MAXC : 1];
+    bool from_x[FROM_H ? MAXC : 1];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         aw[c] = ab[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int ch = lane + 64 * c;
         wv[c] = ch < nch ? *(const float4*)(w + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (FROM_H) {
+            from_x[c] = fminf(fminf(fabsf(wv[c].x), fabsf(wv[c].y)), fminf(fabsf(wv[c].z), fabsf(wv[c].w))) < 1e-20f;
+            iw[c] = from_x[c] ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(1.f / wv[c].x, 1.f / wv[c].y, 1.f / wv[c].z, 1.f / wv[c].w);
+        }
     }
     const int r_end = min(R, (int)(blockIdx.x + 1) * BWD_ROWS);
     // Two rows per iteration, every load of both rows (dy, x, residual gradient) issued before any arithmetic:
     // the kernel is a pure HBM stream and a wave otherwise waits out one memory round trip per row.
     constexpr int NR = 2;
     for (int r0 = blockIdx.x * BWD_ROWS + wave; r0 < r_end; r0 += 4 * NR) {
-        uint2 dyp[NR][MAXC];
+        uint2 dyp[NR][MAXC], hp[NR][FROM_H ? MAXC : 1];
         float4 xv[NR][MAXC], rv[NR][MAXC];
         float mu[NR], rs[NR];
         bool live[NR];
@@ -157,7 +167,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 xv[q][c] = rv[q][c] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ch < nch && live[q]) {
                     if (src >= 0) dyp[q][c] = *(const uint2*)(dy + (size_t)src * lddy + ch * 4);
-                    xv[q][c] = *(const float4*)(x + (size_t)rr * ldx + ch * 4);
+                    if constexpr (FROM_H) {
+                        hp[q][c] = *(const uint2*)(h + (size_t)rr * ldh + ch * 4);
+                        if (from_x[c]) xv[q][c] = *(const float4*)(x + (size_t)rr * ldx + ch * 4);
+                    } else xv[q][c] = *(const float4*)(x + (size_t)rr * ldx + ch * 4);
                     if (dres) rv[q][c] = *(const float4*)(dres + (size_t)rr * lddx + ch * 4);
                 }
             }
@@ -177,6 +190,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     const float4 d = make_float4(bf2f((bf16_t)(p.x & 0xffff)), bf2f((bf16_t)(p.x >> 16)), bf2f((bf16_t)(p.y & 0xffff)), bf2f((bf16_t)(p.y >> 16)));
                     const float4 v = xv[q][c];
                     xh[c] = make_float4((v.x - mu[q]) * rs[q], (v.y - mu[q]) * rs[q], (v.z - mu[q]) * rs[q], (v.w - mu[q]) * rs[q]);
+                    if constexpr (FROM_H) {
+                        const uint2 hh = hp[q][c];
+                        if (!from_x[c]) xh[c] = make_float4(bf2f((bf16_t)(hh.x & 0xffff)) * iw[c].x, bf2f((bf16_t)(hh.x >> 16)) * iw[c].y,
+                                                            bf2f((bf16_t)(hh.y & 0xffff)) * iw[c].z, bf2f((bf16_t)(hh.y >> 16)) * iw[c].w);
+                    }
                     aw[c].x += d.x * xh[c].x; aw[c].y += d.y * xh[c].y; aw[c].z += d.z * xh[c].z; aw[c].w += d.w * xh[c].w;
                     ab[c].x += d.x; ab[c].y += d.y; ab[c].z += d.z; ab[c].w += d.w;
                     g[c] = make_float4(d.x * wv[c].x, d.y * wv[c].y, d.z * wv[c].z, d.w * wv[c].w);
@@ -349,23 +367,25 @@ extern "C" int fm_layernorm_fwd_res(const void* x, int ldx, const void* delta, i
     return 0;
 }
 
-extern "C" int fm_layernorm_bwd(const void* dy, int lddy, const int32_t* dy_row_map, const void* x, int ldx, const void* w,
+static int layernorm_bwd_launch(const void* dy, int lddy, const int32_t* dy_row_map, const void* h, int ldh, const void* x, int ldx, const void* w,
                                 const void* mean, const void* rstd, const void* dres, void* dx, int lddx, void* dx_bf16,
                                 int lddxbf, void* dw, void* db, int R, int D, void* stream) {
     FM_CHECK_ARG(dy && x && w && mean && rstd && dx, "fm_layernorm_bwd: null pointer");
+    FM_CHECK_ARG(!h || ldh % 4 == 0, "fm_layernorm_bwd_h: ldh must be a multiple of 4");
     FM_CHECK_ARG(R > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC_LIMIT, "fm_layernorm_bwd: D=%d unsupported", D);
     FM_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddxbf % 4 == 0, "fm_layernorm_bwd: leading dims must be multiples of 4");
     const int grid = (R + BWD_ROWS - 1) / BWD_ROWS;
     const size_t lds = (size_t)8 * D * sizeof(float);
-#define LN_BWD(C)                                                                                                           \
+#define LN_BWD_(C, FH)                                                                                                      \
     {                                                                                                                       \
-        auto k = ln_bwd_kernel<C>;                                                                                          \
+        auto k = ln_bwd_kernel<C, FH>;                                                                                      \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4) == hipSuccess); \
         (void)once;                                                                                                         \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, lddy, dy_row_map, (const float*)x, ldx, \
-                           (const float*)w, (const float*)mean, (const float*)rstd, (const float*)dres, (float*)dx, lddx,   \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, lddy, dy_row_map, (const bf16_t*)h, ldh, \
+                           (const float*)x, ldx, (const float*)w, (const float*)mean, (const float*)rstd, (const float*)dres, (float*)dx, lddx, \
                            (bf16_t*)dx_bf16, lddxbf, (float*)dw, (float*)db, R, D);                                         \
     }
+#define LN_BWD(C) { if (h) LN_BWD_(C, true) else LN_BWD_(C, false) }
     switch (chunks_for(D)) {
         case 2: LN_BWD(2) break;
         case 3: LN_BWD(3) break;
@@ -373,8 +393,22 @@ extern "C" int fm_layernorm_bwd(const void* dy, int lddy, const int32_t* dy_row_
         default: LN_BWD(8) break;
     }
 #undef LN_BWD
+#undef LN_BWD_
     FM_CHECK_LAUNCH("fm_layernorm_bwd");
     return 0;
+}
+
+extern "C" int fm_layernorm_bwd(const void* dy, int lddy, const int32_t* dy_row_map, const void* x, int ldx, const void* w,
+                                const void* mean, const void* rstd, const void* dres, void* dx, int lddx, void* dx_bf16,
+                                int lddxbf, void* dw, void* db, int R, int D, void* stream) {
+    return layernorm_bwd_launch(dy, lddy, dy_row_map, nullptr, 0, x, ldx, w, mean, rstd, dres, dx, lddx, dx_bf16, lddxbf, dw, db, R, D, stream);
+}
+
+extern "C" int fm_layernorm_bwd_h(const void* dy, int lddy, const void* h, int ldh, const void* x, int ldx, const void* w,
+                                  const void* mean, const void* rstd, const void* dres, void* dx, int lddx, void* dx_bf16,
+                                  int lddxbf, void* dw, int R, int D, void* stream) {
+    FM_CHECK_ARG(h, "fm_layernorm_bwd_h: null pointer");
+    return layernorm_bwd_launch(dy, lddy, nullptr, h, ldh, x, ldx, w, mean, rstd, dres, dx, lddx, dx_bf16, lddxbf, dw, nullptr, R, D, stream);
 }
 
 extern "C" int fm_headnorm_fwd(const void* x, int ldx, const void* w, const void* b, void* y, int ldy, void* stats, int R, int H, float eps,

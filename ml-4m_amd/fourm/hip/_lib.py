@@ -27,7 +27,7 @@ def _load():
 lib = _load()
 lib.fm_last_error.restype = C.c_char_p
 lib.fm_abi_version.restype = C.c_int
-ABI_VERSION = 7
+ABI_VERSION = 8
 if lib.fm_abi_version() != ABI_VERSION:
     raise FourmHipUnavailable(f"libfourm_hip.so ABI {lib.fm_abi_version()} != expected {ABI_VERSION}; rebuild")
 
@@ -151,6 +151,7 @@ gemm_tn_multi = _sig("fm_gemm_tn_multi", P(GemmTNJob), C.c_int, vp)
 layernorm_fwd = _sig("fm_layernorm_fwd", vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, f32, vp)
 layernorm_fwd_res = _sig("fm_layernorm_fwd_res", vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, f32, vp)
 layernorm_bwd = _sig("fm_layernorm_bwd", vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, i32, vp)
+layernorm_bwd_h = _sig("fm_layernorm_bwd_h", vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, i32, i32, vp)
 attn_fwd = _sig("fm_attn_fwd", P(AttnArgs), vp)
 attn_bwd = _sig("fm_attn_bwd", P(AttnArgs), vp)
 select_embed = _sig("fm_select_embed", P(SelectDesc), vp)
@@ -235,7 +236,7 @@ quantile_abs = _sig("fm_quantile_abs", vp, i32, i64, f32, vp, vp)
 diffusion_step = _sig("fm_diffusion_step", vp, vp, f32, f32, vp, vp, vp, f32, f32, f32, f32, vp, vp, i32, i64, vp)
 EXPORTS = ["fm_split3_bf16", "fm_unet_im2col", "fm_groupnorm_nhwc", "fm_add_bf16", "fm_silu_f32_to_bf16", "fm_timestep_embedding", "fm_unet_attention", "fm_diffusion_x0", "fm_quantile_abs",
            "fm_diffusion_step", "fm_unpack_image_u8", "fm_unpack_ids_u16", "fm_unpack_mask_bits", "fm_decoder_attention_from_target", "fm_guidance_combine", "fm_image_mask", "fm_token_budgets", "fm_span_mask", "fm_vq_code_stats", "fm_vq_ema_update", "fm_vq_code_bias", "fm_vq_assign_bias", "fm_vq_code_stats_raw", "fm_vq_ema_update_euclid", "fm_vq_unpatchify", "fm_vq_latent_grad", "fm_tanh_bwd_f32", "fm_embed_rows_f32", "fm_vq_patchify_ex", "fm_vq_cls_emb_bwd", "fm_vq_latent_grad_normalized", "fm_abi_version", "fm_last_error", "fm_gemm_nt", "fm_set_gemm_nt_config", "fm_get_gemm_nt_config", "fm_set_reserved_cus", "fm_get_reserved_cus", "fm_bf16_to_f32_scaled", "fm_add_bf16_f32", "fm_scale_rows_bf16", "fm_gemm_tn", "fm_gemm_tn_multi", "fm_set_gemm_tn_config", "fm_get_gemm_tn_config", "fm_set_tn_transpose_read",
-           "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_fwd_res", "fm_layernorm_bwd", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
+           "fm_get_tn_transpose_read", "fm_layernorm_fwd", "fm_layernorm_fwd_res", "fm_layernorm_bwd", "fm_layernorm_bwd_h", "fm_headnorm_fwd", "fm_headnorm_bwd", "fm_attn_fwd", "fm_attn_bwd",
            "fm_set_attn_transpose_read", "fm_get_attn_transpose_read", "fm_select_embed", "fm_embed_bwd",
            "fm_dense_decoder_mask", "fm_segment_rows", "fm_gather_rows", "fm_cross_entropy", "fm_swiglu_bwd",
            "fm_gelu_bwd", "fm_cast_pad", "fm_transpose_cast_pad", "fm_shadow_refresh", "fm_fold_colscale_grad", "fm_colsum", "fm_f32_to_bf16", "fm_adamw", "fm_adamw_shadow",

@@ -44,6 +44,10 @@ DEFER_RESIDUAL = os.environ.get("FOURM_DEFER_RESIDUAL", "1") == "1"
 # once (FourMEngine.hoist_ctx).  Only the bf16 rounding point moves: bf16(x_hat gamma) bf16(W) -> bf16(x_hat) bf16(W gamma).
 # FOURM_HOIST_CTX=0: one LayerNorm forward / backward per decoder block, as upstream computes it.
 HOIST_CTX = os.environ.get("FOURM_HOIST_CTX", "1") == "1"
+# LayerNorm backward of bias-free norms: x_hat = h / gamma from the saved bf16 norm output h (kept for the dW GEMM of the Linear it feeds)
+# instead of (x - mean) * rstd from the fp32 input: 14 instead of 16 bytes per element of an HBM-bound kernel (fm_layernorm_bwd_h).
+# x_hat then carries h's bf16 rounding (2^-9 relative - the operand the forward GEMMs used).  FOURM_LN_BWD_FROM_H=0: from x, as upstream's fp32 norm.
+LN_BWD_FROM_H = os.environ.get("FOURM_LN_BWD_FROM_H", "1") == "1"
 
 
 def bump_weight_epoch():
@@ -534,6 +538,8 @@ class FourMEngine:
             mean = self.ws.get(f"{tag}.{key}.mu", (x.shape[0],), torch.float32)
             rstd = self.ws.get(f"{tag}.{key}.rs", (x.shape[0],), torch.float32)
             sv[key + ".mu"], sv[key + ".rs"] = mean, rstd
+            if LN_BWD_FROM_H and row_map is None and norm.bias is None and y.dtype == torch.bfloat16:
+                sv[key + ".h"] = y          # the backward rebuilds x_hat from this 2-byte output instead of the 4-byte input (_ln_bwd)
         pend = self._pending
         if pend is not None and pend[0] is x:      # x = residual + delta is still owed: this norm computes and stores it on the way
             self._pending = None
@@ -888,7 +894,7 @@ class FourMEngine:
         dw = self._g(norm.weight)
         db = self._g(norm.bias) if isinstance(norm.bias, nn.Parameter) else None
         ops.layernorm_bwd(dy, x, norm.weight, sv[key + ".mu"], sv[key + ".rs"], g, dres=dres, dx_bf16=g_bf, dw=dw, db=db,
-                          dy_row_map=dy_row_map, R=R)
+                          dy_row_map=dy_row_map, R=R, h=sv.get(key + ".h"))
 
     def _mlp_bwd(self, mlp, sv, g_bf, R, Rp):
         """In: g_bf = d(out) bf16.  Out: dh (bf16 scratch) = gradient w.r.t. the norm2 output."""

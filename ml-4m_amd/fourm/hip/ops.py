@@ -262,8 +262,15 @@ def _ln_fwd(x, w, b, y, mean, rstd, row_map, eps, R):
     return y
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dx, *, dres=None, dx_bf16=None, dw=None, db=None, dy_row_map=None, R=None):
+def layernorm_bwd(dy, x, w, mean, rstd, dx, *, dres=None, dx_bf16=None, dw=None, db=None, dy_row_map=None, R=None, h=None):
+    """``h`` (optional): the bf16 output the forward norm wrote (bias-free norm, same row order as x) - x_hat is then rebuilt from it
+    instead of from the fp32 ``x`` (fm_layernorm_bwd_h: 14 instead of 16 bytes per element)."""
     R = x.shape[0] if R is None else R
+    if h is not None and dy.dtype != torch.float32 and db is None and dy_row_map is None:
+        with _prof("layernorm_bwd", 0.0, R * w.numel() * (2 + 2 + 4 + 4 + (2 if dx_bf16 is not None else 0))):
+            L.check(L.layernorm_bwd_h(_p(dy), _ld(dy), _p(h), _ld(h), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres), _p(dx), _ld(dx),
+                                      _p(dx_bf16), _ld(dx_bf16) if dx_bf16 is not None else 0, _p(dw), R, w.numel(), _stream()))
+        return dx
     with _prof("layernorm_bwd", 0.0, R * w.numel() * (2 + 4 + 4 + 4 + (2 if dx_bf16 is not None else 0))):
         return _ln_bwd(dy, x, w, mean, rstd, dx, dres, dx_bf16, dw, db, dy_row_map, R)
 

@@ -538,6 +538,42 @@ def test_layernorm(R, D):
 
 
 @pytest.mark.parametrize("R,D", [(300, 768), (129, 1024), (64, 384), (17, 2048)])
+def test_layernorm_bwd_from_saved_output(R, D):
+    """fm_layernorm_bwd_h: x_hat rebuilt from the saved bf16 norm output h instead of the fp32 input (bias-free norm).  Exact against
+    the restatement with x_hat = float(h) / w; against the fp32 norm backward within h's bf16 rounding; weights of magnitude 0 (x_hat
+    not recoverable from h) take the fp32 input for their chunk."""
+    ops, L = _ops()
+    x = randn(R, D, seed=35) * 2 + 0.5
+    w = randn(D, seed=36) * 0.2 + 1
+    w[5] = 0.0; w[D - 3] = 1e-30          # chunks 1 and D / 4 - 1 fall back to x
+    h = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    mean, rstd = torch.zeros(R, device=DEV), torch.zeros(R, device=DEV)
+    ops.layernorm_fwd(x, w, None, h, mean, rstd)
+    dy, dres = bf(randn(R, D, seed=37)), randn(R, D, seed=38)
+    dx = torch.zeros(R, D, device=DEV); dxb = torch.zeros(R, D, device=DEV, dtype=torch.bfloat16)
+    dw = torch.ones(D, device=DEV)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dx, dres=dres, dx_bf16=dxb, dw=dw, h=h)
+    # restatement: x_hat from h where every weight of the 4-column chunk is usable, from x elsewhere
+    xh_x = (x - mean[:, None]) * rstd[:, None]
+    usable = (w.abs().view(-1, 4).min(dim=1).values >= 1e-20).repeat_interleave(4)
+    xh = torch.where(usable[None, :], h.float() / torch.where(usable, w, torch.ones_like(w))[None, :], xh_x)
+    g = dy.float() * w
+    want = rstd[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True)) + dres
+    assert rel_err(dx, want) < 1e-5
+    assert rel_err(dw - 1, (dy.float() * xh).sum(0)) < 1e-4
+    assert rel_err(dxb, want) < 4e-3
+    # against the fp32 norm backward: within the rounding h carries
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (D,), wr, None, eps=1e-6).backward(dy.float())
+    assert rel_err(dx, xr.grad + dres) < 4e-3
+    assert rel_err(dw - 1, wr.grad) < 4e-3
+    # in place (dres aliases dx), no bf16 copy, no weight gradient
+    acc = dres.clone()
+    ops.layernorm_bwd(dy, x, w, mean, rstd, acc, dres=acc, h=h)
+    assert rel_err(acc, want) < 1e-5
+
+
+@pytest.mark.parametrize("R,D", [(300, 768), (129, 1024), (64, 384), (17, 2048)])
 def test_layernorm_with_residual_add(R, D):
     """fm_layernorm_fwd_res: x_out = x + delta (bf16) and y = LN(x_out) in one pass - bit-identical to the residual epilogue's sum
     followed by fm_layernorm_fwd (the engine moves the add from the GEMM epilogue into the norm); row_map honoured; fm_add_bf16_f32."""
