@@ -115,19 +115,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ;  dw += sum_r dy * xhat ;  db += sum_r dy
-constexpr int BWD_ROWS = 32;   // rows per workgroup (4 waves x 8)
+// rows per workgroup (4 waves x 8 ... 32 rows): every workgroup ends with one fp32 atomic per column and gradient, all workgroups on the same
+// D addresses - the more rows a workgroup covers, the fewer of those (FOURM_LN_BWD_ROWS: lab)
+static int bwd_rows(int R) {
+    static const int env = [] { const char* e = getenv("FOURM_LN_BWD_ROWS"); return e ? atoi(e) : 0; }();
+    if (env >= 4) return env;
+    return R >= 512 * 64 ? 64 : 32;        // (32768 x 768 from h: 78.6 us at 32 rows, 73.2 at 64, 74.3 at 128; without the atomics 67)
+}
 
 // FROM_H (bias-free norms whose bf16 output h = bf16(xhat * w) was saved for the weight-gradient GEMM anyway): xhat = h / w is rebuilt
 // from the 2-byte h instead of the 4-byte x (16 -> 14 bytes per element of this HBM-bound kernel; relative error of xhat 2^-9, the
 // rounding h already carries into the GEMMs).  Chunks holding a weight of magnitude < 1e-20 (h = 0 there: xhat is not recoverable)
 // read x as before.
-template <int MAXC, bool FROM_H = false>
+template <int MAXC, bool FROM_H = false, bool HAS_DB = true>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const int* __restrict__ dy_row_map,
                                                      const bf16_t* __restrict__ h, int ldh,
                                                      const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* dres, float* dx, int lddx, bf16_t* __restrict__ dx_bf, int lddxbf,
-                                                     float* __restrict__ dw, float* __restrict__ db, int R, int D) {
+                                                     float* __restrict__ dw, float* __restrict__ db, int R, int D, int BWD_ROWS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;   // [2][4 waves][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                             bf2f((bf16_t)(hh.y & 0xffff)) * iw[c].z, bf2f((bf16_t)(hh.y >> 16)) * iw[c].w);
                     }
                     aw[c].x += d.x * xh[c].x; aw[c].y += d.y * xh[c].y; aw[c].z += d.z * xh[c].z; aw[c].w += d.w * xh[c].w;
-                    ab[c].x += d.x; ab[c].y += d.y; ab[c].z += d.z; ab[c].w += d.w;
+                    if constexpr (HAS_DB) { ab[c].x += d.x; ab[c].y += d.y; ab[c].z += d.z; ab[c].w += d.w; }
                     g[c] = make_float4(d.x * wv[c].x, d.y * wv[c].y, d.z * wv[c].z, d.w * wv[c].w);
                     s1 += (g[c].x + g[c].y) + (g[c].z + g[c].w);
                     s2 += (g[c].x * xh[c].x + g[c].y * xh[c].y) + (g[c].z * xh[c].z + g[c].w * xh[c].w);
@@ -223,13 +229,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const int ch = lane + 64 * c;
         if (ch < nch) {
             *(float4*)(red + (size_t)wave * D + ch * 4) = aw[c];
-            *(float4*)(red + (size_t)(4 + wave) * D + ch * 4) = ab[c];
+            if constexpr (HAS_DB) *(float4*)(red + (size_t)(4 + wave) * D + ch * 4) = ab[c];
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < D; i += 256) {
         if (dw) unsafeAtomicAdd(dw + i, (red[i] + red[D + i]) + (red[2 * D + i] + red[3 * D + i]));
-        if (db) unsafeAtomicAdd(db + i, (red[4 * D + i] + red[5 * D + i]) + (red[6 * D + i] + red[7 * D + i]));
+        if constexpr (HAS_DB) if (db) unsafeAtomicAdd(db + i, (red[4 * D + i] + red[5 * D + i]) + (red[6 * D + i] + red[7 * D + i]));
     }
 }
 
@@ -374,16 +380,17 @@ static int layernorm_bwd_launch(const void* dy, int lddy, const int32_t* dy_row_
     FM_CHECK_ARG(!h || ldh % 4 == 0, "fm_layernorm_bwd_h: ldh must be a multiple of 4");
     FM_CHECK_ARG(R > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * MAXC_LIMIT, "fm_layernorm_bwd: D=%d unsupported", D);
     FM_CHECK_ARG(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddxbf % 4 == 0, "fm_layernorm_bwd: leading dims must be multiples of 4");
+    const int BWD_ROWS = bwd_rows(R);
     const int grid = (R + BWD_ROWS - 1) / BWD_ROWS;
     const size_t lds = (size_t)8 * D * sizeof(float);
 #define LN_BWD_(C, FH)                                                                                                      \
     {                                                                                                                       \
-        auto k = ln_bwd_kernel<C, FH>;                                                                                      \
+        auto k = ln_bwd_kernel<C, FH, !FH>;                                                                                     \
         static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2048 * 4) == hipSuccess); \
         (void)once;                                                                                                         \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, lddy, dy_row_map, (const bf16_t*)h, ldh, \
                            (const float*)x, ldx, (const float*)w, (const float*)mean, (const float*)rstd, (const float*)dres, (float*)dx, lddx, \
-                           (bf16_t*)dx_bf16, lddxbf, (float*)dw, (float*)db, R, D);                                         \
+                           (bf16_t*)dx_bf16, lddxbf, (float*)dw, (float*)db, R, D, BWD_ROWS);                               \
     }
 #define LN_BWD(C) { if (h) LN_BWD_(C, true) else LN_BWD_(C, false) }
     switch (chunks_for(D)) {

@@ -538,7 +538,7 @@ class FourMEngine:
             mean = self.ws.get(f"{tag}.{key}.mu", (x.shape[0],), torch.float32)
             rstd = self.ws.get(f"{tag}.{key}.rs", (x.shape[0],), torch.float32)
             sv[key + ".mu"], sv[key + ".rs"] = mean, rstd
-            if LN_BWD_FROM_H and row_map is None and norm.bias is None and y.dtype == torch.bfloat16:
+            if LN_BWD_FROM_H and row_map is None and not isinstance(norm.bias, nn.Parameter) and y.dtype == torch.bfloat16:      # (a buffer bias is upstream's all-zero placeholder, fm_utils.py:93-108)
                 sv[key + ".h"] = y          # the backward rebuilds x_hat from this 2-byte output instead of the 4-byte input (_ln_bwd)
         pend = self._pending
         if pend is not None and pend[0] is x:      # x = residual + delta is still owed: this norm computes and stores it on the way
