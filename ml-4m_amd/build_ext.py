@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "fourm", "_lib", "libfourm_hip.so")
-SOURCES = ["api.cpp", "gemm.hip", "gemm_nt_flat.hip", "gemm_nt3.hip", "gemm_nt4.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "select_embed.hip", "loss.hip", "elementwise.hip", "vq.hip", "fp32_verify.hip", "sample.hip", "masking.hip", "unet.hip"]
+SOURCES = ["api.cpp", "gemm.hip", "gemm_nt_flat.hip", "gemm_nt3.hip", "gemm_nt4.hip", "gemm_tn4.hip", "gemm_skinny.hip", "layernorm.hip", "attention.hip", "select_embed.hip", "loss.hip", "elementwise.hip", "vq.hip", "fp32_verify.hip", "sample.hip", "masking.hip", "unet.hip"]
 
 
 # sample.hip: the sampler's determinism contract needs separately rounded fp32 multiplies and adds (no fused multiply-add)

@@ -807,19 +807,6 @@ __global__ __launch_bounds__(WA * WB * 64) void gemm_tn_kernel(TNArgs a) {
 // over the same rows, so the operand panels they share come from that XCD's L2 once - a stream-K cut at arbitrary offsets would
 // have every workgroup at a different row and lose that.  Atomic traffic: (tiles + gridDim) x 128 KB per LAYER.
 // The main loop is gemm_tn_kernel's ping-pong schedule (K-step 64, 3-stage LDS-DMA ring, transpose reads), restarted per segment.
-struct TNJob {
-    const bf16_t* A; const bf16_t* B; float* out;
-    int R, N, K, lda, ldb, ldo, a_cols, b_cols;
-    int n_tiles_b, tiles, tile_start, kt;        // kt = reduction tiles (of 64 rows) of this job
-    int q;                                       // main share of a tile of the last partial round
-    int lb;                                      // banded cut: k-tiles [q, q + lb) of tile i go to tail workgroup i (0: no band)
-};
-struct TNMultiArgs {
-    TNJob job[FM_TN_MAX_JOBS];
-    int n_jobs, tiles, tail_rr, banded;
-    int hybrid;             // round-robin tails with rem > ntail: one whole tail per tail workgroup, the other rem - ntail tails walked by all of them
-};
-
 // TA = 128, KB = 64: 64 x 64 wave tiles, 144 KB of LDS;  TA = 256, KB = 32: 128 x 64 wave tiles (8 accumulators per wave), 96 KB - per MFMA
 // 2/3 of the LDS-DMA pieces and 3/8 of the transpose reads of the small tile.
 // LS ("lock step", TA = 256, KB = 64, two stages = 128 KB): the structure of gemm_nt3.hip on the TN operands - ONE barrier per K-tile,
@@ -1079,6 +1066,7 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
         // accumulator: rows <-> n (A columns), cols <-> k (B columns); lane = k, regs = n
         float* out = jb.out;
         const int N = jb.N, K = jb.K, ldo = jb.ldo;
+        if (a.lab & 1) return;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int k = k0 + wb * 64 + jj * 32 + (lane & 31);
@@ -1092,81 +1080,15 @@ __global__ __launch_bounds__(512) void gemm_tn_multi_kernel(TNMultiArgs a) {
                 }
         }
     };
-    auto job_of = [&](int tile) {
-        int j = 0;
-        while (j + 1 < a.n_jobs && tile >= a.job[j + 1].tile_start) ++j;
-        return j;
-    };
-
-    // the segments of this workgroup, one call site for the main loop
-    const int full = a.tiles / G, T0 = full * G, rem = a.tiles - T0, ntail = G - rem;
-    auto q_of = [&](int j) { return a.job[j].q; };
-    // Banded cut (contiguous mode): the first `rem` tail workgroups take ONE band [q, q + lb) of "their" tile each - they start
-    // together on neighbouring tiles over the same rows, so they share operand panels in L2 like the mains - and only the remaining
-    // ntail - rem workgroups walk what is left ([q + lb, kt) of every tile) as contiguous runs.
-    // Hybrid cut (round-robin mode with more tails than tail workgroups, e.g. a 4M-B decoder layer: 144 tiles, 112 tail workgroups):
-    // tail workgroup j takes the WHOLE tail of tile j (aligned with its neighbours, like the mains) and the tails of the other
-    // rem - ntail tiles are walked by ALL tail workgroups as contiguous runs - instead of 32 of them taking a second whole tail
-    // (makespan 691 k-tiles against a mean of 576).
-    const int nband = a.hybrid ? 0 : (a.banded ? rem : 0), nwalk = ntail - nband;
-    const int walk_T0 = a.hybrid ? T0 + ntail : T0;                         // first tile of the walked region
-    auto q2_of = [&](int j) { return a.job[j].q + ((a.banded && !a.hybrid) ? a.job[j].lb : 0); };
-    long long u0 = 0, u1 = 0;
-    if (rem > 0 && w >= rem + nband && (!a.tail_rr || a.hybrid)) {
-        long long Lsum = 0;
-        for (int j = 0; j < a.n_jobs; ++j) {
-            const int lo = max(a.job[j].tile_start, walk_T0), hi = a.job[j].tile_start + a.job[j].tiles;
-            if (hi > lo) Lsum += (long long)(hi - lo) * (a.job[j].kt - q2_of(j));
-        }
-        u0 = Lsum * (w - rem - nband) / nwalk; u1 = Lsum * (w - rem - nband + 1) / nwalk;
-    }
-    int phase = 0, f = 0, tj = 0, ci = -1;
-    long long P = 0;
-    for (;;) {
-        int tile = 0, t0 = 0, t1 = 0;
-        bool have = false;
-        if (phase == 0) {
-            if (f < full) { tile = f * G + w; t1 = a.job[job_of(tile)].kt; ++f; have = true; }
-            else { phase = rem == 0 ? 3 : (w < rem ? 1 : ((!a.tail_rr && w < rem + nband) ? 4 : 2)); f = 0; }
-        } else if (phase == 1) {
-            tile = T0 + w; t1 = q_of(job_of(tile)); phase = 3; have = true;
-        } else if (phase == 4) {
-            tile = T0 + (w - rem); const int j = job_of(tile); t0 = q_of(j); t1 = t0 + a.job[j].lb; phase = 3; have = true;
-        } else if (phase == 2 && a.tail_rr && !(a.hybrid && f > 0)) {
-            const int sgm = (w - rem) + f * ntail;          // f counts this tail's segments here
-            if (sgm >= rem) phase = 3;
-            else { tile = T0 + sgm; const int j = job_of(tile); t0 = q_of(j); t1 = a.job[j].kt; ++f; have = true; }
-        } else if (phase == 2) {                            // (hybrid: after the one whole tail, this workgroup's share of the walk)
-            if (tj >= a.n_jobs) phase = 3;
-            else {
-                const int lo = max(a.job[tj].tile_start, walk_T0), hi = a.job[tj].tile_start + a.job[tj].tiles;
-                const int q = q2_of(tj), left = a.job[tj].kt - q;
-                bool advance = true;
-                if (hi > lo && left > 0) {
-                    const long long Pn = P + (long long)(hi - lo) * left;
-                    if (u1 > P && u0 < Pn) {
-                        const long long s0 = max(u0, P) - P, s1 = min(u1, Pn) - P;       // leftover k-tiles of this job: [s0, s1)
-                        if (ci < 0) ci = (int)(s0 / left);
-                        const long long base = (long long)ci * left;
-                        if (base < s1) {
-                            tile = lo + ci; t0 = q + (int)(max(s0, base) - base); t1 = q + (int)(min(s1, base + left) - base);
-                            ++ci; have = true; advance = false;
-                        }
-                    }
-                    if (advance) P = Pn;
-                }
-                if (advance) { ++tj; ci = -1; }
-            }
-        } else break;
-        if (have) run(tile, t0, t1);
-    }
+    tn_multi_walk(a, w, G, run);
 }
 
 int g_nt_config = 9, g_nt_prio = 1;
 // experiment knobs (tools/gemm_lab via fm_lab_set): [0] de-phase groups, [1] de-phase step (x 2048 cycles), [2] gemm_nt3 mode (0 off,
 // 1 = 256-wide tiles, 2 = 192-wide, 3 = by shape: the default; FOURM_NT3=0 turns it off), [3] gemm_nt3 experiment flags
 int g_lab[16] = {0, 0, [] { const char* e = getenv("FOURM_NT3"); return e ? atoi(e) : 3; }(), [] { const char* e = getenv("FOURM_NT3_LAB"); return e ? atoi(e) : 0; }(),
-                 [] { const char* e = getenv("FOURM_NT4"); return e ? atoi(e) : 1; }()};      // [4] gemm_nt4 mode (gemm_nt4.hip; FOURM_NT4=0 turns it off)
+                 [] { const char* e = getenv("FOURM_NT4"); return e ? atoi(e) : 1; }(),       // [4] gemm_nt4 mode (gemm_nt4.hip; FOURM_NT4=0 turns it off)
+                 [] { const char* e = getenv("FOURM_TN4"); return e ? atoi(e) : 0; }()};      // [5] gemm_tn4.hip for the dW job lists (FOURM_TN4=1 turns it on; [6] its lab flags, [7] / [8] its planner constants)
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
@@ -1443,8 +1365,26 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
     // layer 478 -> 461 us (profiles/r02_lab_tn_multi_tiles.txt)
     static const bool small_env = [] { const char* e = getenv("FOURM_TN_MULTI_TILE"); return e && atoi(e) == 128; }();
     const bool big = !(small_env || g_tn_config == 3);
-    const bool ls = big && g_tn_config == 4;                 // lock-step form: 256 x 256 tiles, K-step 64, two stages
-    const int ta = big ? 256 : 128, kb = (big && !ls) ? 32 : 64;
+    // gemm_tn4.hip (4 waves, 512 registers, 256 x 384 tiles, K-step 64): when every job fits its shape rules and the tiling wastes < 8 % of
+    // its MFMAs on columns past the operands.  OFF by default (FOURM_TN4=1 / fm_lab_set(5, 1): on): whole rounds of whole tiles run 10 - 13 %
+    // faster than on the 8-wave kernel (1250 - 1320 against 1134 - 1163 TFLOP/s), but a 4M-B layer is 74 / 96 tiles on 256 CUs - every tile cut
+    // 3.5 ways, every segment ending in 384 KB of fp32 atomics instead of 256 KB - and lands where the 8-wave kernel does (encoder / decoder layer
+    // 430 / 551 against 433 / 559 us; without the atomics 393 / 514 against 413 / 529: profiles/r06_lab_tn4.txt)
+    bool t4 = big && g_lab[5] != 0 && (g_tn_config == 1 || g_tn_config == 4);
+    if (t4) {
+        double useful = 0, padded = 0;
+        for (int i = 0; i < n_jobs && t4; ++i) {
+            const fm_gemm_tn_job& p = jobs[i];
+            const int ac = p.a_cols > 0 ? p.a_cols : p.lda, bc = p.b_cols > 0 ? p.b_cols : p.ldb;
+            t4 = p.R % 64 == 0 && p.R >= 256 && p.N % 128 == 0 && p.K % 128 == 0 && ac >= 128 && bc >= 128 && ac % 8 == 0 && bc % 8 == 0 &&
+                 (((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0 && ((size_t)p.R * p.lda + ac) * 2 < 0x7fffffffull && ((size_t)p.R * p.ldb + bc) * 2 < 0x7fffffffull;
+            useful += (double)p.N * p.K * p.R;
+            padded += (double)((p.N + 255) / 256 * 256) * ((p.K + 383) / 384 * 384) * p.R;
+        }
+        t4 = t4 && useful >= 0.92 * padded;
+    }
+    const bool ls = big && (g_tn_config == 4 || t4);         // lock-step form: 256 x 256 tiles, K-step 64, two stages (the planner constants of t4 too)
+    const int ta = big ? 256 : 128, kb = (big && !ls) ? 32 : 64, tb = t4 ? 384 : 256;
     for (int i = 0; i < n_jobs; ++i) {
         const fm_gemm_tn_job& p = jobs[i];
         FM_CHECK_ARG(p.A && p.B && p.out, "fm_gemm_tn_multi: null pointer");
@@ -1455,7 +1395,7 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         j.R = p.R; j.N = p.N; j.K = p.K; j.lda = p.lda; j.ldb = p.ldb; j.ldo = p.ldo;
         j.a_cols = p.a_cols > 0 ? p.a_cols : p.lda; j.b_cols = p.b_cols > 0 ? p.b_cols : p.ldb;
         FM_CHECK_ARG(j.a_cols >= 8 && j.b_cols >= 8, "fm_gemm_tn_multi: operands need at least 8 readable columns");
-        j.n_tiles_b = (p.K + 255) / 256;
+        j.n_tiles_b = (p.K + tb - 1) / tb;
         j.tiles = ((p.N + ta - 1) / ta) * j.n_tiles_b;
         j.tile_start = tiles;
         j.kt = (p.R + kb - 1) / kb;
@@ -1463,7 +1403,7 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         units += (long long)j.tiles * j.kt;
         masked = masked || p.R % kb != 0;
     }
-    a.n_jobs = n_jobs; a.tiles = tiles;
+    a.n_jobs = n_jobs; a.tiles = tiles; a.lab = g_lab[6];
     int grid = n_compute_units();
     // tiny lists: no more workgroups than 8-k-tile shares (a multiple of the 8 XCDs)
     if (units / 8 < grid) grid = (int)((units / 8 + 7) / 8 * 8);
@@ -1477,12 +1417,14 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         // share is a fraction of a tile, i.e. in the contiguous cut)
         const int rem = tiles % grid, ntail = grid - rem;
         a.tail_rr = rem >= ntail;
-        const double c = ls ? (a.tail_rr ? 12.0 : 64.0) : big ? (a.tail_rr ? 24.0 : 128.0) : 8.0;     // (in k-tiles of this configuration)
+        double c = ls ? (a.tail_rr ? 12.0 : 64.0) : big ? (a.tail_rr ? 24.0 : 128.0) : 8.0;     // (in k-tiles of this configuration)
+        if (t4 && g_lab[7] > 0) c = g_lab[7];                                                     // (lab: fm_lab_set 7 / 8 = c / cb of the 256 x 384 kernel)
         // Contiguous cut with bands (rem < ntail): tail workgroup i takes ONE band [q, q + lb) of tile i - the first rem tails start
         // together on neighbouring tiles over the same rows and share operand panels in L2 like the mains (as plain contiguous runs
         // the tails re-read 1.9 x the operands: profiles/r02_v6_traffic_table.txt) - the other ntail - rem walk the rest.  4M-B encoder
         // layer (108 tiles): 474 -> 420 us (profiles/r02_lab_tn_multi_tiles.txt).  FOURM_TN_BANDS=0: plain contiguous runs (A/B).
-        const double cb = ls ? 16.0 : 32.0;
+        double cb = ls ? 16.0 : 32.0;
+        if (t4 && g_lab[8] > 0) cb = g_lab[8];
         static const bool band_off = [] { const char* e = getenv("FOURM_TN_BANDS"); return e && atoi(e) == 0; }();
         a.banded = !a.tail_rr && rem > 0 && ntail > rem && !band_off;
         static const bool hybrid_off = [] { const char* e = getenv("FOURM_TN_HYBRID"); return e && atoi(e) == 0; }();
@@ -1524,7 +1466,8 @@ extern "C" int fm_gemm_tn_multi(const fm_gemm_tn_job* jobs, int n_jobs, void* st
         (void)once;                                                                                                           \
         hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, a);                                                              \
     }
-    if (ls) LAUNCH_TNM(false, 256, 64, ls)        // (row masking through the buffer descriptor)
+    if (t4) fm_launch_tn4_multi(a, grid, s);
+    else if (ls) LAUNCH_TNM(false, 256, 64, ls)        // (row masking through the buffer descriptor)
     else if (big) { if (masked) LAUNCH_TNM(true, 256, 32) else LAUNCH_TNM(false, 256, 32) }
     else { if (masked) LAUNCH_TNM(true, 128, 64) else LAUNCH_TNM(false, 128, 64) }
 #undef LAUNCH_TNM

@@ -313,14 +313,17 @@ TN_MULTI_LISTS = {
     "ragged": [(1000, 200, 264), (37, 136, 520), (4100, 768, 136), (300, 64, 64)],  # R % 64 != 0, different R per job
     "rr_tails": [(4096, 2048, 768), (4096, 2048, 768), (4096, 768, 2048), (4096, 768, 768), (4096, 2304, 768)],   # 216 tiles: round-robin tails
     "full_round": [(2048, 2048, 768)] * 5 + [(2048, 768, 2048), (2048, 1536, 768)] + [(2048, 768, 768)] * 3,      # 330 tiles: a full round + a cut
+    "t4_ragged_b": [(1024, 768, 2048), (1024, 2560, 1536), (1024, 384, 384), (1024, 128, 768)],   # 256 x 384 tiling: B tiles past K (2048 = 5.33 x 384), A tiles past N
+    "t4_short": [(256, 768, 768), (512, 2304, 768)],                                # segments of one or two K-tiles
 }
 
 
-@pytest.mark.parametrize("tile", [256, 128, "lockstep"])
+@pytest.mark.parametrize("tile", [256, 128, "lockstep", "t4"])
 @pytest.mark.parametrize("name", sorted(TN_MULTI_LISTS))
 def test_gemm_tn_multi(name, tile):
     """fm_gemm_tn_multi: every job of the list accumulates dY^T X into its own output, whatever the cut of the tile list over the
-    grid (whole tiles, main + tails, round-robin or contiguous); rows past R never count; repeated to screen for races."""
+    grid (whole tiles, main + tails, round-robin or contiguous); rows past R never count; repeated to screen for races.
+    "t4": the 4-wave / 512-register kernel on 256 x 384 tiles (gemm_tn4.hip, opt-in: FOURM_TN4=1) where the list fits its shape rules."""
     ops, L = _ops()
     jobs, refs = [], []
     for i, (R, N, K) in enumerate(TN_MULTI_LISTS[name]):
@@ -330,7 +333,8 @@ def test_gemm_tn_multi(name, tile):
         a[R:] = 1e4; b[R:] = float("nan")
         refs.append(1.0 + a[:R].float().t() @ b[:R].float())
         jobs.append((a, b, None, N, K, R))
-    L.lib.fm_set_gemm_tn_config({256: 1, 128: 3, "lockstep": 4}[tile])         # 256 x 256 / K-step 32, 128 x 256, lock-step 256 x 256 / 64
+    L.lib.fm_set_gemm_tn_config({256: 1, 128: 3, "lockstep": 4, "t4": 1}[tile])         # 256 x 256 / K-step 32, 128 x 256, lock-step 256 x 256 / 64
+    L.lib.fm_lab_set(5, 1 if tile == "t4" else 0)
     try:
         for _ in range(3):
             outs = [torch.full((N, K), 1.0, device=DEV, dtype=torch.float32) for _, N, K in TN_MULTI_LISTS[name]]
@@ -339,6 +343,7 @@ def test_gemm_tn_multi(name, tile):
                 assert rel_err(o, ref) < 1e-4, (name, tile, i, rel_err(o, ref))
     finally:
         L.lib.fm_set_gemm_tn_config(TN_DEFAULT)
+        L.lib.fm_lab_set(5, 0)
 
 
 def test_gemm_tn_multi_column_views():

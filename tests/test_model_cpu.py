@@ -147,6 +147,10 @@ def test_gemm_nt4_keeps_the_agpr_file_to_itself(tmp_path):
     kernels, problems = check_nt4_asm.check(check_nt4_asm.compile_to_asm(str(tmp_path)))
     assert not problems, problems[:5]
     assert len(kernels) >= 2 and all(k["mfma"] > 100 and k["asm_agpr"] > 100 for k in kernels.values()), kernels
+    # gemm_tn4.hip (the TN job list on 256 x 384 tiles): the same contract
+    kernels, problems = check_nt4_asm.check(check_nt4_asm.compile_to_asm(str(tmp_path), "gemm_tn4.hip"), "gemm_tn4_multi_kernel")
+    assert not problems, problems[:5]
+    assert len(kernels) == 1 and all(k["mfma"] >= 96 and k["asm_agpr"] > 100 for k in kernels.values()), kernels
 
 
 def test_ctypes_mirrors_match_the_header_layout(tmp_path):

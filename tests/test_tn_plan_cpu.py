@@ -18,7 +18,7 @@ def test_random_job_lists_are_covered_exactly_once():
     for _ in range(60):
         R = rng.choice([60, 37, 64, 1000, 4100, 8192, 300])
         jobs = [(rng.choice(shapes), rng.choice(shapes), R if rng.random() < 0.8 else rng.choice([33, 64, 500])) for _ in range(rng.randint(1, 16))]
-        for big in (True, False, "ls"):
+        for big in (True, False, "ls", "t4"):
             _, _, banded, rr = M.check(jobs, rng.choice([256, 240, 64]), big)
             modes.add("banded" if banded else "rr" if rr else "plain")
     assert {"banded", "rr"} <= modes
@@ -35,6 +35,8 @@ def test_engine_job_lists():
     assert mx0 > 1.15 * avg0                                # (plain round-robin: 32 tail workgroups take a second whole tail)
     for lst in (enc, dec):
         mx, avg, _, _ = M.check(lst, 256, "ls")                # the lock-step configuration
+        assert mx < 1.25 * avg
+        mx, avg, _, _ = M.check(lst, 256, "t4")                # 256 x 384 tiles (gemm_tn4.hip): 74 / 96 tiles, every one cut
         assert mx < 1.25 * avg
     large = [(3072, 1024, 16384), (1024, 1024, 16384), (2752, 1024, 16384), (2752, 1024, 16384), (1024, 2752, 16384)]
     M.check(large, 256, True)                               # 4M-L encoder layer: a full round + a cut

@@ -290,6 +290,19 @@ int main(int argc, char** argv) {
                    c.name, warm, cold, written);
             CK(hipFree(W)); for (auto p : Xs) CK(hipFree(p)); for (auto p : Os) CK(hipFree(p));
         }
+    } else if (mode == "tnrate") {
+        // main-loop rate of the job-list kernels on whole rounds of whole tiles (no cut of a partial round): one job N x K, R rows
+        const int N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 12288, Rr = argc > 4 ? atoi(argv[4]) : 16384;
+        void* A = dev_rand_bf16((size_t)Rr * N, 4), *B = dev_rand_bf16((size_t)Rr * K, 5);
+        void* out = dev_zero((size_t)N * K * 4);
+        fm_gemm_tn_job j{}; j.A = A; j.B = B; j.out = out; j.R = Rr; j.N = N; j.K = K; j.lda = N; j.ldb = K; j.ldo = K;
+        for (int v : {0, 1, 0, 1}) {
+            fm_lab_set(5, v);
+            if (fm_gemm_tn_multi(&j, 1, 0) != 0) { printf("multi: %s\n", fm_last_error()); return 1; }
+            const double us = time_us([&] { fm_gemm_tn_multi(&j, 1, 0); }, 5, 1);
+            printf("N=%d K=%d R=%d tn4=%d: %8.1f us %5.0f TF\n", N, K, Rr, v, us, 2.0 * Rr * N * K / us / 1e6);
+        }
+        fm_lab_set(5, 0);
     } else if (mode == "tnmulti") {
         // all weight-gradient GEMMs of one 4M-B layer: one fm_gemm_tn launch each  vs  ONE fm_gemm_tn_multi launch
         struct Shape { int N, K; };
@@ -298,6 +311,10 @@ int main(int argc, char** argv) {
         const int Rm = argc > 2 ? atoi(argv[2]) : R;
         const int multi_cfg = argc > 3 ? atoi(argv[3]) : 1;      // fm_set_gemm_tn_config for the one-launch form (2 = 256 x 256 tiles)
         const int layers_per_list = argc > 4 ? atoi(argv[4]) : 1; // > 1: the dW GEMMs of several layers in ONE list (distinct operands)
+        if (argc > 5) fm_lab_set(5, atoi(argv[5]));              // 0 (default): the list on gemm.hip's 8-wave kernel, 1: gemm_tn4.hip where it applies
+        if (argc > 6) fm_lab_set(6, atoi(argv[6]));              // 1: no atomic epilogue (timing only; the "rel diff" is then meaningless)
+        if (argc > 7) fm_lab_set(7, atoi(argv[7]));              // planner constants of the 256 x 384 kernel: segment cost c ...
+        if (argc > 8) fm_lab_set(8, atoi(argv[8]));              // ... and band cost cb, in K-tiles
         std::vector<Shape> enc_n, dec_n;
         for (int l = 0; l < layers_per_list; ++l) { enc_n.insert(enc_n.end(), enc.begin(), enc.end()); dec_n.insert(dec_n.end(), dec.begin(), dec.end()); }
         if (layers_per_list > 1) printf("(%d layers per list: divide the times by %d)\n", layers_per_list, layers_per_list);

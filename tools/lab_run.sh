@@ -3,5 +3,5 @@
 cd "$(dirname "$0")/.."
 export LD_LIBRARY_PATH=$PWD/ml-4m_amd/fourm/_lib:$LD_LIBRARY_PATH TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 300 tools/bin/gemm_lab nt ${CFGS:-1003,2001,2003,2005,2041} > gpurun_out/lab_nt4.txt 2>&1
-cat gpurun_out/lab_nt4.txt
+echo "old"; timeout 200 tools/bin/gemm_lab tnmulti 32768 1 1 0 0 | cut -c60-140
+for c in 4 8 16 32 64 128; do for cb in 4 16 48; do echo "t4 c=$c cb=$cb"; timeout 200 tools/bin/gemm_lab tnmulti 32768 1 1 1 0 $c $cb | cut -c60-140; done; done 2>&1 | tee gpurun_out/lab_tn4_c.txt

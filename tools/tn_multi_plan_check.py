@@ -8,12 +8,14 @@ import sys
 
 def plan(jobs, cus, big=True, bands=True, hybrid_on=True):
     """jobs: list of (N, K, R).  Mirrors the host code.  big: True = 256 x 256 tiles with K-step 32, False = 128 x 256 / 64,
-    "ls" = the lock-step form (256 x 256 tiles, K-step 64: fm_set_gemm_tn_config(4))."""
-    ls = big == "ls"
+    "ls" = the lock-step form (256 x 256 tiles, K-step 64: fm_set_gemm_tn_config(4)), "t4" = gemm_tn4.hip (256 x 384 tiles, K-step 64, the
+    lock-step form's planner constants)."""
+    ls = big in ("ls", "t4")
     ta, kb = (256, 64) if ls else (256, 32) if big else (128, 64)
+    tb = 384 if big == "t4" else 256
     J, tiles, units = [], 0, 0
     for N, K, R in jobs:
-        ntb = (K + 255) // 256
+        ntb = (K + tb - 1) // tb
         t = ((N + ta - 1) // ta) * ntb
         kt = (R + kb - 1) // kb
         J.append(dict(tiles=t, tile_start=tiles, kt=kt, q=0, lb=0))
