@@ -49,27 +49,39 @@ def scaled_cosine_alphas(n: int, noise_shift: float = 1.0) -> torch.Tensor:
 class _SchedulerBase:
     order = 1
 
+    # beta tables by name (what scheduling_ddpm.py:119-133 / scheduling_ddim.py:142-156 build): name -> f(T, beta_start, beta_end)
+    _BETA_TABLES = {
+        "linear": lambda T, b0, b1: torch.linspace(b0, b1, T, dtype=torch.float32),
+        "scaled_linear": lambda T, b0, b1: torch.linspace(b0 ** 0.5, b1 ** 0.5, T, dtype=torch.float32) ** 2,
+        "squaredcos_cap_v2": lambda T, b0, b1: betas_for_alpha_bar(T),
+    }
+
     def _init_common(self, num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas, zero_terminal_snr):
-        if "shifted_cosine:" in beta_schedule:
-            self.alphas_cumprod = scaled_cosine_alphas(num_train_timesteps, float(beta_schedule.split(":")[1]))
+        """alphas_cumprod of the training schedule: either the shifted-cosine closed form (no beta table exists then) or the cumulative
+        product of 1 - beta over an explicit / named beta table, optionally rescaled to zero terminal SNR."""
+        T = num_train_timesteps
+        shifted = beta_schedule.partition("shifted_cosine:")
+        if shifted[1]:
+            self.alphas_cumprod = scaled_cosine_alphas(T, float(beta_schedule.split(":")[1]))
         else:
             if trained_betas is not None:
-                self.betas = torch.tensor(trained_betas, dtype=torch.float32)
-            elif beta_schedule == "linear":
-                self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
-            elif beta_schedule == "scaled_linear":
-                self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
-            elif beta_schedule == "squaredcos_cap_v2":
-                self.betas = betas_for_alpha_bar(num_train_timesteps)
+                betas = torch.tensor(trained_betas, dtype=torch.float32)
             else:
-                raise NotImplementedError(f"{beta_schedule} does is not implemented for {self.__class__}")
-            if zero_terminal_snr:
-                self.betas = enforce_zero_terminal_snr(self.betas)
+                table = self._BETA_TABLES.get(beta_schedule)
+                if table is None:
+                    raise NotImplementedError(f"{type(self).__name__}: unknown beta_schedule {beta_schedule!r} (known: {sorted(self._BETA_TABLES)} or 'shifted_cosine:<shift>')")
+                betas = table(T, beta_start, beta_end)
+            self.betas = enforce_zero_terminal_snr(betas) if zero_terminal_snr else betas
             self.alphas = 1.0 - self.betas
             self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
         self.init_noise_sigma = 1.0
         self.num_inference_steps = None
-        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+        self.timesteps = torch.arange(T - 1, -1, -1, dtype=torch.int64)
+
+    @staticmethod
+    def _check_step_count(n, T):
+        if n > T:
+            raise ValueError(f"{n} inference steps asked of a schedule trained on {T} timesteps")
 
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -154,18 +166,17 @@ class DDIMScheduler(_SchedulerBase):
     def set_timesteps(self, num_inference_steps: int, device=None, mode: str = "trailing"):
         """scheduling_ddim.py:194-224: 'leading' | 'trailing' | 'linspace' spacing (https://arxiv.org/abs/2305.08891)."""
         T = self.config.num_train_timesteps
-        if num_inference_steps > T:
-            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than `self.config.train_timesteps`: {T}")
-        self.num_inference_steps = num_inference_steps
-        ratio = T // num_inference_steps
-        if mode == "leading":
-            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64)
-        elif mode == "trailing":
-            ts = np.arange(T, 0, -ratio).round().astype(np.int64) - 1
-        elif mode == "linspace":
-            ts = np.linspace(T, 1, num_inference_steps).round().astype(np.int64) - 1
-        else:
-            raise NotImplementedError
+        self._check_step_count(num_inference_steps, T)
+        self.num_inference_steps = n = num_inference_steps
+        stride = T // n
+        spacings = {
+            "leading": lambda: (np.arange(n) * stride).round()[::-1],
+            "trailing": lambda: np.arange(T, 0, -stride).round() - 1,
+            "linspace": lambda: np.linspace(T, 1, n).round() - 1,
+        }
+        if mode not in spacings:
+            raise NotImplementedError(f"timestep spacing {mode!r} (known: {sorted(spacings)})")
+        ts = np.ascontiguousarray(spacings[mode]()).astype(np.int64)
         self.timesteps = torch.from_numpy(ts).to(device) + self.config.steps_offset
 
     def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output: bool = False, generator=None, variance_noise=None,
@@ -214,21 +225,19 @@ class DDPMScheduler(_SchedulerBase):
     def set_timesteps(self, num_inference_steps: Optional[int] = None, device=None, timesteps: Optional[List[int]] = None, **kwargs):
         """scheduling_ddpm.py:168-219: 'leading' spacing whatever ``mode`` says (it lands in **kwargs upstream too), or custom timesteps."""
         T = self.config.num_train_timesteps
-        if num_inference_steps is not None and timesteps is not None:
-            raise ValueError("Can only pass one of `num_inference_steps` or `custom_timesteps`.")
         if timesteps is not None:
-            if any(timesteps[i] >= timesteps[i - 1] for i in range(1, len(timesteps))):
-                raise ValueError("`custom_timesteps` must be in descending order.")
-            if timesteps[0] >= T:
-                raise ValueError(f"`timesteps` must start before `self.config.train_timesteps`: {T}.")
-            ts = np.array(timesteps, dtype=np.int64)
-            self.custom_timesteps = True
+            if num_inference_steps is not None:
+                raise ValueError("set_timesteps takes a step count or an explicit timestep list, not both")
+            ts = np.asarray(timesteps, dtype=np.int64)
+            if ts.size > 1 and not np.all(np.diff(ts) < 0):
+                raise ValueError("an explicit timestep list must be strictly descending")
+            if ts[0] >= T:
+                raise ValueError(f"an explicit timestep list must start below the {T} training timesteps")
         else:
-            if num_inference_steps > T:
-                raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than `self.config.train_timesteps`: {T}")
+            self._check_step_count(num_inference_steps, T)
             self.num_inference_steps = num_inference_steps
-            ts = (np.arange(0, num_inference_steps) * (T // num_inference_steps)).round()[::-1].copy().astype(np.int64)
-            self.custom_timesteps = False
+            ts = np.ascontiguousarray((np.arange(num_inference_steps) * (T // num_inference_steps)).round()[::-1]).astype(np.int64)
+        self.custom_timesteps = timesteps is not None
         self.timesteps = torch.from_numpy(ts).to(device)
 
     def previous_timestep(self, timestep):
