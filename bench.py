@@ -221,7 +221,7 @@ def cpu_baseline(timeout_s=300, workload="train"):
                 pass
         return rec
     except Exception as e:
-        return {"value": None, "unit": "images/s" if workload == "vq" else "tokens/s", "cores": os.cpu_count(), "kind": "port",
+        return {"value": None, "unit": "images/s" if workload in ("vq", "divae") else "tokens/s", "cores": os.cpu_count(), "kind": "port",
                 "reference_available": os.path.isdir(REFERENCE_TREE),
                 "sample": f"CPU leg did not finish within {timeout_s}s ({type(e).__name__})"}
 
@@ -307,6 +307,31 @@ def cpu_baseline_vq_worker(batch=8, steps=3):
             "reference_available": os.path.isdir(REFERENCE_TREE),
             "sample": f"oracle fp32 PyTorch port of VQ.encode (ViT-B/16 + 16384 x 32 cosine codebook), batch {batch} 224^2 images, median of "
                       f"{steps} passes after 1 warm-up, {t:.2f} s/batch", "cpu": _cpu_model_name()}
+
+
+def cpu_baseline_divae_worker(evals=2, ddim_steps=25):
+    """The DiVAE oracle port (fp32 restatement of the unet_patched decoder, pinned to upstream by tests/golden/make_golden_divae.py) on the host
+    cores: UNet evaluations of ONE image; a decode is ddim_steps of them (the scheduler steps are negligible)."""
+    from oracle import divae_oracle as D
+    threads = min(64, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = D.unet_patched_cfg()
+    P = D.seeded_unet_state_dict(cfg, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 3, cfg.image_size, cfg.image_size, generator=g)
+    cond = torch.randn(1, cfg.cond_channels, 14, 14, generator=g)
+    times, t_start = [], time.perf_counter()
+    with torch.no_grad():
+        while len(times) < evals + 1 or (time.perf_counter() - t_start < 12.0 and len(times) < 61):      # ~12 s of CPU work
+            t0 = time.perf_counter()
+            D.unet_forward(P, cfg, x, 500, cond)
+            times.append(time.perf_counter() - t0)
+    evals = len(times) - 1
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": 1.0 / (t * ddim_steps), "unit": "images/s", "cores": threads, "host_cores": os.cpu_count(), "kind": "port",
+            "reference_available": os.path.isdir(REFERENCE_TREE),
+            "sample": f"oracle fp32 PyTorch port of the unet_patched decoder: median of {evals} evaluations of ONE 224^2 image after 1 warm-up, "
+                      f"{t:.2f} s per evaluation, x {ddim_steps} DDIM steps per decoded image", "cpu": _cpu_model_name()}
 
 
 def cpu_baseline_mod21_worker(batch=1, steps=2):
@@ -489,13 +514,111 @@ def main_vq(a):
         dist.destroy_process_group()
 
 
+def main_divae(a):
+    """the diffusion detokenizer DiVAE (vqvae.py:498-764) - images/s of decode_tokens (token grid -> codebook embedding ->
+    25 DDIM steps of the conditional unet_patched decoder, 196 M parameters, with dynamic thresholding) at batch 8.  Replicas only."""
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "no GPU visible: the detokenizer has no CPU implementation"}))
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from fourm.hip import ops
+    from fourm.vq import DiVAE
+    torch.manual_seed(rank)
+    batch, ddim = a.user_batch or 8, 25
+    model = DiVAE(image_size=224, n_channels=3, enc_type="vit_b_enc", patch_size=16, codebook_size=16384, latent_dim=32, post_mlp=True, norm_codes=True,
+                  scheduler="ddim", prediction_type="sample", beta_schedule="linear", sync_codebook=False)
+    for p in model.decoder.parameters():          # upstream zero-initialises the block tails: give every GEMM real operands
+        if float(p.abs().max()) == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    model = model.to(dev).eval()
+    toks = [torch.randint(0, 16384, (batch, 14, 14), device=dev) for _ in range(2)]
+    gen = torch.Generator().manual_seed(rank)
+
+    def decode(i):
+        return model.decode_tokens(toks[i % 2], timesteps=ddim, generator=gen, verbose=False)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    if a.pmc_worker:          # two UNet evaluations (a decode is 25 of them)
+        quant = model.tokens_to_embedding(toks[0]).float()
+        x = torch.randn(batch, 3, 224, 224, device=dev)
+        for _ in range(2):
+            model.decoder(x, 500, quant)
+        fence()
+        return
+    steps, warmup = min(a.steps, 4), min(a.warmup, 1)
+    for i in range(warmup):
+        decode(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        img = decode(i)
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    flops_img_eval = 190.0e9               # DESIGN §4: 3x3 / 1x1 convolutions + attention of one evaluation per image
+    value = world * batch * steps / dt
+    out = {"metric": "images/sec (DiVAE diffusion detokenizer: decode_tokens, 25 DDIM steps, whole job)", "value": value, "unit": "images/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "DiVAE detokenizer (unet_patched decoder 196 M parameters, 56 x 56 patch grid, 14 x 14 x 32 conditioning, DDIM 25 steps, "
+                                  "dynamic thresholding): DiVAE.decode_tokens on random token grids", "per_gpu_batch": batch, "global_batch": batch * world,
+                      "parallelism": f"replicas x{world}"},
+           "ms_per_unet_evaluation": 1e3 * dt / steps / ddim, "finite": bool(torch.isfinite(img).all()),
+           "mfu": flops_img_eval * ddim * value / world / (BF16_PEAK_TFLOPS * 1e12),
+           "arithmetic": "convolutions as im2col + bf16 GEMMs (fp32 accumulate), bf16 feature maps, GroupNorm / attention softmax / scheduler steps fp32"}
+    if not a.no_kernel_profile and rank == 0:
+        prof = LaunchProfiler()
+        quant = model.tokens_to_embedding(toks[0]).float()
+        x = torch.randn(batch, 3, 224, 224, device=dev)
+        ops.set_profiler(prof)
+        for _ in range(2):
+            model.decoder(x, 500, quant)
+        ops.set_profiler(None)
+        agg = prof.summary()
+        tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
+        gemms = {k: v for k, v in agg.items() if v["flops"]}
+        name, d = max(gemms.items(), key=lambda kv: kv[1]["ms"])
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        fam, _, epi = name.partition("/epi")
+        traffic, detail = (None, None)
+        if world == 1 and not a.no_traffic and fam in KERNEL_REGEX:
+            traffic, detail = pmc_traffic(KERNEL_REGEX[fam].format(epi=epi or "0", nt4="" if (epi or "0") == "0" else "NEVER"), worker_args=["--workload", "divae", "--batch", str(batch)])
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_PEAK_TFLOPS,
+                           "kernel": f"{name} (the convolutions' GEMMs of one UNet evaluation: csrc/gemm_nt3.hip / gemm.hip on im2col rows, M = batch x 56^2 ... batch x 7^2)",
+                           "traffic": traffic, "traffic_detail": detail, "launches_per_evaluation": d["n"] // 2,
+                           "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms,
+                           "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
+        out["kernel_breakdown_ms_per_evaluation"] = {k: round(v["ms"] / 2, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        print(json.dumps(out), file=sys.stderr)
+        out["cpu_baseline"] = cpu_baseline(workload="divae")
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="train", choices=["train", "vq", "train21"], help="train = the headline 4M train step; vq = BASELINE "
-                    "configs[4]: RGB VQ tokenizer (ViT-B/16, 224^2 -> 14 x 14 codes, 16384 x 32 codebook) encode + quantize, batch 64")
+    ap.add_argument("--workload", default="train", choices=["train", "vq", "train21", "divae"], help="train = the headline 4M train step; vq = BASELINE "
+                    "configs[4]: RGB VQ tokenizer (ViT-B/16, 224^2 -> 14 x 14 codes, 16384 x 32 codebook) encode + quantize, batch 64; divae = SURVEY §8 "
+                    "row f4: the diffusion detokenizer, decode_tokens with 25 DDIM steps at batch 8")
     ap.add_argument("--mods", default="mod7", choices=sorted(MODS), help="mod7 = BASELINE configs[1] (4M-B, batch 256, 128+128 tokens); "
                     "mod21 = configs[3] (4M-L, 19 / 17 modalities, batch 64, 256+256 tokens)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256 for mod7, 64 for mod21)")
@@ -525,6 +648,8 @@ def main():
     if a.cpu_baseline_worker:
         if a.workload == "vq":
             print(json.dumps(cpu_baseline_vq_worker()))
+        elif a.workload == "divae":
+            print(json.dumps(cpu_baseline_divae_worker()))
         elif a.workload == "train21":
             print(json.dumps(cpu_baseline_mod21_worker()))
         elif a.cpu_baseline_kind == "reference" or (a.cpu_baseline_kind == "auto" and os.path.isdir(REFERENCE_TREE)):
@@ -534,6 +659,8 @@ def main():
         return
     if a.workload == "vq":
         return main_vq(a)
+    if a.workload == "divae":
+        return main_divae(a)
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
@@ -729,7 +856,8 @@ def main():
         import gc
         gc.collect(); torch.cuda.empty_cache()
         out["extra"] = {"vq": extra_record(["--workload", "vq", "--steps", "10", "--warmup", "3"], 300),
-                        "mod21": extra_record(["--mods", "mod21", "--steps", "5", "--warmup", "2"], 600)}
+                        "mod21": extra_record(["--mods", "mod21", "--steps", "5", "--warmup", "2"], 600),
+                        "divae": extra_record(["--workload", "divae", "--steps", "3", "--warmup", "1"], 300)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -194,7 +194,7 @@ def _assign(vq, eng, z, R, G, B, nh, nw, want_quant):
     cb = vq.quantize._codebook
     K = cb.embed.shape[0]
     if getattr(cb, "euclidean", False):
-        if not bool(cb.initted):                             # kmeans_init=True: the first batch initialises the codebook (quantize_lucid.py:271)
+        if not cb.is_initted():                             # kmeans_init=True: the first batch initialises the codebook (quantize_lucid.py:271)
             cb.init_embed_(z[:R], normalize=bool(vq.quantize.norm_latents))
         # Euclidean codebook (norm_codes=False): arg-max of <z, e> - |e|^2 / 2 over the raw codes; norm_latents normalises z first (:525-527)
         splits = max(1, min(16, K // 1024))
@@ -205,7 +205,7 @@ def _assign(vq, eng, z, R, G, B, nh, nw, want_quant):
         L.check(L.vq_assign_bias(ops._p(z), z.stride(0), ops._p(cb.embed), ops._p(cb.code_bias()), ops._p(cb.embed), K, Ld, R, G,
                                  1 if vq.quantize.norm_latents else 0, ops._p(wv), ops._p(wi), splits, ops._p(tokens), ops._p(quant), ops._stream()))
         return (tokens, quant) if want_quant else tokens
-    if not bool(cb.initted):                                 # kmeans_init=True: the first batch initialises the codebook (quantize_lucid.py:394)
+    if not cb.is_initted():                                 # kmeans_init=True: the first batch initialises the codebook (quantize_lucid.py:394)
         cb.init_embed_(z[:R])
     # ONE buffer of l2-normalised codes, recomputed in place when the codebook changed (in training mode every encode() moves the
     # codebook: a cache keyed on its version would keep every past copy alive)

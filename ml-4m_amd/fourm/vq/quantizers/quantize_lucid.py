@@ -8,7 +8,27 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
-class CosineSimCodebook(nn.Module):
+
+class _InittedOnce:
+    """``initted`` is a device buffer (upstream's checkpoint layout) that flips once, on the first training batch of a k-means-initialised
+    codebook.  Reading it costs a host synchronisation - per tokenize call, and impossible under hipGraph capture - so the answer is cached on
+    the host once it is True; loading a state dict or moving the module forgets the cache."""
+
+    def is_initted(self) -> bool:
+        if not self.__dict__.get("_initted_host", False):
+            self.__dict__["_initted_host"] = bool(self.initted)
+        return self.__dict__["_initted_host"]
+
+    def _mark_initted(self):
+        self.initted.fill_(1.0)
+        self.__dict__["_initted_host"] = True
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__["_initted_host"] = False
+        return super()._load_from_state_dict(*args, **kwargs)
+
+
+class CosineSimCodebook(_InittedOnce, nn.Module):
     def __init__(self, dim, codebook_size, kmeans_init=False, kmeans_iters=10, decay=0.8, eps=1e-5, threshold_ema_dead_code=2,
                  code_replacement_policy="batch_random", use_ddp=False, learnable_codebook=False, sample_codebook_temp=0.):
         super().__init__()
@@ -49,7 +69,7 @@ class CosineSimCodebook(nn.Module):
         (fm_vq_assign, fm_vq_code_stats, fm_vq_ema_update with decay 0).  z: f32 (R, d) raw latents."""
         import torch.distributed as dist
         from fourm.hip import _lib as L, ops
-        if bool(self.initted):
+        if self.is_initted():
             return
         multi = self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         z = z.reshape(-1, z.shape[-1]).float().contiguous()
@@ -72,7 +92,7 @@ class CosineSimCodebook(nn.Module):
                 dist.all_reduce(bins)
                 dist.all_reduce(sums)
             L.check(L.vq_ema_update(ops._p(bins), ops._p(sums), ops._p(self.embed), ops._p(self.cluster_size), K, D, 0.0, ops._stream()))
-        self.initted.fill_(1.0)
+        self._mark_initted()
         self.epoch += 1
 
     @torch.no_grad()
@@ -83,7 +103,7 @@ class CosineSimCodebook(nn.Module):
         z: f32 (R, d) latents as fed to the quantizer; tokens: int64 (R)."""
         import torch.distributed as dist
         from fourm.hip import _lib as L, ops
-        if not bool(self.initted):
+        if not self.is_initted():
             raise RuntimeError("the codebook is not initialised: init_embed_ runs in front of the first code assignment")
         z = z.reshape(-1, z.shape[-1])
         if z.dtype != torch.float32 or z.stride(1) != 1:
@@ -120,7 +140,7 @@ class CosineSimCodebook(nn.Module):
         return bins
 
 
-class EuclideanCodebook(nn.Module):
+class EuclideanCodebook(_InittedOnce, nn.Module):
     """Nearest code by Euclidean distance, EMA codebook (upstream ``EuclideanCodebook``, quantize_lucid.py:181-301; ``VectorQuantize(use_cosine_sim=False)``
     = ``VQ(norm_codes=False)``).  Same buffers as upstream (``initted``, ``cluster_size``, ``embed_avg``, ``embed``), so checkpoints load.
     Kernels: fm_vq_assign_bias with the bias -|e|^2 / 2 (arg-max of <z, e> - |e|^2 / 2 = arg-min of |z - e|^2), fm_vq_code_stats_raw,
@@ -154,7 +174,7 @@ class EuclideanCodebook(nn.Module):
         kernels (fm_vq_assign_bias, fm_vq_code_stats[_raw]).  z: f32 (R, d) latents (normalize: ``norm_latents`` models quantize l2norm(z))."""
         import torch.distributed as dist
         from fourm.hip import _lib as L, ops
-        if bool(self.initted):
+        if self.is_initted():
             return
         multi = self.use_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         z = z.reshape(-1, z.shape[-1]).float().contiguous()
@@ -190,7 +210,7 @@ class EuclideanCodebook(nn.Module):
         self.embed.copy_(means)
         self.embed_avg.copy_(means)
         self.cluster_size.copy_(bins)
-        self.initted.fill_(1.0)
+        self._mark_initted()
         self.epoch += 1
 
     @torch.no_grad()
