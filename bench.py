@@ -600,6 +600,9 @@ def main_divae(a):
                            "avg_launch_us": 1e3 * d["ms"] / d["n"], "share_of_timed_kernels": d["ms"] / tot_ms,
                            "algorithmic_bytes_per_launch": d["bytes"] / d["n"] if d["bytes"] else None}
         out["kernel_breakdown_ms_per_evaluation"] = {k: round(v["ms"] / 2, 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if os.environ.get("BENCH_SHAPE_TABLE"):
+            with open(os.environ["BENCH_SHAPE_TABLE"], "w") as fh:
+                fh.write("\n".join(prof.shape_table(2)) + "\n")
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

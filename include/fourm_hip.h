@@ -66,6 +66,11 @@ typedef struct fm_gemm_nt_args {
      * row counts (FourM.forward_logits, fm.py:521-545).  FM_EPI_BF16 without bias, ldo % 64 == 0, out 128-byte aligned, N % 8 == 0,
      * K % 64 == 0; other arguments are rejected. */
     const int32_t* m_dev; const int32_t* row0_dev;
+    /* Scratch for split-K (ABI 8; optional, NULL = never split): a dense FM_EPI_BF16 launch whose output has too few tiles for the chip
+     * (small M x N, long K: the convolutions of the DiVAE UNet at its coarse levels) is cut into up to 16 K-slices that write fp32 partial
+     * tiles here (slices x M x roundup4(N) x 4 bytes are needed; a smaller buffer means fewer slices or none), followed by one reduction
+     * pass (sum of the slices + bias -> bf16).  The buffer is dead when the call's work has run; calls on one stream may share it. */
+    void* splitk_ws; int64_t splitk_ws_bytes;
 } fm_gemm_nt_args;
 int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
 /* tile configuration of fm_gemm_nt, for A/B measurements (table in csrc/gemm.hip): low byte 0-8 = fixed

@@ -16,6 +16,7 @@
 //   * leading dimensions are multiples of 8 elements (16-byte aligned rows).
 #include <type_traits>
 #include <cstdlib>
+#include <algorithm>
 #include "common.h"
 #include "fourm_hip.h"
 #include "gemm_args.h"
@@ -86,6 +87,14 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     } else {
         const int tile = xcd_remap(blockIdx.x, a.n_tiles_w * a.n_tiles_x);
         tx = tile / a.n_tiles_w; tw = tile % a.n_tiles_w;         // W tiles fastest: X tile shared in L2
+    }
+    if constexpr (EPI == EPI_F32 && !GROUPED && !PERSIST) {
+        if (a.split_k > 1) {          // K-slice blockIdx.y of a split launch: its own operand columns, its own fp32 partial output
+            const int z = blockIdx.y, k0 = z * a.k_slice;
+            a.W += k0; a.X += k0;
+            a.K = min(a.k_slice, a.K - k0);
+            a.out = (float*)a.out + (size_t)z * (size_t)a.split_stride;
+        }
     }
     const bf16_t* Wp = a.W;
     int N = a.N, K = a.K, ldw = a.ldw;
@@ -1088,7 +1097,8 @@ int g_nt_config = 9, g_nt_prio = 1;
 // 1 = 256-wide tiles, 2 = 192-wide, 3 = by shape: the default; FOURM_NT3=0 turns it off), [3] gemm_nt3 experiment flags
 int g_lab[16] = {0, 0, [] { const char* e = getenv("FOURM_NT3"); return e ? atoi(e) : 3; }(), [] { const char* e = getenv("FOURM_NT3_LAB"); return e ? atoi(e) : 0; }(),
                  [] { const char* e = getenv("FOURM_NT4"); return e ? atoi(e) : 1; }(),       // [4] gemm_nt4 mode (gemm_nt4.hip; FOURM_NT4=0 turns it off)
-                 [] { const char* e = getenv("FOURM_TN4"); return e ? atoi(e) : 0; }()};      // [5] gemm_tn4.hip for the dW job lists (FOURM_TN4=1 turns it on; [6] its lab flags, [7] / [8] its planner constants)
+                 [] { const char* e = getenv("FOURM_TN4"); return e ? atoi(e) : 0; }(), 0, 0, 0,
+                 [] { const char* e = getenv("FOURM_NT_SMALL"); return e ? atoi(e) : 1; }()};      // [9] small-grid policy of fm_gemm_nt (128 x 128 tiles / split-K; FOURM_NT_SMALL=0: off)      // [5] gemm_tn4.hip for the dW job lists (FOURM_TN4=1 turns it on; [6] its lab flags, [7] / [8] its planner constants)
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
@@ -1130,9 +1140,25 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED, PP, PERSIST>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(WW * WX * 64), lds, s, a);
+    hipLaunchKernelGGL(k, dim3(grid, a.split_k > 1 ? a.split_k : 1), dim3(WW * WX * 64), lds, s, a);
     FM_CHECK_LAUNCH("fm_gemm_nt");
     return 0;
+}
+
+// out(bf16)[m][n] = bf16(sum over the K-slices of partial[z][m][n] + bf16(bias[n])): the second pass of a split-K launch
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long stride, int M, int N4, int ldp, const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ out, int ldo) {
+    const long long total = (long long)M * N4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int m = (int)(e / N4), n = (int)(e % N4) * 4;
+        float4 acc = *(const float4*)(ws + (size_t)m * ldp + n);
+        for (int z = 1; z < S; ++z) {
+            const float4 t = *(const float4*)(ws + (size_t)z * stride + (size_t)m * ldp + n);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        if (bias) { const float4 b = *(const float4*)(bias + n); acc.x += bfround(b.x); acc.y += bfround(b.y); acc.z += bfround(b.z); acc.w += bfround(b.w); }
+        *(uint2*)(out + (size_t)m * ldo + n) = make_uint2(pack2bf(acc.x, acc.y), pack2bf(acc.z, acc.w));
+    }
 }
 
 // Tile configurations (fm_set_gemm_nt_config):
@@ -1234,6 +1260,40 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
         const int r = fm_launch_nt_skinny(a, p->epilogue, s);
         if (r < 0) { fm_set_error("fm_gemm_nt (skinny): launch failed"); return -2; }
         if (r > 0) return 0;
+    }
+    // Small grids (FOURM_NT_SMALL=0 / fm_lab_set(9, 0): off): a dense bf16 launch whose 256 x 256 tiling would occupy less than half of the CUs
+    // (the convolutions of the DiVAE UNet: M = batch x 56^2 ... batch x 7^2 rows, N = 256 / 512, K up to 9216) runs on 128 x 128 tiles; when
+    // even those leave half of the chip idle and the reduction is long, K is cut into slices on gridDim.y (fp32 partial tiles in the caller's
+    // scratch, fm_gemm_nt_args.splitk_ws) and one reduction pass adds the bias and rounds: M = 392, N = 512, K = 4608: 64 -> ~15 us.
+    if (!grouped && g_lab[9] && p->epilogue == FM_EPI_BF16 && p->M > 32 && !p->out2 && !p->res && p->N % 4 == 0 && (((uintptr_t)p->out) & 7) == 0) {
+        const int cus = n_compute_units();
+        const long t256 = (long)((p->M + 255) / 256) * ((p->N + 255) / 256);
+        if (t256 * 2 <= cus) {
+            const long t128 = (long)((p->M + 127) / 128) * ((p->N + 127) / 128);
+            const int kt = p->K / 64;
+            int S = 1;
+            const long ldp = (p->N + 3) / 4 * 4;
+            if (p->splitk_ws && t128 * 2 <= cus && kt >= 8 && p->K % 64 == 0 && (((uintptr_t)p->splitk_ws) & 15) == 0) {
+                S = (int)std::min<long>({cus / t128, (long)kt / 4, 16L, (long)(p->splitk_ws_bytes / ((long long)p->M * ldp * 4))});
+            }
+            if (S >= 2) {
+                const int ks = (kt + S - 1) / S * 64;             // K elements per slice (whole K-tiles); the last slice may be shorter
+                S = (p->K + ks - 1) / ks;
+                NTArgs b = a;
+                b.out = p->splitk_ws; b.ldo = (int)ldp; b.bias = nullptr;
+                b.split_k = S; b.k_slice = ks; b.split_stride = (long long)p->M * ldp;
+                const int r = launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI_F32, false>(b, max_n, s);
+                if (r != 0) return r;
+                const long long quads = (long long)p->M * (ldp / 4);
+                const int rgrid = (int)std::min<long long>((quads + 255) / 256, 2048);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)p->splitk_ws, S, b.split_stride, p->M, (int)(ldp / 4), (int)ldp,
+                                   (const float*)p->bias, (bf16_t*)p->out, p->ldo);
+                FM_CHECK_LAUNCH("fm_gemm_nt (split-K reduction)");
+                return 0;
+            }
+            if (p->K >= 1536) return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI_BF16, false>(a, max_n, s);
+            return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI_BF16, false>(a, max_n, s);
+        }
     }
     if (!grouped && g_lab[4]) {               // the 4-wave 256 x 384-tile kernel (gemm_nt4.hip) takes the plain bf16 launches it tiles exactly
         const int r = fm_launch_nt4(a, p->epilogue, g_lab[4], s);

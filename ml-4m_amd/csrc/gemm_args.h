@@ -19,6 +19,7 @@ struct NTArgs {
     int prio;                                             // raise the wave priority around the MFMA clusters
     int dephase_groups, dephase_step;                     // experiment (fm_lab_set): staggered workgroup start
     int reverse;                                          // gemm_nt3: tiles from the last row block to the first - a consumer that starts with the rows its producer wrote LAST finds them in the Infinity Cache (LRU: a forward walk over more than 256 MB of freshly written data meets the oldest, evicted, rows first)
+    int split_k, k_slice; long long split_stride;         // gemm_nt_kernel with FM_EPI_F32 on gridDim.y = split_k K-slices of k_slice elements: slice z writes fp32 partials at out + z * split_stride
     int lab;                                              // experiment flags of gemm_nt3 (fm_lab_set 3): 1 no wait for the DMA, 2 no DMA, 4 no stores, 16 all DMA pieces in one k-step, 256 take the residual epilogue
 };
 

@@ -155,6 +155,59 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     }
 }
 
+// One launch for the whole GroupNorm when there are enough (sample, group) pairs to fill the chip: workgroup (g, b) owns the HW x cpg values of
+// its group - three sweeps over data that stays in the L2 (sum -> mean; squared deviations -> rstd; normalise, affine, SiLU, store).  The
+// three-kernel form above costs three ~11 us launches per norm, 76 norms per UNet evaluation; it stays for small batches (B * G < 64), where
+// its row chunks give more workgroups.
+__global__ __launch_bounds__(256) void gn_fused_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ add, int ld_add, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, int HW, int C, int G, int silu, float eps) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cpg = C / G, qpr = cpg / 4;                 // quads (4 channels = 8 bytes) per row of the group
+    const int rows_per_it = 256 / qpr;                    // cpg in {4, 8, 16, 32, ...}: qpr divides 256 (checked by the launcher)
+    const int rl = threadIdx.x / qpr, c0 = g * cpg + (threadIdx.x % qpr) * 4;
+    const bf16_t* xb = x + (size_t)b * HW * ldx + c0;
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+    if (add) { const float4 t = *(const float4*)(add + (size_t)b * ld_add + c0); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    const float inv_n = 1.0f / ((float)HW * (float)cpg);
+    float s = 0.f;
+    for (int r = rl; r < HW; r += rows_per_it) {
+        float f[4];
+        unpack_bf4(*(const uint2*)(xb + (size_t)r * ldx), f);
+        s += (f[0] + av[0]) + (f[1] + av[1]) + (f[2] + av[2]) + (f[3] + av[3]);
+    }
+    const float mean = block_sum(s) * inv_n;
+    float q = 0.f;
+    for (int r = rl; r < HW; r += rows_per_it) {
+        float f[4];
+        unpack_bf4(*(const uint2*)(xb + (size_t)r * ldx), f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = f[j] + av[j] - mean; q += d * d; }
+    }
+    const float rstd = rsqrtf(block_sum(q) * inv_n + eps);
+    const float4 wv = *(const float4*)(w + c0), bv = *(const float4*)(bias + c0);
+    const float ws[4] = {wv.x * rstd, wv.y * rstd, wv.z * rstd, wv.w * rstd}, bs[4] = {bv.x, bv.y, bv.z, bv.w};
+    bf16_t* yb = y + (size_t)b * HW * ldy + c0;
+    for (int r = rl; r < HW; r += rows_per_it) {
+        float f[4], o[4];
+        unpack_bf4(*(const uint2*)(xb + (size_t)r * ldx), f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = (f[j] + av[j] - mean) * ws[j] + bs[j];
+            if (silu) t = t / (1.0f + __expf(-t));
+            o[j] = t;
+        }
+        *(uint2*)(yb + (size_t)r * ldy) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+    }
+}
+
 // out = a + b (bf16 feature maps: skip_connection(x) + h, x + attention)
 __global__ __launch_bounds__(256) void add_bf16_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, bf16_t* __restrict__ out, int ldo,
                                                        long long rows, int C) {
@@ -354,6 +407,14 @@ extern "C" int fm_groupnorm_nhwc(const void* x, int ldx, const void* add, int ld
     FM_CHECK_ARG(x && w && b && y && stats && B > 0 && HW > 0 && C > 0 && groups > 0, "fm_groupnorm_nhwc: bad argument");
     FM_CHECK_ARG(C % groups == 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "fm_groupnorm_nhwc: C=%d groups=%d (C %% groups == 0, C %% 4 == 0)", C, groups);
     FM_CHECK_ARG(C <= 1024 && groups <= 256, "fm_groupnorm_nhwc: C=%d groups=%d (C <= 1024)", C, groups);
+    static const int fused_env = [] { const char* e = getenv("FOURM_GN_FUSED"); return e ? atoi(e) : 1; }();
+    const int cpg = C / groups;
+    if (fused_env && B * groups >= 64 && cpg % 4 == 0 && 256 % (cpg / 4) == 0 && (!add || ld_add % 4 == 0)) {
+        hipLaunchKernelGGL(gn_fused_kernel, dim3(groups, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (const float*)add, ld_add, (const float*)w,
+                           (const float*)b, (bf16_t*)y, ldy, HW, C, groups, silu, eps);
+        FM_CHECK_LAUNCH("fm_groupnorm_nhwc");
+        return 0;
+    }
     const int chunks = (HW + GN_ROWS - 1) / GN_ROWS;
     float* partial = (float*)stats + (size_t)B * groups * 2;                   // scratch layout: [B][G][2] sums, then [B][chunks][G][2] partials
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * chunks), dim3(256), (size_t)(256 / (C / 4)) * C * 2 * sizeof(float), (hipStream_t)stream, (const bf16_t*)x, ldx,

@@ -75,6 +75,18 @@ def _ld(t: torch.Tensor) -> int:
 # ---------------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------------
+# split-K scratch of fm_gemm_nt (fm_gemm_nt_args.splitk_ws): one fp32 buffer per device, shared by every launch (stream order)
+SPLITK_MAX_OUT = 128 * 128 * 128          # outputs of up to 128 tiles of 128 x 128 can be split (the kernel decides)
+_SPLITK_WS = {}
+
+
+def _splitk_ws(device):
+    t = _SPLITK_WS.get(device)
+    if t is None:
+        t = _SPLITK_WS[device] = torch.empty(16 * SPLITK_MAX_OUT, dtype=torch.float32, device=device)      # 128 MB: 16 slices of the largest output
+    return t
+
+
 def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bias2=None, out2=None, Hp=0, N=None, K=None, M=None):
     """out[m][n] = sum_k x[m][k] w[n][k] (+ epilogue).  x: bf16 (M, >=K); w: bf16 (N, >=K).
     fp32 operands select the verification kernel (any strides for w)."""
@@ -90,6 +102,9 @@ def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bia
     a.ldo2 = _ld(out2) if out2 is not None else 0
     a.ldr = _ld(res) if res is not None else 0
     a.Hp, a.epilogue = Hp, epilogue
+    if epilogue == L.EPI_BF16 and a.M * a.N <= SPLITK_MAX_OUT and a.K >= 512:       # (only launches that can be split need the scratch)
+        ws = _splitk_ws(x.device)
+        a.splitk_ws, a.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     two = 2 if epilogue == L.EPI_SWIGLU else 1
     nbytes = 2.0 * a.K * (a.M + two * a.N) + a.M * a.N * two * out.element_size()        # operands once + output once
     nbytes += (a.M * a.N * 4.0 if res is not None and epilogue in (L.EPI_RESIDUAL, L.EPI_F32) else 0.0) + (a.M * a.N * 4.0 if out2 is not None else 0.0)

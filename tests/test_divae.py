@@ -122,6 +122,48 @@ def _small_net():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,HW,C,silu,with_add", [(1, 196, 256, True, True), (4, 3136, 256, True, False), (8, 784, 512, True, True), (2, 49, 1024, False, True),
+                                                   (8, 196, 128, True, True), (3, 50, 512, False, False)])
+def test_groupnorm_nhwc_both_forms(B, HW, C, silu, with_add):
+    """fm_groupnorm_nhwc on bf16 NHWC rows (+ a per-sample per-channel addend in front: GroupNorm32(h + emb), unet.py:230-246) against
+    F.group_norm in fp32: the three-kernel form (B * groups < 64) and the one-launch form (workgroup = one (sample, group))."""
+    from fourm.hip import _lib as L, ops
+    torch.manual_seed(B * 1000 + HW + C)
+    G = 32
+    x = (torch.randn(B * HW, C, device="cuda") * 1.5 + 0.7).bfloat16()
+    add = torch.randn(B, C, device="cuda") if with_add else None
+    w, b = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.2
+    y = torch.zeros(B * HW, C, device="cuda", dtype=torch.bfloat16)
+    st = torch.zeros(B * G * ((HW + 31) // 32 + 1) * 2, device="cuda")
+    L.check(L.groupnorm_nhwc(ops._p(x), C, ops._p(add), C if with_add else 0, ops._p(w), ops._p(b), ops._p(y), C, ops._p(st), B, HW, C, G, 1e-5, 1 if silu else 0, ops._stream()))
+    xin = x.float().view(B, HW, C) + (add[:, None, :] if with_add else 0.0)
+    ref = torch.nn.functional.group_norm(xin.permute(0, 2, 1), G, w, b, 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = torch.nn.functional.silu(ref)
+    err = float((y.float().view(B, HW, C) - ref).abs().max())
+    assert err <= 2 ** -7 * float(ref.abs().max()), (err, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,heads,ch", [(8, 196, 1, 512), (8, 49, 1, 512), (2, 30, 2, 64), (4, 200, 2, 128)])
+def test_unet_attention(B, T, heads, ch):
+    """fm_unet_attention (QKVAttentionLegacy, unet.py:329-358: per head [q | k | v] channel blocks, scale ch^-1/4 on q and k, fp32 softmax) against a
+    torch restatement.  (An eight-queries-per-workgroup variant was measured in round 6: 157 us against 49 us per call at batch 8, T = 196, ch = 512 -
+    both forms pay one LDS read per multiply-add, and the one-query form has 8 x the workgroups to hide it; dropped.)"""
+    from fourm.hip import _lib as L, ops
+    torch.manual_seed(T + ch)
+    qkv = torch.randn(B * T, heads * 3 * ch, device="cuda").bfloat16()
+    out = torch.zeros(B * T, heads * ch, device="cuda", dtype=torch.bfloat16)
+    L.check(L.unet_attention(ops._p(qkv), qkv.stride(0), ops._p(out), out.stride(0), B, T, heads, ch, ops._stream()))
+    x = qkv.float().view(B, T, heads, 3, ch)
+    q, k, v = x[:, :, :, 0], x[:, :, :, 1], x[:, :, :, 2]
+    w = torch.softmax(torch.einsum("bthc,bshc->bhts", q, k) / ch ** 0.5, dim=-1)
+    ref = torch.einsum("bhts,bshc->bthc", w, v).reshape(B * T, heads * ch)
+    err = float((out.float() - ref).abs().max())
+    assert err <= 2 ** -7 * float(ref.abs().max()) + 1e-3, (err, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
 def test_hip_unet_matches_upstream_fixture():
     """One evaluation of the conditional UNet (per-sample timesteps, conditioning mask, integer timestep): bf16 GEMM operands / fp32
     accumulation against upstream's fp32 run."""

@@ -305,6 +305,34 @@ def test_gemm_tn_masks_rows_past_R(cfg, R, Rbuf):
         L.lib.fm_set_gemm_tn_config(TN_DEFAULT)
 
 
+@pytest.mark.parametrize("M,N,K,bias", [(392, 512, 4608, True), (1568, 512, 9216, True), (392, 512, 512, False), (6272, 512, 4608, True),
+                                        (25088, 256, 2304, True), (200, 132, 1024, True), (1568, 1536, 512, False), (392, 512, 4672, True)])
+def test_gemm_nt_small_grids(M, N, K, bias):
+    """Small-grid policy of fm_gemm_nt: a dense bf16 launch whose 256 x 256 tiling leaves more than half of the CUs idle runs on 128 x 128 tiles,
+    and with a long reduction as K-slices on gridDim.y + one reduction pass (split-K, fp32 partials in the scratch the caller lends).  Against an
+    fp32 matmul of the same bf16 operands; against the launch with the policy off the outputs agree to a bf16 rounding (summation order)."""
+    ops, L = _ops()
+    x = bf(randn(M + 3, K, seed=60))[:M]
+    w = bf(randn(N, K, seed=61) * 0.05)
+    b = randn(N, seed=62) if bias else None
+    ldo = ops.ru(N, 64)
+    ref = x.float() @ w.float().t() + (bf(b).float() if bias else 0.0)
+    outs = {}
+    for small in (1, 0):
+        L.lib.fm_lab_set(9, small)
+        try:
+            for _ in range(2):
+                out = torch.full((M, ldo), 7.0, device=DEV, dtype=torch.bfloat16)
+                ops.gemm_nt(x, w, out, bias=b, M=M, N=N, K=K)
+        finally:
+            L.lib.fm_lab_set(9, 1)
+        assert max_err(out[:, :N], bf(ref)) <= 2 ** -7 * float(ref.abs().max()), (small, max_err(out[:, :N], bf(ref)))
+        if N < ldo:
+            assert bool((out[:, ops.ru(N, 4):] == 7.0).all())          # columns past roundup4(N) untouched
+        outs[small] = out[:, :N].float()
+    assert rel_err(outs[1], outs[0]) < 2e-3
+
+
 TN_DEFAULT = 1
 TN_MULTI_LISTS = {
     # (R, N, K) per job
