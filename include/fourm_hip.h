@@ -71,6 +71,13 @@ typedef struct fm_gemm_nt_args {
      * tiles here (slices x M x roundup4(N) x 4 bytes are needed; a smaller buffer means fewer slices or none), followed by one reduction
      * pass (sum of the slices + bias -> bf16).  The buffer is dead when the call's work has run; calls on one stream may share it. */
     void* splitk_ws; int64_t splitk_ws_bytes;
+    /* Implicit 3 x 3 convolution (ABI 8; conv_C = 0: off).  X is then a bf16 feature map in rows, (B, conv_H >> conv_up, conv_W >> conv_up, conv_C)
+     * with row stride ldx, read at (y >> conv_up, x >> conv_up) (conv_up = 1: the nearest x2 up-sampling in front of the convolution); the launch
+     * computes out[(b, oy, ox)][n] = sum over tap, c of in[b][oy stride + tap / 3 - 1][ox stride + tap % 3 - 1][c] W[n][tap conv_C + c] (zero
+     * padding) on a (conv_Ho, conv_Wo) output grid: M = B conv_Ho conv_Wo, K = 9 conv_C, conv_C % 64 == 0, conv_stride 1 | 2 - exactly
+     * fm_unet_im2col + the plain launch (bit-identical), without writing the 9 x expanded rows.  FM_EPI_BF16 (may be split over K like any
+     * small launch) or FM_EPI_F32, dense, no residual / second output. */
+    int32_t conv_C, conv_H, conv_W, conv_Ho, conv_Wo, conv_stride, conv_up, conv_pad_;
 } fm_gemm_nt_args;
 int fm_gemm_nt(const fm_gemm_nt_args* args, void* stream);
 /* tile configuration of fm_gemm_nt, for A/B measurements (table in csrc/gemm.hip): low byte 0-8 = fixed

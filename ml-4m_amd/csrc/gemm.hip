@@ -49,7 +49,14 @@ constexpr int BK = 64;           // reduction elements per LDS stage
 // of a tile is retired before the last barrier both wave rows pass), so that latency and the workgroup relaunch
 // disappear under the stores.  The first wait of such a tile is a full vmcnt(0): the wave's own epilogue stores are
 // younger than those loads and vmcnt only promises order among loads.
-template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false, bool PERSIST = false>
+// (a 16-byte block of zeros: the source of LDS-DMA pieces that must contribute nothing - reduction rows past the live count of the TN kernels,
+// taps outside the image of the implicit convolution)
+__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// CONV (dense, not persistent): the X operand is gathered - see NTArgs::conv_*: row t of the tile is an output pixel, K-tile kt lies inside ONE
+// tap (conv_C % KB == 0) and reads KB channels of the input pixel that tap selects, or zeros.  Everything else (LDS layout, main loop, epilogues,
+// the K-slices of a split launch) is the plain kernel's: the result is bit-identical to fm_unet_im2col + the plain launch.
+template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false, bool PERSIST = false, bool CONV = false>
 __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     constexpr int NWAVES = WW * WX;
     constexpr int RB = KB * 2;                                 // bytes per LDS row
@@ -88,10 +95,12 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         const int tile = xcd_remap(blockIdx.x, a.n_tiles_w * a.n_tiles_x);
         tx = tile / a.n_tiles_w; tw = tile % a.n_tiles_w;         // W tiles fastest: X tile shared in L2
     }
+    int conv_k0 = 0;                                          // CONV: first reduction index of this launch / K-slice
     if constexpr (EPI == EPI_F32 && !GROUPED && !PERSIST) {
         if (a.split_k > 1) {          // K-slice blockIdx.y of a split launch: its own operand columns, its own fp32 partial output
             const int z = blockIdx.y, k0 = z * a.k_slice;
-            a.W += k0; a.X += k0;
+            a.W += k0;
+            if constexpr (CONV) conv_k0 = k0; else a.X += k0;
             a.K = min(a.k_slice, a.K - k0);
             a.out = (float*)a.out + (size_t)z * (size_t)a.split_stride;
         }
@@ -112,6 +121,9 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
     constexpr int PW = TW / (RPP * NWAVES), PX = TX / (RPP * NWAVES);
     const bf16_t* wsrc[PW];
     const bf16_t* xsrc[PX];
+    int cv_y[CONV ? PX : 1], cv_x[CONV ? PX : 1];         // CONV: input coordinates of tap (0, 0) for the piece's output pixel
+    int cs_c0 = 0, cs_ky = 0, cs_kx = 0;                   // CONV: first channel and tap of the K-tile staged next
+    if constexpr (CONV) { const int tap = conv_k0 / a.conv_C; cs_c0 = conv_k0 - tap * a.conv_C; cs_ky = tap / 3; cs_kx = tap - cs_ky * 3; }
     auto set_sources = [&]() {
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
@@ -133,8 +145,19 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
             const int t = (p * NWAVES + wave) * RPP + lane / CPR;
             const int lc = (lane % CPR) ^ ((t >> SWSH) & (CPR - 1));
             int m = m0 + t;
-            m = m < a.M ? m : a.M - 1;
-            xsrc[p] = a.X + (size_t)m * a.ldx + lc * 8;
+            if constexpr (CONV) {
+                const bool live = m < a.M;
+                m = live ? m : a.M - 1;
+                const int hw = a.conv_Ho * a.conv_Wo, b = m / hw, r = m - b * hw, oy = r / a.conv_Wo, ox = r - oy * a.conv_Wo;
+                cv_y[p] = live ? oy * a.conv_stride - 1 : -(1 << 20);          // (a dead row never passes the bounds test)
+                cv_x[p] = ox * a.conv_stride - 1;
+                xsrc[p] = a.X + (size_t)b * (a.conv_H >> a.conv_up) * (a.conv_W >> a.conv_up) * a.ldx + lc * 8;
+                // no up-sampling: the pixel of tap (ky, kx) is (ky W + kx) rows behind the pixel of tap (0, 0) - a uniform offset per K-tile
+                if (!a.conv_up) xsrc[p] += ((long long)cv_y[p] * a.conv_W + cv_x[p]) * a.ldx;
+            } else {
+                m = m < a.M ? m : a.M - 1;
+                xsrc[p] = a.X + (size_t)m * a.ldx + lc * 8;
+            }
         }
     };
     set_sources();
@@ -142,6 +165,16 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[p] + kt * KB), LDS_PTR(smem + buf * STAGE + (p * NWAVES + wave) * 1024), 16, 0, 0);
     };
     auto stage_x = [&](int kt, int buf, int p) {
+        if constexpr (CONV) {
+            const int c0 = cs_c0, ky = cs_ky, kx = cs_kx;     // (the K-tiles of a launch are staged in order: the tap advances with them, no division per K-tile)
+            const int y = cv_y[p] + ky, x = cv_x[p] + kx;
+            const bool in = (unsigned)y < (unsigned)a.conv_H && (unsigned)x < (unsigned)a.conv_W;
+            const bf16_t* src;
+            if (!a.conv_up) src = xsrc[p] + ((long long)(ky * a.conv_W + kx) * a.ldx + c0);          // (uniform offset: scalar arithmetic)
+            else src = xsrc[p] + (size_t)((y >> 1) * (a.conv_W >> 1) + (x >> 1)) * a.ldx + c0;
+            src = in ? src : (const bf16_t*)g_zero16;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(smem + buf * STAGE + TW * RB + (p * NWAVES + wave) * 1024), 16, 0, 0);
+        } else
         __builtin_amdgcn_global_load_lds(GLB_PTR(xsrc[p] + kt * KB), LDS_PTR(smem + buf * STAGE + TW * RB + (p * NWAVES + wave) * 1024), 16, 0, 0);
     };
     auto stage = [&](int kt, int buf) {
@@ -149,6 +182,10 @@ __global__ __launch_bounds__(WW * WX * 64) void gemm_nt_kernel(NTArgs a) {
         for (int p = 0; p < PW; ++p) stage_w(kt, buf, p);
 #pragma unroll
         for (int p = 0; p < PX; ++p) stage_x(kt, buf, p);
+        if constexpr (CONV) {                               // next K-tile: KB channels further, or the next tap
+            cs_c0 += KB;
+            if (cs_c0 == a.conv_C) { cs_c0 = 0; if (++cs_kx == 3) { cs_kx = 0; ++cs_ky; } }
+        }
     };
 
     if (a.dephase_groups > 1) {       // experiment: start the workgroups of a CU / of the chip out of phase (epilogue of one under the main loop of another)
@@ -543,7 +580,6 @@ struct TNArgs {
 // Reduction rows past the live row count contribute nothing: their LDS-DMA pieces are fetched from this 16-byte zero block
 // instead of the operand (the caller's buffers need no zeroed padding rows, and a workspace reused with fewer live rows
 // cannot leak stale rows into a weight gradient).
-__device__ __attribute__((aligned(16))) const uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
 
 // element (row, col) of a row-major [64][cols] bf16 LDS tile with RB bytes per row; 16-byte chunks are
 // XOR-swizzled by (row & 3) << 2 so that the 4 rows a transpose read touches fall on different banks
@@ -1098,7 +1134,8 @@ int g_nt_config = 9, g_nt_prio = 1;
 int g_lab[16] = {0, 0, [] { const char* e = getenv("FOURM_NT3"); return e ? atoi(e) : 3; }(), [] { const char* e = getenv("FOURM_NT3_LAB"); return e ? atoi(e) : 0; }(),
                  [] { const char* e = getenv("FOURM_NT4"); return e ? atoi(e) : 1; }(),       // [4] gemm_nt4 mode (gemm_nt4.hip; FOURM_NT4=0 turns it off)
                  [] { const char* e = getenv("FOURM_TN4"); return e ? atoi(e) : 0; }(), 0, 0, 0,
-                 [] { const char* e = getenv("FOURM_NT_SMALL"); return e ? atoi(e) : 1; }()};      // [9] small-grid policy of fm_gemm_nt (128 x 128 tiles / split-K; FOURM_NT_SMALL=0: off)      // [5] gemm_tn4.hip for the dW job lists (FOURM_TN4=1 turns it on; [6] its lab flags, [7] / [8] its planner constants)
+                 [] { const char* e = getenv("FOURM_NT_SMALL"); return e ? atoi(e) : 1; }(),
+                 [] { const char* e = getenv("FOURM_CONV_K32"); return e ? atoi(e) : 1; }()};     // [10] implicit convolutions on K-step 32 (48 KB of LDS: 3 workgroups per CU cover the gather's address arithmetic; FOURM_CONV_K32=0: K-step 64)      // [9] small-grid policy of fm_gemm_nt (128 x 128 tiles / split-K; FOURM_NT_SMALL=0: off)      // [5] gemm_tn4.hip for the dW job lists (FOURM_TN4=1 turns it on; [6] its lab flags, [7] / [8] its planner constants)
 int g_nt_swiglu = 12;
 int g_nt_auto[2] = {11, 10};        // automatic choice: short reductions / long ones (K >= 1536) and the reading epilogues
 
@@ -1120,7 +1157,7 @@ static int n_compute_units() {
 int fm_grid_cus() { return n_compute_units(); }      // (gemm_nt3.hip sizes its persistent grid with the same reservation)
 namespace {
 
-template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false, bool PERSIST = false>
+template <int TW, int TX, int WW, int WX, int KB, int STAGES, int EPI, bool GROUPED, bool PP = false, bool PERSIST = false, bool CONV = false>
 int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
     constexpr int NPT = (EPI == EPI_SWIGLU) ? TW / 2 : TW;
     a.n_tiles_w = (max_n + NPT - 1) / NPT;
@@ -1137,7 +1174,7 @@ int launch_nt_cfg(NTArgs a, int max_n, hipStream_t s) {
         const int slots = n_compute_units() * (int)(160 * 1024 / lds) / 8 * 8;
         if (grid > slots) grid = slots;
     }
-    auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED, PP, PERSIST>;
+    auto k = gemm_nt_kernel<TW, TX, WW, WX, KB, STAGES, EPI, GROUPED, PP, PERSIST, CONV>;
     static bool once = (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3(grid, a.split_k > 1 ? a.split_k : 1), dim3(WW * WX * 64), lds, s, a);
@@ -1256,10 +1293,43 @@ extern "C" int fm_gemm_nt(const fm_gemm_nt_args* p, void* stream) {
         return -1;
     }
     const int max_n = grouped ? p->max_N : p->N;
-    if (!grouped && p->M <= 32) {             // a handful of rows (a decoding step): the weight-streaming kernel of gemm_skinny.hip
+    if (!grouped && p->M <= 32 && p->conv_C == 0) {             // a handful of rows (a decoding step): the weight-streaming kernel of gemm_skinny.hip
         const int r = fm_launch_nt_skinny(a, p->epilogue, s);
         if (r < 0) { fm_set_error("fm_gemm_nt (skinny): launch failed"); return -2; }
         if (r > 0) return 0;
+    }
+    a.conv_C = p->conv_C; a.conv_H = p->conv_H; a.conv_W = p->conv_W; a.conv_Ho = p->conv_Ho; a.conv_Wo = p->conv_Wo; a.conv_stride = p->conv_stride; a.conv_up = p->conv_up;
+    if (p->conv_C > 0) {          // implicit 3 x 3 convolution: the gathering instantiation of the 128 x 128 kernel, split over K when the grid is small
+        FM_CHECK_ARG(!grouped && !p->m_dev && !p->out2 && !p->res && (p->epilogue == FM_EPI_BF16 || p->epilogue == FM_EPI_F32), "fm_gemm_nt (conv): dense FM_EPI_BF16 / FM_EPI_F32 only");
+        FM_CHECK_ARG(p->conv_C % 64 == 0 && p->K == 9 * p->conv_C && (p->conv_stride == 1 || p->conv_stride == 2) && (p->conv_up == 0 || p->conv_up == 1) &&
+                     p->conv_H > 0 && p->conv_W > 0 && p->conv_Ho > 0 && p->conv_Wo > 0 && p->M % (p->conv_Ho * p->conv_Wo) == 0,
+                     "fm_gemm_nt (conv): C=%d K=%d stride=%d up=%d grid %dx%d -> %dx%d M=%d", p->conv_C, p->K, p->conv_stride, p->conv_up, p->conv_H, p->conv_W, p->conv_Ho, p->conv_Wo, p->M);
+        FM_CHECK_ARG(p->conv_Ho == (p->conv_H + 2 - 3) / p->conv_stride + 1 && p->conv_Wo == (p->conv_W + 2 - 3) / p->conv_stride + 1, "fm_gemm_nt (conv): output grid does not match the input grid");
+        if (p->epilogue == FM_EPI_F32) return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI_F32, false, false, false, true>(a, max_n, s);
+        const int cus = n_compute_units();
+        const long t128 = (long)((p->M + 127) / 128) * ((p->N + 127) / 128);
+        const int kt = p->K / 64;
+        const long ldp = (p->N + 3) / 4 * 4;
+        int S = 1;
+        if (g_lab[9] && p->splitk_ws && t128 * 2 <= cus && p->N % 4 == 0 && (((uintptr_t)p->splitk_ws) & 15) == 0 && (((uintptr_t)p->out) & 7) == 0)
+            S = (int)std::min<long>({cus / t128, (long)kt / 4, 16L, (long)(p->splitk_ws_bytes / ((long long)p->M * ldp * 4))});
+        if (S >= 2) {
+            const int ks = (kt + S - 1) / S * 64;
+            S = (p->K + ks - 1) / ks;
+            NTArgs b = a;
+            b.out = p->splitk_ws; b.ldo = (int)ldp; b.bias = nullptr;
+            b.split_k = S; b.k_slice = ks; b.split_stride = (long long)p->M * ldp;
+            const int r = launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI_F32, false, false, false, true>(b, max_n, s);
+            if (r != 0) return r;
+            const long long quads = (long long)p->M * (ldp / 4);
+            const int rgrid = (int)std::min<long long>((quads + 255) / 256, 2048);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, s, (const float*)p->splitk_ws, S, b.split_stride, p->M, (int)(ldp / 4), (int)ldp,
+                               (const float*)p->bias, (bf16_t*)p->out, p->ldo);
+            FM_CHECK_LAUNCH("fm_gemm_nt (conv, split-K reduction)");
+            return 0;
+        }
+        if (g_lab[10]) return launch_nt_cfg<128, 128, 2, 2, 32, 3, EPI_BF16, false, false, false, true>(a, max_n, s);      // K-step 32, 48 KB of LDS = 3 workgroups per CU (43.3 -> 44.6 images/s)
+        return launch_nt_cfg<128, 128, 2, 2, 64, 3, EPI_BF16, false, false, false, true>(a, max_n, s);
     }
     // Small grids (FOURM_NT_SMALL=0 / fm_lab_set(9, 0): off): a dense bf16 launch whose 256 x 256 tiling would occupy less than half of the CUs
     // (the convolutions of the DiVAE UNet: M = batch x 56^2 ... batch x 7^2 rows, N = 256 / 512, K up to 9216) runs on 128 x 128 tiles; when

@@ -19,6 +19,10 @@ struct NTArgs {
     int prio;                                             // raise the wave priority around the MFMA clusters
     int dephase_groups, dephase_step;                     // experiment (fm_lab_set): staggered workgroup start
     int reverse;                                          // gemm_nt3: tiles from the last row block to the first - a consumer that starts with the rows its producer wrote LAST finds them in the Infinity Cache (LRU: a forward walk over more than 256 MB of freshly written data meets the oldest, evicted, rows first)
+    // implicit 3 x 3 convolution (gemm_nt_kernel<..., CONV>): X = a (B, conv_H >> conv_up, conv_W >> conv_up, conv_C) bf16 feature map in rows, read at
+    // (y >> conv_up, x >> conv_up); output row m = (b, oy, ox) of a (conv_Ho, conv_Wo) grid; reduction index k = tap * conv_C + c reads
+    // in[b][oy * stride + tap / 3 - 1][ox * stride + tap % 3 - 1][c] (zero outside the (conv_H, conv_W) grid) - fm_unet_im2col's rows without the round trip
+    int conv_C, conv_H, conv_W, conv_Ho, conv_Wo, conv_stride, conv_up;
     int split_k, k_slice; long long split_stride;         // gemm_nt_kernel with FM_EPI_F32 on gridDim.y = split_k K-slices of k_slice elements: slice z writes fp32 partials at out + z * split_stride
     int lab;                                              // experiment flags of gemm_nt3 (fm_lab_set 3): 1 no wait for the DMA, 2 no DMA, 4 no stores, 16 all DMA pieces in one k-step, 256 take the residual epilogue
 };

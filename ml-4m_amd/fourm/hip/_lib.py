@@ -48,7 +48,8 @@ class GemmNTArgs(C.Structure):
     _fields_ = [("W", vp), ("W2", vp), ("X", vp), ("out", vp), ("out2", vp), ("res", vp), ("bias", vp), ("bias2", vp),
                 ("M", i32), ("N", i32), ("K", i32), ("ldw", i32), ("ldx", i32), ("ldo", i32), ("ldo2", i32), ("ldr", i32),
                 ("Hp", i32), ("epilogue", i32), ("groups", vp), ("tile_group", vp), ("max_N", i32), ("pad_", i32),
-                ("m_dev", vp), ("row0_dev", vp), ("splitk_ws", vp), ("splitk_ws_bytes", i64)]
+                ("m_dev", vp), ("row0_dev", vp), ("splitk_ws", vp), ("splitk_ws_bytes", i64),
+                ("conv_C", i32), ("conv_H", i32), ("conv_W", i32), ("conv_Ho", i32), ("conv_Wo", i32), ("conv_stride", i32), ("conv_up", i32), ("conv_pad_", i32)]
 
 
 class GemmTNArgs(C.Structure):

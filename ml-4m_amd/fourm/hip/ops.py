@@ -87,9 +87,11 @@ def _splitk_ws(device):
     return t
 
 
-def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bias2=None, out2=None, Hp=0, N=None, K=None, M=None):
+def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bias2=None, out2=None, Hp=0, N=None, K=None, M=None, conv=None):
     """out[m][n] = sum_k x[m][k] w[n][k] (+ epilogue).  x: bf16 (M, >=K); w: bf16 (N, >=K).
-    fp32 operands select the verification kernel (any strides for w)."""
+    fp32 operands select the verification kernel (any strides for w).
+    conv = dict(C, H, W, Ho, Wo, stride, up): x is a (B, H >> up, W >> up, C) feature map in rows and the launch is the 3 x 3 convolution
+    with the (N, 9 C) weight rows w (taps outermost) as an implicit GEMM (fm_gemm_nt_args.conv_*); M = B Ho Wo and K = 9 C must be given."""
     if x.dtype == torch.float32:
         return _gemm_f32(x, w, out, epilogue=epilogue, bias=bias, res=res, w2=w2, bias2=bias2, out2=out2, Hp=Hp, N=N, K=K, M=M)
     a = L.GemmNTArgs()
@@ -102,6 +104,9 @@ def gemm_nt(x, w, out, *, epilogue=L.EPI_BF16, bias=None, res=None, w2=None, bia
     a.ldo2 = _ld(out2) if out2 is not None else 0
     a.ldr = _ld(res) if res is not None else 0
     a.Hp, a.epilogue = Hp, epilogue
+    if conv is not None:
+        a.conv_C, a.conv_H, a.conv_W, a.conv_Ho, a.conv_Wo = conv["C"], conv["H"], conv["W"], conv["Ho"], conv["Wo"]
+        a.conv_stride, a.conv_up = conv.get("stride", 1), conv.get("up", 0)
     if epilogue == L.EPI_BF16 and a.M * a.N <= SPLITK_MAX_OUT and a.K >= 512:       # (only launches that can be split need the scratch)
         ws = _splitk_ws(x.device)
         a.splitk_ws, a.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4

@@ -19,6 +19,12 @@ from fourm.hip import _lib as L
 from fourm.hip import ops
 
 
+import os
+
+# 3 x 3 convolutions with C % 64 == 0 input channels as implicit GEMMs (no im2col round trip; bit-identical).  FOURM_UNET_IMPLICIT_CONV=0: im2col + GEMM.
+IMPLICIT_CONV = os.environ.get("FOURM_UNET_IMPLICIT_CONV", "1") == "1"
+
+
 def ru(x, m):
     return (x + m - 1) // m * m
 
@@ -218,11 +224,19 @@ class _UNetEngine:
                                  ops._p(y), C, ops._p(st), B, HW, C, norm.num_groups, float(norm.eps), 1 if silu else 0, ops._stream()))
         return y
 
-    def conv3(self, tag, x, conv, B, H, W, stride=1, up1=0):
-        C = conv.weight.shape[1]
+    def conv3(self, tag, x, conv, B, H, W, stride=1, up1=0, out=None, f32_out=False):
+        """3 x 3 convolution (padding 1) of the (B, H >> up1, W >> up1, C) rows x read on the (H, W) grid.  C % 64 == 0: implicit GEMM (the gather runs
+        inside the GEMM's LDS-DMA addresses, fm_gemm_nt_args.conv_*); else fm_unet_im2col + the plain GEMM."""
+        C, Co = conv.weight.shape[1], conv.weight.shape[0]
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        if out is None:
+            out = self.buf(tag, B * Ho * Wo, Co)
+        if IMPLICIT_CONV and C % 64 == 0:
+            ops.gemm_nt(x, self.w_conv(conv), out, epilogue=L.EPI_F32 if f32_out else L.EPI_BF16, bias=conv.bias.detach().float().contiguous() if conv.bias is not None else None,
+                        M=B * Ho * Wo, N=Co, K=9 * C, conv=dict(C=C, H=H, W=W, Ho=Ho, Wo=Wo, stride=stride, up=up1))
+            return out, Ho, Wo
         col, Ho, Wo = self.im2col("col", x, C, B, H, W, 3, stride, up1)
-        out = self.buf(tag, B * Ho * Wo, conv.weight.shape[0])
-        self.gemm(col, self.w_conv(conv), conv.bias, out, B * Ho * Wo, conv.weight.shape[0], col.shape[1])
+        self.gemm(col, self.w_conv(conv), conv.bias, out, B * Ho * Wo, Co, col.shape[1], f32_out=f32_out)
         return out, Ho, Wo
 
     def res(self, tag, m, x, emb_all, B, H, W):
@@ -344,10 +358,9 @@ class _UNetEngine:
             h, hh, ww = self.run(blk, cat, emb_all, B, hh, ww)
         a = self.gn("act", h, net.out[0], B, hh * ww, h.shape[1], True)
         conv = net.out[2]
-        col, _, _ = self.im2col("col", a, h.shape[1], B, hh, ww)
         OP = conv.weight.shape[0]
         y = self.buf("y", B * hh * ww, ru(OP, 4), torch.float32)
-        self.gemm(col, self.w_conv(conv), conv.bias, y, B * hh * ww, OP, col.shape[1], f32_out=True)
+        self.conv3("y", a, conv, B, hh, ww, out=y, f32_out=True)
         img = torch.empty(B, net.out_channels, H, W, dtype=torch.float32, device=dev)
         L.check(L.vq_unpatchify(ops._p(y), y.stride(0), ops._p(img), B, net.out_channels, H, W, P, ops._stream()))
         return img

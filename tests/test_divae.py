@@ -145,6 +145,41 @@ def test_groupnorm_nhwc_both_forms(B, HW, C, silu, with_add):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C,Co,stride,up,f32", [(2, 14, 14, 128, 256, 1, 0, False), (8, 7, 7, 512, 512, 1, 0, False), (3, 28, 28, 256, 256, 2, 0, False),
+                                                      (2, 28, 28, 256, 512, 1, 1, False), (2, 56, 56, 256, 48, 1, 0, True), (1, 9, 11, 64, 100, 1, 0, False),
+                                                      (8, 56, 56, 256, 256, 1, 0, False)])
+def test_implicit_conv_gemm(B, H, W, C, Co, stride, up, f32):
+    """fm_gemm_nt with conv_*: the 3 x 3 convolution as an implicit GEMM (the gather inside the LDS-DMA addresses) against fm_unet_im2col + the plain
+    launch on the same rows, and against F.conv2d in fp32 on the same bf16 operands (stride 1 | 2, nearest x2 up-sampling in front, fp32 output,
+    grids small enough to be split over K and large ones)."""
+    from fourm.hip import _lib as L, ops
+    torch.manual_seed(H * W + C + Co)
+    hi, wi = H >> up, W >> up                                     # physical input grid; (H, W) is the grid the convolution reads
+    x = torch.randn(B * hi * wi, C, device="cuda").bfloat16()
+    w4 = (torch.randn(Co, C, 3, 3, device="cuda") * (1.0 / (3.0 * C ** 0.5))).bfloat16()
+    wk = w4.permute(0, 2, 3, 1).reshape(Co, 9 * C).contiguous()     # taps outermost
+    bias = torch.randn(Co, device="cuda")
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    M = B * Ho * Wo
+    ldo = (Co + 63) // 64 * 64
+    odt = torch.float32 if f32 else torch.bfloat16
+    got = torch.full((M, ldo), 3.0, device="cuda", dtype=odt)
+    ops.gemm_nt(x, wk, got, epilogue=L.EPI_F32 if f32 else L.EPI_BF16, bias=bias, M=M, N=Co, K=9 * C, conv=dict(C=C, H=H, W=W, Ho=Ho, Wo=Wo, stride=stride, up=up))
+    col = torch.zeros(M, 9 * C, device="cuda", dtype=torch.bfloat16)
+    L.check(L.unet_im2col(ops._p(x), C, C, None, 0, 0, 0, 0, ops._p(col), 9 * C, 9 * C, B, H, W, 3, stride, up, ops._stream()))
+    ref2 = torch.full((M, ldo), 3.0, device="cuda", dtype=odt)
+    ops.gemm_nt(col, wk, ref2, epilogue=L.EPI_F32 if f32 else L.EPI_BF16, bias=bias, M=M, N=Co, K=9 * C)
+    assert rel(got[:, :Co], ref2[:, :Co]) < 2e-3, rel(got[:, :Co], ref2[:, :Co])
+    xin = x.float().view(B, hi, wi, C).permute(0, 3, 1, 2)
+    if up:
+        xin = torch.nn.functional.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = torch.nn.functional.conv2d(xin, w4.float(), (bias if f32 else bias.bfloat16().float()), stride=stride, padding=1).permute(0, 2, 3, 1).reshape(M, Co)
+    err = float((got[:, :Co].float() - ref).abs().max())
+    assert err <= 2 ** -7 * float(ref.abs().max()) + 1e-3, (err, float(ref.abs().max()))
+    assert bool((got[:, (Co + 3) // 4 * 4:] == 3.0).all())            # columns past roundup4(Co) untouched
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,T,heads,ch", [(8, 196, 1, 512), (8, 49, 1, 512), (2, 30, 2, 64), (4, 200, 2, 128)])
 def test_unet_attention(B, T, heads, ch):
     """fm_unet_attention (QKVAttentionLegacy, unet.py:329-358: per head [q | k | v] channel blocks, scale ch^-1/4 on q and k, fp32 softmax) against a
