@@ -45,6 +45,10 @@ class GraphedTrainStep:
         # the table of "every shadow stale after an optimizer step" is first built by the SECOND forward)
         for _ in range(max(2, warmup)):
             self._eager_step()
+        if data_parallel is not None and getattr(getattr(eng, "reducer", None), "_direct", None) is None and getattr(eng.reducer, "world", 1) > 1:
+            # DataParallel falls back to torch.distributed collectives when the direct binding cannot be honoured (store not on a GPU, backend
+            # not nccl): capturing those is the hipErrorCapturedEvent crash this path exists to rule out
+            raise RuntimeError("GraphedTrainStep: the gradient reducer did not get its direct RCCL communicator (comm='direct' was downgraded); stay eager")
         self._sig = self._signature()
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)           # the captured backward starts a fresh accumulation window (memset captured)

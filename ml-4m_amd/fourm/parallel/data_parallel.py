@@ -70,8 +70,8 @@ class GradReducer:
         if comm == "direct" and (self.world > 1 or force):
             if not flat.is_cuda:
                 raise ValueError("comm='direct' needs the gradient store on a GPU")
-            from .rccl import DirectComm
-            self._direct = DirectComm(group, flat.device)
+            from .rccl import shared_comm
+            self._direct = shared_comm(group, flat.device)          # (one communicator per group and device, whatever the number of reducer rebuilds)
             self._avg = True
         self._wire_bufs = {}                   # (offset, length) -> bf16 staging buffer, allocated once
         self._shards = {}

@@ -101,6 +101,31 @@ class DirectComm:
             self._comm = C.c_void_p()
 
 
+_COMMS = {}
+
+
+def shared_comm(group=None, device: Optional[torch.device] = None) -> DirectComm:
+    """ONE communicator per (process group, device), created on first use and reused by every gradient reducer built afterwards (the data-parallel
+    wrapper rebuilds its reducer whenever the flat gradient store is re-allocated: a communicator per rebuild would leak - ncclCommInitRank is a
+    collective and nothing destroyed the old ones).  Destroyed by close_all() / at interpreter exit."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    key = (id(group) if group is not None else None, device.index)
+    c = _COMMS.get(key)
+    if c is None or not c._comm:
+        c = _COMMS[key] = DirectComm(group, device)
+    return c
+
+
+def close_all():
+    for c in list(_COMMS.values()):
+        c.close()
+    _COMMS.clear()
+
+
+import atexit  # noqa: E402
+atexit.register(close_all)
+
+
 class _DirectWork:
     """Stand-in for torch's Work handle: wait() = the CURRENT stream waits for what the exchange stream has been given so far."""
 
