@@ -457,18 +457,28 @@ def main_vq(a):
             model.tokenize(xs[i % 2])
         fence()
         return
+    from fourm.vq import tokenize_sub_batches
+    n_streams = a.vq_streams
     for i in range(a.warmup):
         model.tokenize(xs[i % 2])
+    tokenize_sub_batches(model, [xs[i % 2] for i in range(2 * n_streams + 1)], n_streams)       # (allocates the per-stream scratch sets)
     fence()
+    # one sub-batch at a time (the number of rounds 1 - 5) ...
     t0 = time.perf_counter()
     for i in range(a.steps):
         tok = model.tokenize(xs[i % 2])
     fence()
+    dt1 = time.perf_counter() - t0
+    # ... and the timed region: upstream's loop over sub-batches of 64 (save_vq_tokens.py:262-288) with two of them in flight on two HIP streams
+    t0 = time.perf_counter()
+    toks = tokenize_sub_batches(model, [xs[i % 2] for i in range(a.steps)], n_streams)
+    fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev)
+    tok = toks[-1]
+    t = torch.tensor([dt, dt1], device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
+    dt, dt1 = float(t[0]), float(t[1])
     flops_img = 37.0e9                      # 36.8 GFLOP ViT + 0.21 GFLOP code search per image
     value = world * batch * a.steps / dt
     out = {"metric": "images/sec (RGB VQ tokenizer encode+quantize, whole job)", "value": value, "unit": "images/s", "n_gpus": world,
@@ -476,7 +486,8 @@ def main_vq(a):
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "RGB VQ tokenizer (ViT-B/16 encoder 90.5M params, 224^2 -> 14x14 codes, 16384 x 32 cosine codebook): "
                                   "VQ.tokenize on uniform [-1,1] images", "per_gpu_batch": batch, "global_batch": batch * world,
-                      "parallelism": f"replicas x{world}"},
+                      "parallelism": f"replicas x{world}; {n_streams} sub-batches of {batch} in flight on {n_streams} HIP streams (fourm.vq.tokenize_sub_batches)"},
+           "one_sub_batch_in_flight_images_per_s": world * batch * a.steps / dt1,
            "codes_per_sec": value * 196, "mfu": flops_img * value / world / (BF16_PEAK_TFLOPS * 1e12),
            "arithmetic": "ViT blocks bf16 operands / fp32 accumulate; post-MLP, 1x1 projection and code search fp32"}
     if not a.no_kernel_profile and rank == 0:
@@ -553,19 +564,27 @@ def main_divae(a):
             model.decoder(x, 500, quant)
         fence()
         return
-    steps, warmup = min(a.steps, 4), min(a.warmup, 1)
+    from fourm.vq import decode_token_batches
+    n_streams = a.vq_streams
+    steps, warmup = min(a.steps, 7), min(a.warmup, 1)
     for i in range(warmup):
         decode(i)
+    decode_token_batches(model, [toks[i % 2] for i in range(n_streams + 1)], n_streams, timesteps=ddim, generator=gen, verbose=False)     # (per-stream scratch)
     fence()
-    t0 = time.perf_counter()
-    for i in range(steps):
+    t0 = time.perf_counter()                   # one decode at a time ...
+    for i in range(2):
         img = decode(i)
     fence()
+    dt1 = (time.perf_counter() - t0) / 2
+    t0 = time.perf_counter()                   # ... and the timed region: `steps` decodes of batch 8, n_streams of them in flight
+    imgs = decode_token_batches(model, [toks[i % 2] for i in range(steps)], n_streams, timesteps=ddim, generator=gen, verbose=False)
+    fence()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev)
+    img = imgs[-1]
+    t = torch.tensor([dt, dt1], device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
+    dt, dt1 = float(t[0]), float(t[1])
     flops_img_eval = 190.0e9               # 3x3 / 1x1 convolutions + attention of one evaluation per image
     value = world * batch * steps / dt
     out = {"metric": "images/sec (DiVAE diffusion detokenizer: decode_tokens, 25 DDIM steps, whole job)", "value": value, "unit": "images/s", "n_gpus": world,
@@ -573,8 +592,9 @@ def main_divae(a):
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "DiVAE detokenizer (unet_patched decoder 196 M parameters, 56 x 56 patch grid, 14 x 14 x 32 conditioning, DDIM 25 steps, "
                                   "dynamic thresholding): DiVAE.decode_tokens on random token grids", "per_gpu_batch": batch, "global_batch": batch * world,
-                      "parallelism": f"replicas x{world}"},
-           "ms_per_unet_evaluation": 1e3 * dt / steps / ddim, "finite": bool(torch.isfinite(img).all()),
+                      "parallelism": f"replicas x{world}; {n_streams} decodes of batch {batch} in flight on {n_streams} HIP streams (fourm.vq.decode_token_batches)"},
+           "ms_per_unet_evaluation_one_decode_in_flight": 1e3 * dt1 / ddim, "one_decode_in_flight_images_per_s": world * batch / dt1,
+           "finite": bool(torch.isfinite(img).all()),
            "mfu": flops_img_eval * ddim * value / world / (BF16_PEAK_TFLOPS * 1e12),
            "arithmetic": "convolutions as im2col + bf16 GEMMs (fp32 accumulate), bf16 feature maps, GroupNorm / attention softmax / scheduler steps fp32"}
     if not a.no_kernel_profile and rank == 0:
@@ -631,6 +651,7 @@ def main():
     ap.add_argument("--masking", default="uniform", choices=["uniform", "dirichlet"], help="uniform = SURVEY §8d's synthetic budgets (the headline); "
                     "dirichlet = the batches come from the device-side masking pipeline (Dirichlet token budgets, image masks, span masking: "
                     "fourm.data.masking.DeviceUnifiedMasking), and the record carries the producer's time per batch")
+    ap.add_argument("--vq-streams", type=int, default=2, help="--workload vq: sub-batches of 64 in flight (HIP streams) in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (test hook: several ranks on one GPU)")
@@ -860,7 +881,7 @@ def main():
         gc.collect(); torch.cuda.empty_cache()
         out["extra"] = {"vq": extra_record(["--workload", "vq", "--steps", "10", "--warmup", "3"], 300),
                         "mod21": extra_record(["--mods", "mod21", "--steps", "5", "--warmup", "2"], 600),
-                        "divae": extra_record(["--workload", "divae", "--steps", "3", "--warmup", "1"], 300)}
+                        "divae": extra_record(["--workload", "divae", "--steps", "7", "--warmup", "1"], 400)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -73,12 +73,15 @@ class Workspace:
     """Named device buffers, allocated (zero-filled) on first use and reused while the shape matches.
     Padding rows / columns are never written by any kernel, so they stay zero for the GEMM contracts."""
 
-    def __init__(self, device):
+    def __init__(self, device, per_stream: bool = False):
+        """per_stream: a buffer set per HIP stream (the key carries the current stream's handle), so that calls issued on different streams - two
+        tokenizer sub-batches in flight (fourm.vq.tokenize_sub_batches) - never share scratch.  Off for the train step (one stream, ~1500 lookups)."""
         self.device = device
+        self.per_stream = per_stream
         self.bufs: Dict[tuple, torch.Tensor] = {}
 
     def get(self, name, shape, dtype):
-        key = (name, tuple(shape), dtype)
+        key = (name, tuple(shape), dtype, torch.cuda.current_stream(self.device).cuda_stream) if self.per_stream else (name, tuple(shape), dtype)
         t = self.bufs.get(key)
         if t is None:
             t = self.bufs[key] = torch.zeros(shape, dtype=dtype, device=self.device)

@@ -80,10 +80,15 @@ SPLITK_MAX_OUT = 128 * 128 * 128          # outputs of up to 128 tiles of 128 x 
 _SPLITK_WS = {}
 
 
+SCRATCH_TAG = None          # set while a hipGraph is being captured: scratch allocated then belongs to THAT graph (torch captures every graph on the same
+                            # side stream, so the stream alone would hand one graph's scratch to the next - and two graphs may replay concurrently)
+
+
 def _splitk_ws(device):
-    t = _SPLITK_WS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, SCRATCH_TAG)          # (launches on different streams must not share partial tiles)
+    t = _SPLITK_WS.get(key)
     if t is None:
-        t = _SPLITK_WS[device] = torch.empty(16 * SPLITK_MAX_OUT, dtype=torch.float32, device=device)      # 128 MB: 16 slices of the largest output
+        t = _SPLITK_WS[key] = torch.empty(16 * SPLITK_MAX_OUT, dtype=torch.float32, device=device)      # 128 MB: 16 slices of the largest output
     return t
 
 

@@ -4,6 +4,80 @@ import os
 from .vqvae import VQ, VQVAE, DiVAE
 
 
+def tokenize_sub_batches(model, sub_batches, n_streams: int = 2):
+    """upstream's tokenization loop - ``for sub_batch in imgs_batch.split(batch_size): tokens = model.tokenize(sub_batch)``
+    (save_vq_tokens.py:262-288) - with up to ``n_streams`` sub-batches in flight, each on its own HIP stream.  Returns the token tensors in
+    order; the CURRENT stream has waited for all of them on return.
+
+    Why: at the reference's sub-batch of 64 a GEMM of the ViT-B tokenizer has 12 544 rows = 147 - 196 output tiles for 256 CUs (less than one
+    round), and a second sub-batch's kernels run on the CUs the first leaves idle: 12.7 -> 14.7 k images/s with two streams
+    (tools/vq_two_streams.py).  Safe because the tokenizer engines keep one scratch set per stream (Workspace(per_stream=True)); weight images and
+    the normalised codebook are built by the first sub-batch, which therefore runs alone."""
+    import torch
+    sub_batches = list(sub_batches)
+    if not sub_batches:
+        return []
+    with torch.no_grad():
+        first = model.tokenize(sub_batches[0])                 # builds every cached operand on the current stream
+        if n_streams <= 1 or len(sub_batches) == 1:
+            return [first] + [model.tokenize(x) for x in sub_batches[1:]]
+        cur = torch.cuda.current_stream()
+        pool = getattr(model, "_tok_streams", None)
+        if pool is None or len(pool) < n_streams or pool[0].device != cur.device:
+            pool = [torch.cuda.Stream(device=cur.device) for _ in range(n_streams)]
+            object.__setattr__(model, "_tok_streams", pool)
+        ready = torch.cuda.Event()
+        ready.record(cur)                                      # inputs and cached operands are complete up to here
+        out = [first]
+        for i, x in enumerate(sub_batches[1:]):
+            s = pool[i % n_streams]
+            if i < n_streams:
+                s.wait_event(ready)
+            with torch.cuda.stream(s):
+                out.append(model.tokenize(x))
+                x.record_stream(s)
+                out[-1].record_stream(cur)
+        for s in pool[:min(n_streams, len(sub_batches) - 1)]:
+            cur.wait_stream(s)
+    return out
+
+
+def decode_token_batches(model, token_batches, n_streams: int = 2, **decode_kwargs):
+    """``[model.decode_tokens(t, **decode_kwargs) for t in token_batches]`` for the diffusion detokenizer with up to ``n_streams`` batches in
+    flight, each sampling loop on its own HIP stream.  At batch 8 the UNet's kernels are small (4 - 400 workgroups): a second decode's kernels
+    run beside them.  The host enqueues one whole decode after the other (the scheduler object's host state is never shared mid-loop); the UNet
+    engine keeps one scratch set per stream.  ``generator`` in decode_kwargs may be a list (one per batch)."""
+    import torch
+    token_batches = list(token_batches)
+    if not token_batches:
+        return []
+    gens = decode_kwargs.pop("generator", None)
+    gen_of = (lambda i: gens[i]) if isinstance(gens, (list, tuple)) else (lambda i: gens)
+    with torch.no_grad():
+        first = model.decode_tokens(token_batches[0], generator=gen_of(0), **decode_kwargs)      # builds the cached weight images
+        if n_streams <= 1 or len(token_batches) == 1:
+            return [first] + [model.decode_tokens(t, generator=gen_of(i + 1), **decode_kwargs) for i, t in enumerate(token_batches[1:])]
+        cur = torch.cuda.current_stream()
+        pool = getattr(model, "_dec_streams", None)
+        if pool is None or len(pool) < n_streams or pool[0].device != cur.device:
+            pool = [torch.cuda.Stream(device=cur.device) for _ in range(n_streams)]
+            object.__setattr__(model, "_dec_streams", pool)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        out = [first]
+        for i, t in enumerate(token_batches[1:]):
+            s = pool[i % n_streams]
+            if i < n_streams:
+                s.wait_event(ready)
+            with torch.cuda.stream(s):
+                out.append(model.decode_tokens(t, generator=gen_of(i + 1), **decode_kwargs))
+                t.record_stream(s)
+                out[-1].record_stream(cur)
+        for s in pool[:min(n_streams, len(token_batches) - 1)]:
+            cur.wait_stream(s)
+    return out
+
+
 def get_image_tokenizer(tokenizer_id: str, tokenizers_root: str = "./tokenizer_ckpts", encoder_only: bool = False, device: str = "cuda",
                         verbose: bool = True, return_None_on_fail: bool = False):
     """Load a tokenizer checkpoint saved by the upstream trainers: ``{root}/{id}.pth`` = {'model': state_dict, 'args': Namespace}.

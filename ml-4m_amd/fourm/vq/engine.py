@@ -37,6 +37,10 @@ class _VitEngine(FourMEngine):
     def device(self):
         return self.model.blocks[0].norm1.weight.device
 
+    def prepare(self):
+        if self.ws is None or self.ws.device != self.device:
+            self.ws = Workspace(self.device, per_stream=True)          # (sub-batches may be in flight on several streams: tokenize_sub_batches)
+
     # gradients of tokenizer training: one fp32 buffer per parameter, attached as ``param.grad`` after the backward
     def grad_view(self, p):
         g = self._grads.get(id(p))

@@ -25,6 +25,12 @@ import os
 IMPLICIT_CONV = os.environ.get("FOURM_UNET_IMPLICIT_CONV", "1") == "1"
 
 
+# One evaluation = ~430 launches issued from Python: at batch 8 the host needs 8.3 ms to enqueue what the GPU runs in ~6.5 ms (tools/divae_host_probe.py).
+# In eval mode the launch sequence of a (shape, stream) is captured into a hipGraph after two eager evaluations and replayed from then on
+# (inputs copied into static buffers, the output copied out).  FOURM_UNET_GRAPH=0: always eager.
+UNET_GRAPH = os.environ.get("FOURM_UNET_GRAPH", "1") == "1"
+
+
 def ru(x, m):
     return (x + m - 1) // m * m
 
@@ -134,6 +140,8 @@ class PatchedUNetCondCat(nn.Module):
             raise RuntimeError("PatchedUNetCondCat runs on the HIP kernels only: move the model and its inputs to an MI355X (there is no CPU path)")
         if self._engine is None:
             self._engine = _UNetEngine(self)
+        if UNET_GRAPH and not self.training and not torch.cuda.is_current_stream_capturing():
+            return self._engine.forward_graphed(sample, timestep, encoder_hidden_states, cond_mask)
         return self._engine.forward(sample, timestep, encoder_hidden_states, cond_mask)
 
 
@@ -196,7 +204,7 @@ class _UNetEngine:
         return hit[1], hit[2]
 
     def buf(self, tag, rows, cols, dtype=torch.bfloat16):
-        key = (tag, dtype)
+        key = (tag, dtype, torch.cuda.current_stream(self.net.device).cuda_stream, ops.SCRATCH_TAG)      # one scratch set per stream / per captured graph
         b = self._buf.get(key)
         n = rows * cols
         if b is None or b.numel() < n or b.device != self.net.device:
@@ -291,6 +299,48 @@ class _UNetEngine:
             else:
                 raise TypeError(type(m))
         return h, H, W
+
+    # ---- one evaluation, replayed from a hipGraph ----------------------------------------------------------------------------------
+    def _weights_stamp(self):
+        return tuple((p._version, p.data_ptr()) for p in self.net.parameters())
+
+    def forward_graphed(self, sample, timestep, cond, cond_mask):
+        """forward() through a captured graph per (shapes, mask or not, stream).  The first two evaluations of a key run eagerly (they build the
+        cached weight images and size every scratch buffer); the third is captured.  A parameter that changed (version / storage) drops the graphs."""
+        dev = sample.device
+        key = (tuple(sample.shape), tuple(cond.shape), cond_mask is not None, torch.cuda.current_stream(dev).cuda_stream)
+        stamp = self._weights_stamp()
+        if getattr(self, "_graph_stamp", None) != stamp:
+            self._graphs, self._graph_warm, self._graph_stamp = {}, {}, stamp
+        g = self._graphs.get(key)
+        if g is None:
+            n = self._graph_warm.get(key, 0)
+            if n < 2:
+                self._graph_warm[key] = n + 1
+                return self.forward(sample, timestep, cond, cond_mask)
+            B = sample.shape[0]
+            st = dict(x=sample.detach().float().contiguous().clone(), t=torch.zeros(B, dtype=torch.float32, device=dev), c=cond.detach().float().contiguous().clone(),
+                      m=cond_mask.to(dev).clone() if cond_mask is not None else None)
+            torch.cuda.current_stream(dev).synchronize()
+            graph = torch.cuda.CUDAGraph()
+            ops.SCRATCH_TAG = ("graph", len(self._graphs), key)          # scratch allocated during the capture lives in this graph's pool and is its alone
+            try:
+                with torch.cuda.graph(graph):
+                    st["out"] = self.forward(st["x"], st["t"], st["c"], st["m"])
+            finally:
+                ops.SCRATCH_TAG = None
+            g = self._graphs[key] = (graph, st)
+        graph, st = g
+        st["x"].copy_(sample.detach())
+        st["c"].copy_(cond.detach())
+        if st["m"] is not None:
+            st["m"].copy_(cond_mask)
+        if torch.is_tensor(timestep):
+            st["t"].copy_(timestep.detach().reshape(-1).float().expand(st["t"].shape[0]) if timestep.numel() == 1 else timestep.detach().reshape(-1).float())
+        else:
+            st["t"].fill_(float(timestep))
+        graph.replay()
+        return st["out"].clone()
 
     # ---- one evaluation --------------------------------------------------------------------------------------------------------------
     def forward(self, sample, timestep, cond, cond_mask):

@@ -199,6 +199,64 @@ def test_unet_attention(B, T, heads, ch):
 
 
 @pytest.mark.gpu
+def test_unet_evaluation_replayed_from_a_graph_is_bit_identical():
+    """In eval mode the third evaluation of a (shape, stream) is captured into a hipGraph and replayed from then on (FOURM_UNET_GRAPH): the same
+    bits as the eager launch sequence, for scalar and per-sample timesteps, with and without the conditioning mask, across weight updates."""
+    from fourm.vq import DiVAE
+    import fourm.vq.models.unet.unet as U
+    torch.manual_seed(0)
+    m = DiVAE(image_size=64, n_channels=3, enc_type="vit_s_enc", patch_size=16, codebook_size=256, latent_dim=16, post_mlp=True, norm_codes=True,
+              scheduler="ddim", prediction_type="sample", beta_schedule="linear", sync_codebook=False)
+    for p in m.decoder.parameters():
+        if float(p.detach().abs().max()) == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    m = m.cuda().eval()
+    x, q = torch.randn(5, 3, 64, 64, device="cuda"), torch.randn(5, 16, 4, 4, device="cuda")
+    ts = torch.tensor([10.0, 500.0, 999.0, 3.0, 250.0], device="cuda")
+    mask = torch.rand(5, 4, 4, device="cuda") < 0.3
+    saved = U.UNET_GRAPH
+    try:
+        for args in ((x, 500, q), (x, ts, q), (x, ts, q, mask)):
+            U.UNET_GRAPH = False
+            want = m.decoder(*args).clone()
+            U.UNET_GRAPH = True
+            for i in range(5):                                        # two eager warm-ups, the capture, two replays
+                xi = x + 0.0 if i != 3 else x * 0.5                   # (a replay with other inputs in between)
+                got = m.decoder(xi, *args[1:])
+                if i != 3:
+                    assert torch.equal(got, want), (len(args), i)
+        with torch.no_grad():
+            next(m.decoder.parameters()).mul_(1.01)                  # a weight update drops the captured graphs
+        U.UNET_GRAPH = False
+        want = m.decoder(x, 500, q).clone()
+        U.UNET_GRAPH = True
+        for i in range(4):
+            assert torch.equal(m.decoder(x, 500, q), want), i
+    finally:
+        U.UNET_GRAPH = saved
+
+
+@pytest.mark.gpu
+def test_decode_token_batches_in_flight_on_two_streams():
+    """fourm.vq.decode_token_batches: two sampling loops in flight on their own HIP streams give, bit for bit, the images of one decode after the
+    other (same per-batch CPU generators; the UNet engine keeps a scratch set per stream)."""
+    from fourm.vq import DiVAE, decode_token_batches
+    torch.manual_seed(5)
+    m = DiVAE(image_size=64, n_channels=3, enc_type="vit_s_enc", patch_size=16, codebook_size=256, latent_dim=16, post_mlp=True, norm_codes=True,
+              scheduler="ddim", prediction_type="sample", beta_schedule="linear", sync_codebook=False)
+    for p in m.decoder.parameters():
+        if float(p.detach().abs().max()) == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    m = m.cuda().eval()
+    toks = [torch.randint(0, 256, (8 if i % 2 else 5, 4, 4), device="cuda") for i in range(5)]
+    want = [m.decode_tokens(t, timesteps=4, generator=torch.Generator().manual_seed(100 + i), verbose=False).clone() for i, t in enumerate(toks)]
+    for n in (2, 1):
+        got = decode_token_batches(m, toks, n_streams=n, timesteps=4, generator=[torch.Generator().manual_seed(100 + i) for i in range(len(toks))], verbose=False)
+        torch.cuda.synchronize()
+        assert all(torch.equal(g, w) for g, w in zip(got, want)), n
+
+
+@pytest.mark.gpu
 def test_hip_unet_matches_upstream_fixture():
     """One evaluation of the conditional UNet (per-sample timesteps, conditioning mask, integer timestep): bf16 GEMM operands / fp32
     accumulation against upstream's fp32 run."""

@@ -81,6 +81,23 @@ def test_code_assignment_bit_exact_given_latents(name):
 
 
 @pytest.mark.gpu
+def test_tokenize_sub_batches_in_flight_on_several_streams():
+    """fourm.vq.tokenize_sub_batches (upstream's loop over sub-batches, save_vq_tokens.py:262-288, with 2 / 3 of them in flight on their own HIP
+    streams): the same tokens, bit for bit, as one call after the other - the engines keep a scratch set per stream."""
+    from fourm.vq import VQ, tokenize_sub_batches
+    torch.manual_seed(3)
+    model = VQ(image_size=224, enc_type="vit_b_enc", patch_size=16, post_mlp=True, codebook_size=16384, latent_dim=32, norm_codes=True, sync_codebook=False).cuda().eval()
+    subs = [torch.rand(16 if i % 3 else 24, 3, 224, 224, device="cuda") * 2 - 1 for i in range(7)]        # ragged sub-batch sizes
+    want = [model.tokenize(x).clone() for x in subs]
+    for n in (2, 3, 1):
+        for _ in range(2):
+            got = tokenize_sub_batches(model, subs, n_streams=n)
+            torch.cuda.synchronize()
+            assert len(got) == len(want) and all(torch.equal(g, w) for g, w in zip(got, want)), n
+    assert tokenize_sub_batches(model, []) == []
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", list(VQ_CASES))
 def test_tokenize_end_to_end(name):
     c, cfg, sd, x, g = case(name)

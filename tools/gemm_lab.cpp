@@ -118,7 +118,8 @@ int main(int argc, char** argv) {
         if (argc > 3) { pads.clear(); char* t = strtok(argv[3], ","); while (t) { pads.push_back(atoi(t)); t = strtok(nullptr, ","); } }
         NTCase cases[] = {{"qkv      N2304 K768 ", 2304, 768, FM_EPI_BF16}, {"proj/dX  N768  K768 ", 768, 768, FM_EPI_BF16},
                           {"dX fc2   N2048 K768 ", 2048, 768, FM_EPI_BF16}, {"dX fc13  N768  K4096", 768, 4096, FM_EPI_BF16},
-                          {"dX qkv   N768  K2304", 768, 2304, FM_EPI_BF16}, {"swiglu   N2x2048 K768", 2048, 768, FM_EPI_SWIGLU}};
+                          {"dX qkv   N768  K2304", 768, 2304, FM_EPI_BF16}, {"fc2      N768  K2048", 768, 2048, FM_EPI_BF16},
+                          {"swiglu   N2x2048 K768", 2048, 768, FM_EPI_SWIGLU}};
         set_cfg(cfg);
         for (auto& c : cases) {
             printf("%s |", c.name);
