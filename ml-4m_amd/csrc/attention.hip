@@ -73,14 +73,18 @@ __device__ __forceinline__ const char* tile_addr(const char* tile, int row, int 
 }
 
 // copy `rows` x 64 bf16 (row stride ld elements) into a swizzled LDS tile; rows >= limit are clamped
-template <int NWAVES>
+// AUX: cache-policy bits of the LDS-DMA (2 = non-temporal: the backward's saved q / k / v are read exactly once)
+#ifndef ATTN_BWD_SAVED_NT
+#define ATTN_BWD_SAVED_NT 2          // (-DATTN_BWD_SAVED_NT=0: plain loads; 56.58 -> 56.36 ms per 4M-B step same-box, profiles/r06_ab_nontemporal.txt)
+#endif
+template <int NWAVES, int AUX = 0>
 __device__ __forceinline__ void stage_rows(const bf16_t* src, int ld, int row0, int limit, int rows, char* tile, int wave, int lane) {
     for (int p = wave; p < rows / 8; p += NWAVES) {
         const int t = p * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ sw3(t);
         int r = row0 + t;
         r = r < limit ? r : limit - 1;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src + (size_t)r * ld + lc * 8), LDS_PTR(tile + p * 8 * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src + (size_t)r * ld + lc * 8), LDS_PTR(tile + p * 8 * ROWB), 16, 0, AUX);
     }
 }
 
@@ -1088,15 +1092,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
     const bf16_t* Ob = a.O + (size_t)b * N * a.ldo + h * HD;
     const bf16_t* dOb = a.dO + (size_t)b * N * a.lddo + h * HD;
 
-    stage_rows<4>(Qb, a.ldq, 0, N, N, T0, wave, lane);
+    stage_rows<4, ATTN_BWD_SAVED_NT>(Qb, a.ldq, 0, N, N, T0, wave, lane);
     stage_rows<4>(dOb, a.lddo, 0, N, N, T1, wave, lane);
     const int key = wave * 32 + (lane & 31);             // pass A: this lane's key
     bf16x8_t kf[4], vf[4];
 #if ATTN_KV_DMA
     // K and V reach their registers through the (still unused) dS^T area: whole 128-byte lines by LDS-DMA instead of 32-byte pieces per row and
     // instruction (the fragment loads were 1 024 of a workgroup's ~1 900 L2 requests)
-    stage_rows<4>(Kb, a.ldk, 0, N, N, dSl, wave, lane);
-    stage_rows<4>(Vb, a.ldv, 0, N, N, dSl + N * ROWB, wave, lane);
+    stage_rows<4, ATTN_BWD_SAVED_NT>(Kb, a.ldk, 0, N, N, dSl, wave, lane);
+    stage_rows<4, ATTN_BWD_SAVED_NT>(Vb, a.ldv, 0, N, N, dSl + N * ROWB, wave, lane);
 #else
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {

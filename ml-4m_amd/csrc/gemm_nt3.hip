@@ -400,7 +400,13 @@ __global__ __launch_bounds__(512) void gemm_nt3_kernel(NTArgs a) {
                         const int h = hw0 + (lane & 7) * 8;
                         const uint32_t ok = (m0 + rl < a.M && h < N) ? 0u : OOB;
                         if (which == 2) __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out, ok | ((uint32_t)(rl * a.ldo) * 2u + (uint32_t)h * 2u), 0, 0);
-                        else __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out2, ok | ((uint32_t)(rl * a.ldo2) * 2u + (uint32_t)(h + (which == 1 ? a.Hp : 0)) * 2u), 0, 0);
+                        // g and u are saved for the backward only: NON-TEMPORAL stores, so that their 268 MB do not push the activation (the operand of the fc2
+                        // GEMM that runs next) out of the 256 MB Infinity Cache - fc2 forward 101 -> 86 us in situ, 0.4 - 0.7 ms per 4M-B step same-box
+                        // (FOURM_NT3_LAB bit 32: plain stores, bit 64 / 128: sc0 sc1 / sc0 nt - measured equal to plain / to nt)
+                        else if (a.lab & 32) __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out2, ok | ((uint32_t)(rl * a.ldo2) * 2u + (uint32_t)(h + (which == 1 ? a.Hp : 0)) * 2u), 0, 0);
+                        else if (a.lab & 64) __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out2, ok | ((uint32_t)(rl * a.ldo2) * 2u + (uint32_t)(h + (which == 1 ? a.Hp : 0)) * 2u), 0, 17);
+                        else if (a.lab & 128) __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out2, ok | ((uint32_t)(rl * a.ldo2) * 2u + (uint32_t)(h + (which == 1 ? a.Hp : 0)) * 2u), 0, 3);
+                        else __builtin_amdgcn_raw_buffer_store_b128(rv[q], rs_out2, ok | ((uint32_t)(rl * a.ldo2) * 2u + (uint32_t)(h + (which == 1 ? a.Hp : 0)) * 2u), 0, 2);
                     }
                 }
             }

@@ -14,6 +14,16 @@ constexpr int MAXC_LIMIT = 8;   // float4 chunks per lane  ->  D <= 64 * 4 * 8 =
 // lives in registers, so a tight bound keeps the VGPR count low and the occupancy (= memory-level
 // parallelism of this HBM-bound kernel) high.
 
+// 16-byte / 8-byte loads with the non-temporal hint (lab: a stream that is read once need not displace what the next kernel will read)
+__device__ __forceinline__ float4 ld4(const float* p, bool nt) {
+    if (nt) { const f32x4_t t = __builtin_nontemporal_load((const f32x4_t*)p); return make_float4(t[0], t[1], t[2], t[3]); }
+    return *(const float4*)p;
+}
+__device__ __forceinline__ uint2 ld2u(const bf16_t* p, bool nt) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u2_t;
+    if (nt) { const u2_t t = __builtin_nontemporal_load((const u2_t*)p); return make_uint2(t[0], t[1]); }
+    return *(const uint2*)p;
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
     *(float4*)p = make_float4(a, b, c, d);
@@ -31,7 +41,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ b, OutT* __restrict__ y, int ldy,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      const int* __restrict__ row_map, int R, int D, float eps,
-                                                     const bf16_t* __restrict__ delta = nullptr, int ldd = 0, float* __restrict__ xo = nullptr, int ldxo = 0) {
+                                                     const bf16_t* __restrict__ delta = nullptr, int ldd = 0, float* __restrict__ xo = nullptr, int ldxo = 0,
+                                                     int nt_res = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
     // weights once per wave; two rows per iteration with both rows' loads issued first (HBM stream: more bytes in flight)
@@ -51,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
             for (int c = 0; c < MAXC; ++c) {
                 const int ch = lane + 64 * c;
-                v[q][c] = (ch < nch && r < R) ? *(const float4*)(x + (size_t)r * ldx + ch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[q][c] = (ch < nch && r < R) ? ld4(x + (size_t)r * ldx + ch * 4, nt_res & 2) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         if constexpr (RES) {
@@ -62,7 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 #pragma unroll
                 for (int c = 0; c < MAXC; ++c) {
                     const int ch = lane + 64 * c;
-                    dl[q][c] = (ch < nch && r < R) ? *(const uint2*)(delta + (size_t)r * ldd + ch * 4) : make_uint2(0u, 0u);
+                    dl[q][c] = (ch < nch && r < R) ? ld2u(delta + (size_t)r * ldd + ch * 4, nt_res & 2) : make_uint2(0u, 0u);
                 }
             }
 #pragma unroll
@@ -74,7 +85,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                     float d4[4];
                     unpack_bf4(dl[q][c], d4);
                     v[q][c].x += d4[0]; v[q][c].y += d4[1]; v[q][c].z += d4[2]; v[q][c].w += d4[3];
-                    if (ch < nch && r < R) *(float4*)(xo + (size_t)r * ldxo + ch * 4) = v[q][c];
+                    if (ch < nch && r < R) {
+                        if (nt_res & 1) __builtin_nontemporal_store(f32x4_t{v[q][c].x, v[q][c].y, v[q][c].z, v[q][c].w}, (f32x4_t*)(xo + (size_t)r * ldxo + ch * 4));
+                        else *(float4*)(xo + (size_t)r * ldxo + ch * 4) = v[q][c];
+                    }
                 }
             }
         }
@@ -117,6 +131,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w ;  dw += sum_r dy * xhat ;  db += sum_r dy
 // rows per workgroup (4 waves x 8 ... 32 rows): every workgroup ends with one fp32 atomic per column and gradient, all workgroups on the same
 // D addresses - the more rows a workgroup covers, the fewer of those (FOURM_LN_BWD_ROWS: lab)
+// lab (FOURM_LN_NT): bit 0 = the forward's new fp32 residual stream, bit 1 = the backward's fp32 residual gradient leave as non-temporal stores;
+// bit 2 = the forward's x / delta, bit 3 = the backward's dy / residual gradient, bit 4 = the backward's saved h arrive as non-temporal loads
+static int ln_nt_flags() {
+    static const int f = [] { const char* e = getenv("FOURM_LN_NT"); return e ? atoi(e) : 24; }();      // default: the backward's read-once streams (dy, the residual gradient, the saved h) as non-temporal loads: 56.73 -> 56.40 ms per 4M-B step same-box; the forward's (bits 0, 2) and the gradient store (bit 1) measured equal or worse
+    return f;
+}
 static int bwd_rows(int R) {
     static const int env = [] { const char* e = getenv("FOURM_LN_BWD_ROWS"); return e ? atoi(e) : 0; }();
     if (env >= 4) return env;
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* dres, float* dx, int lddx, bf16_t* __restrict__ dx_bf, int lddxbf,
-                                                     float* __restrict__ dw, float* __restrict__ db, int R, int D, int BWD_ROWS) {
+                                                     float* __restrict__ dw, float* __restrict__ db, int R, int D, int BWD_ROWS, int nt_dx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = (float*)smem;   // [2][4 waves][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,12 +192,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 dyp[q][c] = make_uint2(0u, 0u);
                 xv[q][c] = rv[q][c] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ch < nch && live[q]) {
-                    if (src >= 0) dyp[q][c] = *(const uint2*)(dy + (size_t)src * lddy + ch * 4);
+                    if (src >= 0) dyp[q][c] = ld2u(dy + (size_t)src * lddy + ch * 4, nt_dx & 2);
                     if constexpr (FROM_H) {
-                        hp[q][c] = *(const uint2*)(h + (size_t)rr * ldh + ch * 4);
+                        hp[q][c] = ld2u(h + (size_t)rr * ldh + ch * 4, nt_dx & 4);
                         if (from_x[c]) xv[q][c] = *(const float4*)(x + (size_t)rr * ldx + ch * 4);
                     } else xv[q][c] = *(const float4*)(x + (size_t)rr * ldx + ch * 4);
-                    if (dres) rv[q][c] = *(const float4*)(dres + (size_t)rr * lddx + ch * 4);
+                    if (dres) rv[q][c] = ld4(dres + (size_t)rr * lddx + ch * 4, nt_dx & 2);
                 }
             }
         }
@@ -216,7 +236,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     const float4 t = rv[q][c];
                     const float4 o = make_float4(rs[q] * (g[c].x - m1 - xh[c].x * m2) + t.x, rs[q] * (g[c].y - m1 - xh[c].y * m2) + t.y,
                                                  rs[q] * (g[c].z - m1 - xh[c].z * m2) + t.z, rs[q] * (g[c].w - m1 - xh[c].w * m2) + t.w);
-                    *(float4*)(dx + (size_t)r * lddx + ch * 4) = o;
+                    if (nt_dx & 1) __builtin_nontemporal_store(f32x4_t{o.x, o.y, o.z, o.w}, (f32x4_t*)(dx + (size_t)r * lddx + ch * 4));
+                    else *(float4*)(dx + (size_t)r * lddx + ch * 4) = o;
                     if (dx_bf) *(uint2*)(dx_bf + (size_t)r * lddxbf + ch * 4) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
                 }
             }
@@ -358,7 +379,7 @@ extern "C" int fm_layernorm_fwd_res(const void* x, int ldx, const void* delta, i
     if (grid > 256 * 16) grid = 256 * 16;
 #define LN_FWD(T, C)                                                                                                        \
     hipLaunchKernelGGL((ln_fwd_kernel<T, C, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (const float*)w, \
-                       (const float*)b, (T*)y, ldy, (float*)mean, (float*)rstd, row_map, R, D, eps, (const bf16_t*)delta, ldd, (float*)x_out, ldxo)
+                       (const float*)b, (T*)y, ldy, (float*)mean, (float*)rstd, row_map, R, D, eps, (const bf16_t*)delta, ldd, (float*)x_out, ldxo, (ln_nt_flags() & 1) | ((ln_nt_flags() >> 1) & 2))
 #define LN_FWD_C(T)                                    \
     switch (chunks_for(D)) {                           \
         case 2: LN_FWD(T, 2); break;                   \
@@ -390,7 +411,7 @@ static int layernorm_bwd_launch(const void* dy, int lddy, const int32_t* dy_row_
         (void)once;                                                                                                         \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dy, lddy, dy_row_map, (const bf16_t*)h, ldh, \
                            (const float*)x, ldx, (const float*)w, (const float*)mean, (const float*)rstd, (const float*)dres, (float*)dx, lddx, \
-                           (bf16_t*)dx_bf16, lddxbf, (float*)dw, (float*)db, R, D, BWD_ROWS);                               \
+                           (bf16_t*)dx_bf16, lddxbf, (float*)dw, (float*)db, R, D, BWD_ROWS, ((ln_nt_flags() >> 1) & 1) | ((ln_nt_flags() >> 2) & 2) | ((ln_nt_flags() >> 2) & 4));                               \
     }
 #define LN_BWD(C) { if (h) LN_BWD_(C, true) else LN_BWD_(C, false) }
     switch (chunks_for(D)) {
