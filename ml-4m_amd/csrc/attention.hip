@@ -77,6 +77,12 @@ __device__ __forceinline__ const char* tile_addr(const char* tile, int row, int 
 #ifndef ATTN_BWD_SAVED_NT
 #define ATTN_BWD_SAVED_NT 2          // (-DATTN_BWD_SAVED_NT=0: plain loads; 56.58 -> 56.36 ms per 4M-B step same-box, profiles/r06_ab_nontemporal.txt)
 #endif
+#ifndef ATTN_FWD_KV_NT
+#define ATTN_FWD_KV_NT 2             // k / v of the 128 x 128 forward as non-temporal LDS-DMA: they are not read again before the backward (56.85 -> 56.60 ms per step same-box; -DATTN_FWD_KV_NT=0: plain)
+#endif
+#ifndef ATTN_BWD_DO_NT
+#define ATTN_BWD_DO_NT 0             // lab build (-DATTN_BWD_DO_NT=2): dO of the 128 x 128 backward (just written by the proj dX GEMM, read once here) as non-temporal LDS-DMA
+#endif
 template <int NWAVES, int AUX = 0>
 __device__ __forceinline__ void stage_rows(const bf16_t* src, int ld, int row0, int limit, int rows, char* tile, int wave, int lane) {
     for (int p = wave; p < rows / 8; p += NWAVES) {
@@ -346,8 +352,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd128_kernel(AttnArgs a) {
     const bf16_t* Kb = a.K + (size_t)b * a.kvr * a.ldk + h * HD;
     const bf16_t* Vb = a.V + (size_t)b * a.kvr * a.ldv + h * HD;
 
-    stage_rows<4>(Kb, a.ldk, 0, N, N, Kt, wave, lane);
-    stage_rows<4>(Vb, a.ldv, 0, N, N, Vt, wave, lane);
+    stage_rows<4, ATTN_FWD_KV_NT>(Kb, a.ldk, 0, N, N, Kt, wave, lane);
+    stage_rows<4, ATTN_FWD_KV_NT>(Vb, a.ldv, 0, N, N, Vt, wave, lane);
     bf16x8_t qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8_t*)(Qb + (size_t)q * a.ldq + (kk * 2 + fhi) * 8);
@@ -1093,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd128_kernel(AttnArgs a) {
     const bf16_t* dOb = a.dO + (size_t)b * N * a.lddo + h * HD;
 
     stage_rows<4, ATTN_BWD_SAVED_NT>(Qb, a.ldq, 0, N, N, T0, wave, lane);
-    stage_rows<4>(dOb, a.lddo, 0, N, N, T1, wave, lane);
+    stage_rows<4, ATTN_BWD_DO_NT>(dOb, a.lddo, 0, N, N, T1, wave, lane);
     const int key = wave * 32 + (lane & 31);             // pass A: this lane's key
     bf16x8_t kf[4], vf[4];
 #if ATTN_KV_DMA
@@ -1407,9 +1413,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd128o_kernel(AttnArgs a) {
         const int t = p * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ sw3(t);
         const uint32_t dst = (p >> 2) * RG + (p & 3) * 1024;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(Qb + (size_t)t * a.ldq + lc * 8), LDS_PTR(smem + dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(dOb + (size_t)t * a.lddo + lc * 8), LDS_PTR(smem + dst + 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(Kb + (size_t)t * a.ldk + lc * 8), LDS_PTR(smem + oK + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(Qb + (size_t)t * a.ldq + lc * 8), LDS_PTR(smem + dst), 16, 0, ATTN_BWD_SAVED_NT);      // (saved q / k: read once)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(dOb + (size_t)t * a.lddo + lc * 8), LDS_PTR(smem + dst + 4096), 16, 0, ATTN_BWD_DO_NT);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(Kb + (size_t)t * a.ldk + lc * 8), LDS_PTR(smem + oK + p * 1024), 16, 0, ATTN_BWD_SAVED_NT);
     }
     const int key = wave * 32 + r31;                     // pass A: this lane's key
     bf16x8_t vf[4];
