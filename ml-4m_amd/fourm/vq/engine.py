@@ -86,8 +86,11 @@ def _pos_rows(eng, vit, B, nh, nw, Rp):
             t = F.interpolate(t, size=(nh, nw), mode="bicubic", align_corners=False)
         pos = torch.zeros(Rp, eng.D, dtype=torch.float32, device=t.device)
         pos[:B * nh * nw] = t[0].permute(1, 2, 0).reshape(nh * nw, eng.D).repeat(B, 1)
-        eng._cache = {k: v for k, v in eng._cache.items() if not (isinstance(k, tuple) and k[0] == "pos")}
+        # drop the tables of an OLDER position embedding only: one table per batch size stays (sub-batches of different sizes may be in flight on
+        # several streams, fourm.vq.tokenize_sub_batches - freeing the other size's table under a running GEMM corrupted its residual operand)
+        eng._cache = {k: v for k, v in eng._cache.items() if not (isinstance(k, tuple) and k[0] == "pos" and k[4:] != key[4:])}
         eng._cache[key] = pos
+        torch.cuda.current_stream(pos.device).synchronize()        # (built once per batch size: complete before any other stream may pick it up)
     return pos
 
 

@@ -90,7 +90,7 @@ def test_tokenize_sub_batches_in_flight_on_several_streams():
     subs = [torch.rand(16 if i % 3 else 24, 3, 224, 224, device="cuda") * 2 - 1 for i in range(7)]        # ragged sub-batch sizes
     want = [model.tokenize(x).clone() for x in subs]
     for n in (2, 3, 1):
-        for _ in range(2):
+        for _ in range(6):
             got = tokenize_sub_batches(model, subs, n_streams=n)
             torch.cuda.synchronize()
             assert len(got) == len(want) and all(torch.equal(g, w) for g, w in zip(got, want)), n
