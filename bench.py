@@ -601,10 +601,13 @@ def main_divae(a):
         prof = LaunchProfiler()
         quant = model.tokens_to_embedding(toks[0]).float()
         x = torch.randn(batch, 3, 224, 224, device=dev)
+        import fourm.vq.models.unet.unet as unet_mod
+        graph_on, unet_mod.UNET_GRAPH = unet_mod.UNET_GRAPH, False          # (the launch events ride on the eager launch sequence, not on graph replays)
         ops.set_profiler(prof)
         for _ in range(2):
             model.decoder(x, 500, quant)
         ops.set_profiler(None)
+        unet_mod.UNET_GRAPH = graph_on
         agg = prof.summary()
         tot_ms = sum(d["ms"] for d in agg.values()) or 1.0
         gemms = {k: v for k, v in agg.items() if v["flops"]}
