@@ -28,7 +28,7 @@ def up_to_date(srcs) -> bool:
     if not os.path.exists(OUT):
         return False
     t = os.path.getmtime(OUT)
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(ROOT, "include", "fourm_hip.h"), __file__]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_args.h"), os.path.join(CSRC, "agpr_mfma.h"), os.path.join(ROOT, "include", "fourm_hip.h"), __file__]
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
@@ -45,7 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(objdir, os.path.basename(s) + ".o")
         objs.append(o)
         if not force and os.path.exists(o) and os.path.getmtime(o) >= max(
-                os.path.getmtime(s), os.path.getmtime(os.path.join(CSRC, "common.h")), os.path.getmtime(os.path.join(CSRC, "gemm_args.h")),
+                os.path.getmtime(s), os.path.getmtime(os.path.join(CSRC, "common.h")), os.path.getmtime(os.path.join(CSRC, "gemm_args.h")), os.path.getmtime(os.path.join(CSRC, "agpr_mfma.h")),
                 os.path.getmtime(os.path.join(ROOT, "include", "fourm_hip.h"))):
             continue
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
