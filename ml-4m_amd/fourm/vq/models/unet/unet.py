@@ -329,6 +329,8 @@ class _UNetEngine:
                     st["out"] = self.forward(st["x"], st["t"], st["c"], st["m"])
             finally:
                 ops.SCRATCH_TAG = None
+            while len(self._graphs) >= 6:                      # (a graph keeps its scratch: bound what a stream of changing shapes can pile up)
+                self._graphs.pop(next(iter(self._graphs)))
             g = self._graphs[key] = (graph, st)
         graph, st = g
         st["x"].copy_(sample.detach())
