@@ -305,7 +305,8 @@ int launch_nt4(NTArgs a, hipStream_t s) {
 
 }  // namespace
 
-// mode: bit 0 = take N % 384 == 0 on 256 x 384 tiles, bit 1 = take N % 256 == 0 on 4-wave 256 x 256 tiles, bit 2 = legacy (unstaged) stores.
+// mode: bit 0 = take N % 384 == 0 on 256 x 384 tiles (when that costs no more rounds x width than gemm_nt3's tiles), bit 1 = take N % 256 == 0 on 4-wave
+// 256 x 256 tiles, bit 2 = legacy (unstaged) stores, bit 3 = lab: bit 0 whatever the rounds.
 // Returns 1 when it took the launch, 0 when the arguments are outside what it handles, < 0 on a launch error.
 int fm_launch_nt4(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     using namespace fmk;
@@ -313,7 +314,16 @@ int fm_launch_nt4(const fmk::NTArgs& a, int epilogue, int mode, hipStream_t s) {
     if (a.M % 256 != 0 || a.M < 2048 || a.K % 64 != 0 || a.K < 192 || a.ldo % 64 != 0 || (((uintptr_t)a.out) & 127) != 0) return 0;
     if ((size_t)384 * (size_t)a.ldo * 2 >= 0x7fffffffull || (size_t)384 * (size_t)a.ldx * 2 >= 0x7fffffffull || (size_t)384 * (size_t)a.ldw * 2 >= 0x7fffffffull) return 0;
     const bool stg = !(mode & 4);
-    if ((mode & 1) && a.N % 384 == 0) return stg ? launch_nt4<384, 256, 2, 2, true>(a, s) : launch_nt4<384, 256, 2, 2, false>(a, s);
+    if ((mode & 1) && a.N % 384 == 0) {
+        // Rounds x tile width, like gemm_nt3's choice between its 256- and 192-wide tiles: with CUs reserved for RCCL (fm_set_reserved_cus: 240 of 256)
+        // N = 768 is 256 tiles of 256 x 384 = TWO rounds (cost 768) where gemm_nt3's 256-wide tiles need two rounds of 256 (cost 512) - the launch
+        // then goes to gemm_nt3.  On all 256 CUs the costs tie (384 = 2 x 192, 1152 = 6 x 192) and this kernel wins on requests per multiply-add.
+        const long cus = fm_grid_cus(), xt = a.M / 256;
+        const long c4 = ((long)(a.N / 384) * xt + cus - 1) / cus * 384;
+        const long c256 = ((long)((a.N + 255) / 256) * xt + cus - 1) / cus * 256, c192 = a.N % 192 == 0 ? ((long)(a.N / 192) * xt + cus - 1) / cus * 192 : c256;
+        if (c4 > (c256 < c192 ? c256 : c192) && !(mode & 8)) return 0;          // (mode bit 3: lab - take the launch whatever the rounds)
+        return stg ? launch_nt4<384, 256, 2, 2, true>(a, s) : launch_nt4<384, 256, 2, 2, false>(a, s);
+    }
     if ((mode & 2) && a.N % 256 == 0) return stg ? launch_nt4<256, 256, 2, 2, true>(a, s) : launch_nt4<256, 256, 2, 2, false>(a, s);
     return 0;
 }

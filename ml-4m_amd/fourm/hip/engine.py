@@ -48,6 +48,8 @@ HOIST_CTX = os.environ.get("FOURM_HOIST_CTX", "1") == "1"
 # instead of (x - mean) * rstd from the fp32 input: 14 instead of 16 bytes per element of an HBM-bound kernel (fm_layernorm_bwd_h).
 # x_hat then carries h's bf16 rounding (2^-9 relative - the operand the forward GEMMs used).  FOURM_LN_BWD_FROM_H=0: from x, as upstream's fp32 norm.
 LN_BWD_FROM_H = os.environ.get("FOURM_LN_BWD_FROM_H", "1") == "1"
+# lab: keep the data-parallel CU reservation for the whole step (the behaviour up to round 5) instead of the backward only
+DP_RESERVE_ALWAYS = os.environ.get("FOURM_DP_RESERVE_ALWAYS", "0") == "1"
 
 
 def bump_weight_epoch():
@@ -1073,6 +1075,11 @@ class FourMEngine:
         self._ctx, self._dw_jobs = None, None
         if self.reducer is not None:
             self.reducer.begin()
+            # CUs left free of the persistent GEMM grids for RCCL's kernels: only while an exchange can be in flight, i.e. from here to finish() -
+            # the forward runs on every CU (with 16 of 256 reserved the dense GEMM family loses its whole-round tilings: +3.6 ms per 4M-B step
+            # when the reservation covers the whole step, profiles/r06_reserved_cus.txt)
+            if getattr(self.reducer, "reserved_cus", 0):
+                L.lib.fm_set_reserved_cus(int(self.reducer.reserved_cus))
         m, ws = self.model, self.ws
         enc, dec, st, hs = c["enc"], c["dec"], c["st"], c["hs"]
         B, N, Mt, D = enc["B"], enc["Nt"], dec["Nt"], self.D
@@ -1161,3 +1168,5 @@ class FourMEngine:
         self._embed_bwd(enc, ge, dctx, False)
         if self.reducer is not None:
             self.reducer.finish()        # remaining slices + wait: gradients are averaged when backward returns
+            if getattr(self.reducer, "reserved_cus", 0) and not DP_RESERVE_ALWAYS:
+                L.lib.fm_set_reserved_cus(0)

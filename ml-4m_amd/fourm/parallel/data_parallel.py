@@ -332,9 +332,8 @@ class DataParallel(nn.Module):
                                         comm=self._comm if eng.flat_grads.is_cuda and dist.get_backend(self.process_group) == "nccl" else "torch")
             self._reducer_for = eng.flat_grads
             self._reducer.time_exchange = bool(getattr(self, "time_exchange", False))
-            if eng.flat_grads.is_cuda and dist.get_backend(self.process_group) == "nccl":
-                from fourm.hip import _lib
-                _lib.lib.fm_set_reserved_cus(self._reserved_cus)       # RCCL's kernels run beside the persistent GEMM grids
+            # RCCL's kernels run beside the persistent GEMM grids: the engine reserves the CUs for the span of the backward (begin() ... finish())
+            self._reducer.reserved_cus = self._reserved_cus if (eng.flat_grads.is_cuda and dist.get_backend(self.process_group) == "nccl") else 0
         eng.reducer = self._reducer if self._sync else None
 
     def forward(self, *args, **kwargs):
